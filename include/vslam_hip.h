@@ -1,0 +1,284 @@
+/*
+ * vslam_hip.h -- C ABI of the MI355X-native (gfx950) visual-SLAM hot path.
+ *
+ * The reference (yunjinli/visual-slam) has no plugin/FFI layer: its "operator
+ * API" is the set of free functions in include/visnav/*.h that src/slam.cpp
+ * calls directly.  Every entry point below is what a thin C++ wrapper with the
+ * reference's own signature binds to (the wrappers live in
+ * include/visnav_amd/*.h; the reference-side patch is shown in INTEGRATION.md).
+ * Each declaration cites the reference interface it replaces (file:line,
+ * relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - unless a function name ends in `_dev`, every pointer is a HOST pointer
+ *     owned by the caller, and the call is synchronous w.r.t. its outputs;
+ *   - return value: VSL_OK (0) or a negative VSL_ERR_* code; nothing throws;
+ *   - a vsl_ctx owns one HIP stream plus its scratch; calls on DIFFERENT
+ *     contexts may run concurrently from different host threads (the reference
+ *     has up to three threads inside this path: main, opt_thread,
+ *     global_ba_thread -- src/slam.cpp:1557, :1780); one context must not be
+ *     used from two threads at once;
+ *   - there is NO CPU fallback: without a HIP device vsl_ctx_create fails with
+ *     VSL_ERR_NO_DEVICE and nothing else can be called.
+ *
+ * Descriptor layout: 256 bits as 4 x uint64_t, bit i in word i/64 at position
+ * i%64 -- the libstdc++ layout of std::bitset<256>
+ * (include/visnav/common_types.h:120), so
+ * reinterpret_cast<const uint64_t*>(vector<bitset<256>>::data()) is the
+ * argument.
+ */
+#ifndef VSLAM_HIP_H
+#define VSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSL_OK 0
+#define VSL_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, ...) */
+#define VSL_ERR_HIP (-2)       /* a HIP runtime call failed; see vsl_last_error  */
+#define VSL_ERR_NOMEM (-3)     /* host or device allocation failed               */
+#define VSL_ERR_CAPACITY (-4)  /* caller-provided output capacity too small      */
+#define VSL_ERR_NO_DEVICE (-5) /* no HIP device / extension unusable             */
+#define VSL_ERR_IO (-6)        /* file could not be read / parsed                */
+#define VSL_ERR_NUMERIC (-7)   /* linear solve failed (non-finite / not SPD)     */
+
+typedef struct vsl_ctx vsl_ctx;
+
+/* ---------------------------------------------------------------- context */
+
+const char* vsl_version(void);
+/* Human-readable text of the last failure on this context (never NULL). */
+const char* vsl_last_error(const vsl_ctx* ctx);
+/* Number of HIP devices visible to the process (0 if none / no runtime). */
+int vsl_device_count(void);
+
+/* Create a context on `device` with its own non-blocking HIP stream. */
+int vsl_ctx_create(int device, vsl_ctx** out);
+/* Create a context that enqueues on an existing hipStream_t (e.g. the stream a
+ * caller times with its own events).  The stream is borrowed, not owned. */
+int vsl_ctx_create_on_stream(int device, void* hip_stream, vsl_ctx** out);
+int vsl_ctx_destroy(vsl_ctx* ctx);
+int vsl_ctx_synchronize(vsl_ctx* ctx);
+/* The hipStream_t this context enqueues on. */
+void* vsl_ctx_stream(vsl_ctx* ctx);
+
+/* Per-stage device timing with hipEvents on the context's stream.  When
+ * enabled, every kernel stage is bracketed by events; vsl_ctx_stage_ms returns
+ * the accumulated milliseconds and launch count per stage since the last
+ * reset (this synchronizes the stream). */
+enum {
+  VSL_STAGE_RESPONSE = 0, /* K1 min-eigenvalue response + candidates          */
+  VSL_STAGE_SELECT = 1,   /* K2 sort + greedy min-distance selection          */
+  VSL_STAGE_DESCRIBE = 2, /* K3+K4 orientation + rBRIEF-256                   */
+  VSL_STAGE_MATCH = 3,    /* K5 Hamming best/second-best, both directions     */
+  VSL_STAGE_MATCH_FIN = 4,/* K5 ratio test + cross-check + ordered emit       */
+  VSL_STAGE_BA_LIN = 5,   /* K6 residual + Jacobian blocks                    */
+  VSL_STAGE_BA_SCHUR = 6, /* K7 Schur-complement reduction                    */
+  VSL_STAGE_BA_SOLVE = 7, /* reduced camera system Cholesky + back-subst.     */
+  VSL_STAGE_BOW_TRANSFORM = 8,
+  VSL_STAGE_BOW_SCORE = 9,
+  VSL_STAGE_COUNT = 10
+};
+int vsl_ctx_set_profiling(vsl_ctx* ctx, int enabled);
+int vsl_ctx_stage_ms(vsl_ctx* ctx, int stage, double* total_ms, int64_t* launches);
+int vsl_ctx_reset_profiling(vsl_ctx* ctx);
+
+/* ------------------------------------------------- keypoints (host buffers) */
+
+/* Replaces visnav::detectKeypointsAndDescriptors (include/visnav/keypoints.h:223-229)
+ * = detectKeypoints (:133-150) -> computeAngles (:152-189) -> computeDescriptors
+ * (:191-221).  img: 8-bit gray, `pitch` bytes per row.  Outputs, for
+ * i < *n_out <= cap: corners_xy[2i], [2i+1] (integer-valued doubles, order =
+ * descending corner response), angles[i] (radians), desc[4i..4i+3].
+ * Detector semantics = cv::goodFeaturesToTrack(img, num_features, 0.01, 8,
+ * noArray(), 3, false) followed by InBounds(x, y, 19). */
+int vsl_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch,
+                        int num_features, int rotate_features, int cap,
+                        double* corners_xy, double* angles, uint64_t* desc, int* n_out);
+
+/* Replaces visnav::detectKeypoints (include/visnav/keypoints.h:133-150). */
+int vsl_detect_keypoints(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch,
+                         int num_features, int cap, double* corners_xy, int* n_out);
+
+/* Replaces visnav::computeAngles (include/visnav/keypoints.h:152-189).
+ * corners_xy: n points (truncated to int like the reference, :159-160). */
+int vsl_compute_angles(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch,
+                       const double* corners_xy, int n, int rotate_features, double* angles);
+
+/* Replaces visnav::computeDescriptors (include/visnav/keypoints.h:191-221):
+ * descriptors from caller-provided corners and angles. */
+int vsl_compute_descriptors(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch,
+                            const double* corners_xy, const double* angles, int n,
+                            uint64_t* desc);
+
+/* Raw K1 output for parity tests: fp32 min-eigenvalue response (w*h floats,
+ * dense rows), the quantity cv::cornerMinEigenVal(img, 3, 3) produces inside
+ * goodFeaturesToTrack (called at include/visnav/keypoints.h:138). */
+int vsl_min_eig_response(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch,
+                         float* response);
+
+/* --------------------------------------------------- matcher (host buffers) */
+
+/* Replaces visnav::matchDescriptors (include/visnav/keypoints.h:323-369,
+ * helper isPQiffQP :278-313): best / second-best Hamming with strict-<
+ * (lowest index wins ties), reject best >= threshold, reject
+ * second < best * dist_2_best (double), mutual cross-check with the same
+ * tests.  pairs: (i, j) with ascending i, capacity 2*min(n1,n2) int32. */
+int vsl_match_descriptors(vsl_ctx* ctx, const uint64_t* d1, int n1, const uint64_t* d2, int n2,
+                          int threshold, double dist_2_best, int32_t* pairs, int* n_out);
+
+/* ------------------------------------- device-resident batched frame store */
+/*
+ * The throughput path: B images live in HBM; detect/describe runs over a range
+ * of slots per call (one launch set for the whole range), stereo / temporal
+ * matching runs over a list of (slot_a, slot_b) pairs per call.  Nothing
+ * returns to the host until a download call.  All enqueue on ctx's stream.
+ */
+typedef struct vsl_frames vsl_frames;
+
+int vsl_frames_create(vsl_ctx* ctx, int max_images, int w, int h, int max_features,
+                      int max_pairs, vsl_frames** out);
+int vsl_frames_destroy(vsl_frames* f);
+/* Device pointer to slot 0 of the image store: max_images dense w*h u8 images,
+ * image k at base + k*w*h.  A caller may fill it directly (e.g. from a device
+ * tensor); `_dev` marks the pointer as a device pointer. */
+void* vsl_frames_images_dev(vsl_frames* f);
+/* Copy n host images (row pitch `pitch`, image stride `img_stride` bytes) into
+ * slots [first, first+n). */
+int vsl_frames_upload(vsl_ctx* ctx, vsl_frames* f, int first, int n, const uint8_t* imgs,
+                      size_t pitch, size_t img_stride);
+/* detectKeypointsAndDescriptors over slots [first, first+n) (asynchronous). */
+int vsl_frames_detect_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features,
+                               int rotate_features);
+/* matchDescriptors for n_pairs (slot_a, slot_b) pairs; slot_pairs is a HOST
+ * array of 2*n_pairs slot indices; results land in pair slots [0, n_pairs)
+ * (asynchronous). */
+int vsl_frames_match(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_pairs,
+                     int threshold, double dist_2_best);
+/* Synchronize and copy one image's keypoints out (same layout as
+ * vsl_detect_describe). */
+int vsl_frames_download_keypoints(vsl_ctx* ctx, vsl_frames* f, int slot, int cap,
+                                  double* corners_xy, double* angles, uint64_t* desc, int* n_out);
+/* Synchronize and copy one pair's match list out (capacity 2*max_features). */
+int vsl_frames_download_matches(vsl_ctx* ctx, vsl_frames* f, int pair, int cap_pairs,
+                                int32_t* pairs, int* n_out);
+/* Synchronize and copy only the per-image keypoint counts / per-pair match
+ * counts (cheap completeness check for benchmarks). */
+int vsl_frames_download_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_t* n_keypoints,
+                               int n_pairs, int32_t* n_matches);
+
+/* -------------------------------------------------------- bundle adjustment */
+/*
+ * Replaces visnav::bundle_adjustment (include/visnav/map_utils.h:337-421) and
+ * visnav::global_bundle_adjustment (include/visnav/loop_closure_utils.h:672-748):
+ * the caller flattens Cameras / Landmarks / Corners to the arrays below
+ * (include/visnav_amd/bundle_adjustment.h does that for the reference types).
+ * Cost functor = BundleAdjustmentReprojectionCostFunctor
+ * (include/visnav/reprojection.h:81-105) with the camera models of
+ * include/visnav/camera_models.h, pose update = T * exp(delta)
+ * (include/visnav/local_parameterization_se3.hpp:43-50), loss = Huber
+ * (map_utils.h:384-387), solver = Levenberg-Marquardt with Schur elimination
+ * of the landmark blocks (map_utils.h:406-411: SPARSE_SCHUR, 20 iterations).
+ */
+enum { VSL_CAM_DS = 0, VSL_CAM_PINHOLE = 1, VSL_CAM_EUCM = 2, VSL_CAM_KB4 = 3 };
+
+typedef struct vsl_ba_problem {
+  int32_t n_cams;           /* camera poses (left and right are separate blocks)   */
+  int32_t n_lms;            /* landmarks                                           */
+  int32_t n_obs;            /* observations = residual blocks                      */
+  int32_t cam_model[2];     /* VSL_CAM_* of intrinsics[0], intrinsics[1]           */
+  double* poses;            /* [7*n_cams] qx qy qz qw tx ty tz (T_w_c), in/out     */
+  const uint8_t* cam_fixed; /* [n_cams] 1 = SetParameterBlockConstant              */
+  const int32_t* cam_intr;  /* [n_cams] 0/1: which intrinsics block (fcid.cam_id)  */
+  const double* intr;       /* [16] two 8-vectors fx fy cx cy p1..p4 (constant)    */
+  double* points;           /* [3*n_lms] in/out                                    */
+  const int32_t* obs_cam;   /* [n_obs]                                             */
+  const int32_t* obs_lm;    /* [n_obs]                                             */
+  const double* obs_uv;     /* [2*n_obs] detected corner (p_2d)                    */
+} vsl_ba_problem;
+
+typedef struct vsl_ba_options {
+  int32_t use_huber;          /* BundleAdjustmentOptions::use_huber (map_utils.h:326) */
+  double huber_parameter;     /* :329, pixels                                         */
+  int32_t max_num_iterations; /* :332                                                 */
+  int32_t verbosity;          /* 0 silent, 1 one line, 2 per-iteration table (stderr) */
+} vsl_ba_options;
+
+typedef struct vsl_ba_summary {
+  double initial_cost, final_cost;
+  int32_t iterations;            /* LM iterations run (successful + unsuccessful) */
+  int32_t successful_steps;
+  int32_t termination;           /* 0 no-convergence(max iters) 1 function tol 2 gradient tol
+                                    3 parameter tol 4 failure                      */
+  double linearize_ms, schur_ms, solve_ms, total_ms; /* device time, summed */
+} vsl_ba_summary;
+
+int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
+                      vsl_ba_summary* summary);
+
+/* One linearization at the current poses/points, for parity tests and for the
+ * multi-GPU global-BA path (each rank reduces its landmark range; S and g are
+ * then summed with an all-reduce).  Cameras are numbered by free-camera index
+ * c (fixed cameras skipped, ascending camera id); n_free = #free cameras.
+ *   S  [(6*n_free)^2] row-major, = sum_c F^T F  -  sum_l (F^T E) (E^T E)^-1 (E^T F)
+ *   g  [6*n_free]             , = sum F^T r     -  sum_l (F^T E) (E^T E)^-1 (E^T r)
+ *   cost = 1/2 sum rho(|r|^2)
+ * computed WITHOUT Jacobi scaling or LM damping (mu = 0), with the Huber
+ * corrector applied (residual and Jacobian scaled by sqrt(rho')).
+ * lm_first/lm_count restrict the reduction to landmarks [lm_first,
+ * lm_first+lm_count) and their observations (lm_count < 0: all). */
+int vsl_ba_linearize(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
+                     int lm_first, int lm_count, double* S, double* g, double* cost, int* n_free);
+
+/* Residual r (2) and Jacobian blocks J_pose (2x6 row-major, tangent
+ * (upsilon, omega) of T*exp(delta)) and J_point (2x3) per observation, raw
+ * (no robust scaling) -- parity hook for K6. */
+int vsl_ba_residuals_jacobians(vsl_ctx* ctx, const vsl_ba_problem* prob, double* r, double* J_pose,
+                               double* J_point);
+
+/* --------------------------------------------------------------- DBoW2 path */
+/*
+ * Replaces, for loop-closure candidate scoring:
+ *   ORBVocabulary::loadFromTextFile (thirdparty/DBoW2_ORBSLAM/DBoW2/TemplatedVocabulary.h:1338-1424)
+ *   ORBVocabulary::transform        (TemplatedVocabulary.h:1127-1194, :1218-1259; FORB::distance FORB.cpp:81-101)
+ *   ORBVocabulary::score            (TemplatedVocabulary.h:1199-1203 -> L1Scoring::score, ScoringObject.cpp:23-68)
+ * Only TF_IDF weighting + L1 scoring (what ORBvoc.txt declares and the only
+ * combination the reference exercises) is implemented; other header values
+ * make vsl_voc_load_text fail with VSL_ERR_INVALID.
+ */
+typedef struct vsl_voc vsl_voc;
+
+int vsl_voc_load_text(vsl_ctx* ctx, const char* path, vsl_voc** out);
+int vsl_voc_destroy(vsl_voc* voc);
+/* k, L, number of nodes (root included), number of words. */
+int vsl_voc_info(const vsl_voc* voc, int* k, int* L, int* n_nodes, int* n_words);
+
+/* desc32: n descriptors of 32 bytes in DBoW2/cv::Mat byte order (MSB-first
+ * within each byte, include/visnav/converter.h:23-33).  Outputs: the BowVector
+ * as (word_ids ascending, word_vals L1-normalised) with *nnz entries
+ * (capacity n), and the FeatureVector flattened as (fv_node[i], fv_feat[i])
+ * sorted by (node, feature index), *fv_n entries (capacity n). */
+int vsl_bow_transform(vsl_ctx* ctx, const vsl_voc* voc, const uint8_t* desc32, int n, int levelsup,
+                      uint32_t* word_ids, double* word_vals, int* nnz, uint32_t* fv_node,
+                      uint32_t* fv_feat, int* fv_n);
+
+/* L1 score of one query BowVector against m candidates given in CSR form
+ * (c_offsets[m+1]); ids ascending within each vector. */
+int vsl_bow_score_batch(vsl_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int q_nnz,
+                        const uint32_t* c_ids, const double* c_vals, const int32_t* c_offsets,
+                        int m, double* scores);
+
+/* Bit-order converters of include/visnav/converter.h:23-33 and :50-61
+ * (bitset<256> word layout <-> 32-byte MSB-first row).  Pure host helpers. */
+void vsl_desc_bitset_to_bytes(const uint64_t* desc, int n, uint8_t* desc32);
+void vsl_desc_bytes_to_bitset(const uint8_t* desc32, int n, uint64_t* desc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_H */

@@ -1,0 +1,129 @@
+/*
+ * vslam_oracle.h -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library -- as the checker / the timed CPU baseline, never as part of the
+ * product path (visual-slam_amd/ never includes, links or dlopens it).
+ *
+ * PARITY PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - The reference itself cannot be compiled here (OpenCV, Eigen, Sophus, Ceres,
+ *     Pangolin, TBB are empty submodules) and its tests hold no
+ *     golden vectors for this path, so every function below whose
+ *     semantics come from those third-party libraries is "parity unpinned"
+ *     against the real binary:
+ *        cv::goodFeaturesToTrack (OpenCV 4.7 imgproc)      -- orc_min_eig_response, orc_good_features
+ *        ceres::Solve (Ceres 2.0/2.1 LM + SPARSE_SCHUR)    -- orc_bundle_adjust
+ *        Sophus SE3 exp / Dx_this_mul_exp_x_at_0           -- orc_ba_*
+ *   - Functions that restate code that IS in the reference tree, line by line in
+ *     behaviour, are pinned by hand-checkable known-answer tests
+ *     (tests/test_oracle_kat.py) and by the one assertion the reference's own
+ *     tests make (bitset <-> cv::Mat round trip,
+ *     test/src/test_loop_closure_utils.cpp:152-159):
+ *        computeAngles / computeDescriptors / matchDescriptors (keypoints.h)
+ *        camera project() x4 (camera_models.h), the BA functor (reprojection.h)
+ *        DBoW2 transform / L1 score / BowVector::normalize
+ */
+#ifndef VSLAM_ORACLE_H
+#define VSLAM_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- keypoints.h ---------------------------------------------------------- */
+/* [upstream] cv::cornerMinEigenVal(img, blockSize=3, ksize=3) as called inside
+ * goodFeaturesToTrack (keypoints.h:138). resp: w*h floats. */
+void orc_min_eig_response(const uint8_t* img, int w, int h, size_t pitch, float* resp);
+/* [upstream] cv::goodFeaturesToTrack(img, max_corners, quality, min_dist, noArray(), 3, false).
+ * xy: 2*max_corners ints.  Returns the number of corners. */
+int orc_good_features(const uint8_t* img, int w, int h, size_t pitch, int max_corners, double quality,
+                      double min_dist, int* xy, float* response_out /* nullable */);
+/* keypoints.h:133-150 */
+int orc_detect_keypoints(const uint8_t* img, int w, int h, size_t pitch, int num_features,
+                         double* corners_xy);
+/* keypoints.h:152-189 */
+void orc_compute_angles(const uint8_t* img, int w, int h, size_t pitch, const double* corners_xy,
+                        int n, int rotate_features, double* angles);
+/* Integer image moments of the same loop (m01, m10), exact. */
+void orc_patch_moments(const uint8_t* img, int w, int h, size_t pitch, const double* corners_xy,
+                       int n, int64_t* m01, int64_t* m10);
+/* keypoints.h:191-221 (faithful: 8 libm calls per descriptor bit) */
+void orc_compute_descriptors(const uint8_t* img, int w, int h, size_t pitch, const double* corners_xy,
+                             const double* angles, int n, uint64_t* desc);
+/* keypoints.h:223-229; cap = num_features */
+int orc_detect_describe(const uint8_t* img, int w, int h, size_t pitch, int num_features,
+                        int rotate_features, double* corners_xy, double* angles, uint64_t* desc);
+/* keypoints.h:323-369 + :278-313.  pairs capacity 2*n1.  Returns #matches. */
+int orc_match_descriptors(const uint64_t* d1, int n1, const uint64_t* d2, int n2, int threshold,
+                          double dist_2_best, int32_t* pairs);
+/* converter.h:23-33, :50-61 */
+void orc_bitset_to_bytes(const uint64_t* desc, uint8_t* out32);
+void orc_bytes_to_bitset(const uint8_t* in32, uint64_t* desc);
+
+/* ---- DBoW2 ---------------------------------------------------------------- */
+typedef struct orc_voc orc_voc;
+orc_voc* orc_voc_load_text(const char* path); /* TemplatedVocabulary.h:1338-1424 */
+void orc_voc_free(orc_voc*);
+void orc_voc_info(const orc_voc*, int* k, int* L, int* n_nodes, int* n_words);
+/* TemplatedVocabulary.h:1127-1194 (+ :1218-1259, FORB.cpp:81-101, BowVector.cpp:34-84,
+ * FeatureVector.cpp:30-44).  Capacities: n each. */
+void orc_bow_transform(const orc_voc*, const uint8_t* desc32, int n, int levelsup, uint32_t* word_ids,
+                       double* word_vals, int* nnz, uint32_t* fv_node, uint32_t* fv_feat, int* fv_n);
+/* ScoringObject.cpp:23-68 */
+double orc_bow_score_l1(const uint32_t* ids1, const double* v1, int n1, const uint32_t* ids2,
+                        const double* v2, int n2);
+
+/* ---- bundle adjustment ----------------------------------------------------- */
+/* camera_models.h project(): model 0 ds (:246-270), 1 pinhole (:75-94), 2 eucm (:158-178),
+ * 3 kb4 (:341-374) */
+void orc_project(int model, const double* intr8, const double* p3, double* uv2);
+/* reprojection.h:81-105: residual = p_2d - project(T_w_c^-1 * p_w) */
+void orc_ba_residual(int model, const double* pose7, const double* point3, const double* intr8,
+                     const double* uv2, double* r2);
+/* The same through dual numbers, like Ceres AutoDiffCostFunction<.,2,7,3,8> followed by
+ * LocalParameterizationSE3::ComputeJacobian (local_parameterization_se3.hpp:56-63):
+ * J_pose 2x6 row-major (upsilon, omega), J_point 2x3 row-major. */
+void orc_ba_residual_jacobian(int model, const double* pose7, const double* point3,
+                              const double* intr8, const double* uv2, double* r2, double* J_pose,
+                              double* J_point);
+/* local_parameterization_se3.hpp:43-50: T_plus = T * exp(delta), delta = (upsilon, omega). */
+void orc_se3_plus(const double* pose7, const double* delta6, double* out7);
+
+typedef struct orc_ba_problem {
+  int32_t n_cams, n_lms, n_obs;
+  int32_t cam_model[2];
+  double* poses;
+  const uint8_t* cam_fixed;
+  const int32_t* cam_intr;
+  const double* intr;
+  double* points;
+  const int32_t* obs_cam;
+  const int32_t* obs_lm;
+  const double* obs_uv;
+} orc_ba_problem;
+
+typedef struct orc_ba_options {
+  int32_t use_huber;
+  double huber_parameter;
+  int32_t max_num_iterations;
+  int32_t verbosity;
+  int32_t num_threads; /* residual/Jacobian evaluation threads (ceres_options.num_threads, map_utils.h:409) */
+} orc_ba_options;
+
+typedef struct orc_ba_summary {
+  double initial_cost, final_cost;
+  int32_t iterations, successful_steps, termination;
+  double linearize_ms, schur_ms, solve_ms, total_ms;
+} orc_ba_summary;
+
+/* S, g, cost exactly as documented for vsl_ba_linearize in include/vslam_hip.h. */
+int orc_ba_linearize(const orc_ba_problem*, const orc_ba_options*, int lm_first, int lm_count, double* S,
+                     double* g, double* cost, int* n_free);
+/* map_utils.h:337-421 / loop_closure_utils.h:672-748 with [upstream] Ceres LM semantics. */
+int orc_bundle_adjust(const orc_ba_problem*, const orc_ba_options*, orc_ba_summary*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
