@@ -2,10 +2,10 @@
  * vslam_hip.h -- C ABI of the MI355X-native (gfx950) visual-SLAM hot path.
  *
  * The reference (yunjinli/visual-slam) has no plugin/FFI layer: its "operator
- * API" is the set of free functions in include/visnav/*.h that src/slam.cpp
+ * API" is the set of free functions of the include/visnav headers that src/slam.cpp
  * calls directly.  Every entry point below is what a thin C++ wrapper with the
  * reference's own signature binds to (the wrappers live in
- * include/visnav_amd/*.h; the reference-side patch is shown in INTEGRATION.md).
+ * the include/visnav_amd headers; the reference-side patch is shown in INTEGRATION.md).
  * Each declaration cites the reference interface it replaces (file:line,
  * relative to the reference checkout).
  *
@@ -155,6 +155,16 @@ int vsl_frames_upload(vsl_ctx* ctx, vsl_frames* f, int first, int n, const uint8
 /* detectKeypointsAndDescriptors over slots [first, first+n) (asynchronous). */
 int vsl_frames_detect_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features,
                                int rotate_features);
+/* Exactness guard of the rBRIEF stage (see DESIGN.md "Bit-exact descriptors"): synchronizes and
+ * re-evaluates, with the host's libm exactly as include/visnav/keypoints.h:206-214 does, every
+ * descriptor bit whose rotated sample coordinate lies within the guard band of a rounding
+ * boundary (expected ~3e-6 bits per frame); *n_resolved (nullable) = number of bits checked.
+ * Download calls do this implicitly; call it between vsl_frames_detect_describe and
+ * vsl_frames_match when the match must see the patched bits. */
+int vsl_frames_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
+/* Diagnostic knob: width of that guard band (default 1e-12; tests widen it to exercise the path). */
+int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
+
 /* matchDescriptors for n_pairs (slot_a, slot_b) pairs; slot_pairs is a HOST
  * array of 2*n_pairs slot indices; results land in pair slots [0, n_pairs)
  * (asynchronous). */

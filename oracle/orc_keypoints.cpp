@@ -53,7 +53,10 @@ struct Img {
 //   Dy = sepFilter(row [s 2s s], col [-1 0 1]):   Ry = ((s*I(x-1)) + (2s*I(x))) + (s*I(x+1)); Dy = Ry(y+1) - Ry(y-1)
 //   cov = (Dx*Dx, Dx*Dy, Dy*Dy) in fp32
 //   3x3 unnormalised box sum, accumulated in double (boxFilter uses a CV_64F sum buffer for 32F
-//   sources), rounded to fp32 once; BORDER_REFLECT_101 applied to the cov image
+//   sources) as row sums then column sums in a FIXED order (OpenCV's running-sum order depends on
+//   the whole row/column history and is not reproducible in parallel; the sums are exact in double
+//   unless a gradient is ~1e-10, so the order only matters in those cases), rounded to fp32 once;
+//   BORDER_REFLECT_101 applied to the cov image
 //   a = A*0.5f, b = B, c = C*0.5f;  lambda_min = (a + c) - sqrtf((a - c)*(a - c) + b*b)   (fp32, no FMA)
 void orc_min_eig_response(const uint8_t* img, int w, int h, size_t pitch, float* resp) {
   Img I{img, w, h, pitch};
@@ -79,21 +82,25 @@ void orc_min_eig_response(const uint8_t* img, int w, int h, size_t pitch, float*
       cyy[(size_t)y * w + x] = dy * dy;
     }
   }
+  // row sums R(x,y) = (c(x-1,y) + c(x,y)) + c(x+1,y) in double, then A = (R(x,y-1) + R(x,y)) + R(x,y+1)
+  std::vector<double> rxx((size_t)w * h), rxy((size_t)w * h), ryy((size_t)w * h);
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
-      double A = 0, B = 0, C = 0;
-      for (int dy = -1; dy <= 1; dy++) {
-        const int yy = reflect101(y + dy, h);
-        for (int dx = -1; dx <= 1; dx++) {
-          const int xx = reflect101(x + dx, w);
-          A += (double)cxx[(size_t)yy * w + xx];
-          B += (double)cxy[(size_t)yy * w + xx];
-          C += (double)cyy[(size_t)yy * w + xx];
-        }
-      }
+      const size_t l = (size_t)y * w + reflect101(x - 1, w), m = (size_t)y * w + x, r = (size_t)y * w + reflect101(x + 1, w);
+      rxx[m] = ((double)cxx[l] + (double)cxx[m]) + (double)cxx[r];
+      rxy[m] = ((double)cxy[l] + (double)cxy[m]) + (double)cxy[r];
+      ryy[m] = ((double)cyy[l] + (double)cyy[m]) + (double)cyy[r];
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    const size_t u = (size_t)reflect101(y - 1, h) * w, m = (size_t)y * w, d = (size_t)reflect101(y + 1, h) * w;
+    for (int x = 0; x < w; x++) {
+      const double A = (rxx[u + x] + rxx[m + x]) + rxx[d + x];
+      const double B = (rxy[u + x] + rxy[m + x]) + rxy[d + x];
+      const double C = (ryy[u + x] + ryy[m + x]) + ryy[d + x];
       const float a = (float)A * 0.5f, b = (float)B, c = (float)C * 0.5f;
-      const float d = a - c;
-      float t = d * d;
+      const float dd = a - c;
+      float t = dd * dd;
       const float bb = b * b;
       t = t + bb;
       resp[(size_t)y * w + x] = (a + c) - sqrtf(t);

@@ -1,0 +1,148 @@
+"""GPU parity: K1-K4 (detect.hip, describe.hip) through the C ABI vs the oracle's restatement of
+include/visnav/keypoints.h:133-229 (+ [upstream] cv::goodFeaturesToTrack).
+Bars: fp32 response bit-exact (same IEEE operation order, no FMA); keypoint lists identical (same
+points, same order); integer moments / angles / 256-bit descriptors bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(synth):
+    rng = np.random.default_rng(3)
+    left, right = synth.stereo_pair(11)
+    noise = rng.integers(0, 256, (480, 752), dtype=np.uint8)          # > 8192 candidates: radix-select path
+    flat = np.full((480, 752), 90, np.uint8)                            # no corners at all
+    grad = np.tile(np.arange(752, dtype=np.uint8), (480, 1))            # wrap-around ramp: ties galore
+    checker = (((np.mgrid[0:480, 0:752][0] // 16) + (np.mgrid[0:480, 0:752][1] // 16)) % 2 * 200 + 20).astype(np.uint8)
+    small = rng.integers(0, 256, (97, 131), dtype=np.uint8)             # ragged sizes, partial tiles
+    return dict(left=left, right=right, noise=noise, flat=flat, grad=grad, checker=checker, small=small)
+
+
+@pytest.fixture(scope="module")
+def images(synth):
+    return _images(synth)
+
+
+@pytest.mark.parametrize("name", ["left", "noise", "flat", "grad", "checker", "small"])
+def test_response_bit_exact(ctx, orc, images, name):
+    img = images[name]
+    got = ctx.min_eig_response(img)
+    exp = orc.min_eig_response(img)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["left", "right", "noise", "flat", "grad", "checker", "small"])
+@pytest.mark.parametrize("nf", [1500, 100])
+def test_detect_describe_bit_exact(ctx, orc, images, name, nf):
+    img = images[name]
+    xy, ang, desc = ctx.detect_describe(img, nf, True)
+    oxy, oang, odesc = orc.detect_describe(img, nf, True)
+    assert np.array_equal(xy, oxy)
+    assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
+    assert np.array_equal(desc, odesc)
+    if name in ("left", "right") and nf == 1500:
+        assert len(xy) > 1000
+
+
+def test_detect_without_rotation(ctx, orc, images):
+    xy, ang, desc = ctx.detect_describe(images["left"], 800, False)
+    oxy, oang, odesc = orc.detect_describe(images["left"], 800, False)
+    assert np.array_equal(xy, oxy) and not ang.any() and np.array_equal(desc, odesc)
+
+
+def test_separate_entry_points(ctx, orc, images):
+    img = images["right"]
+    kp = ctx.detect_keypoints(img, 1200)
+    assert np.array_equal(kp, orc.detect_keypoints(img, 1200))
+    ang = ctx.compute_angles(img, kp, True)
+    oang = orc.compute_angles(img, kp, True)
+    assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
+    # computeDescriptors with caller-provided angles (not the ones the image implies)
+    rng = np.random.default_rng(1)
+    arb = rng.uniform(-np.pi, np.pi, len(kp))
+    arb[:8] = [0.0, np.pi / 2, -np.pi / 2, np.pi, -np.pi, np.pi / 4, 1e-17, -0.0]
+    assert np.array_equal(ctx.compute_descriptors(img, kp, arb), orc.compute_descriptors(img, kp, arb))
+    assert np.array_equal(ctx.compute_descriptors(img, kp, oang), orc.compute_descriptors(img, kp, oang))
+
+
+def test_near_tie_guard_path(ctx, orc, images):
+    # widen the guard band so that thousands of samples take the host-libm re-evaluation path; the
+    # result must not change (it is the reference's formula either way)
+    img = images["left"]
+    ctx.set_tie_eps(2e-3)
+    try:
+        xy, ang, desc = ctx.detect_describe(img, 300, True)
+    finally:
+        ctx.set_tie_eps(1e-12)
+    oxy, oang, odesc = orc.detect_describe(img, 300, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_golden_euroc(ctx, k):
+    g = np.load(GOLDEN / ("euroc_pair%d.npz" % k))
+    for c in (0, 1):
+        xy, ang, desc = ctx.detect_describe(g["img%d" % c], 1500, True)
+        assert np.array_equal(xy.astype(np.int32), g["xy%d" % c])
+        assert np.array_equal(ang.view(np.uint64), g["angle_bits%d" % c])
+        assert np.array_equal(desc, g["desc%d" % c])
+        resp = ctx.min_eig_response(g["img%d" % c])
+        assert np.bitwise_xor.reduce(resp.view(np.uint32).ravel()) == g["resp_bits_xor%d" % c]
+        assert resp.view(np.uint32).astype(np.uint64).sum() == g["resp_bits_sum%d" % c]
+
+
+def test_pitch_and_bad_arguments(ctx, orc, vsl, images):
+    img = images["left"]
+    padded = np.zeros((480, 800), np.uint8)
+    padded[:, :752] = img
+    view = padded[:, :752]  # pitch 800
+    import ctypes as C
+    xy = np.zeros((500, 2)); ang = np.zeros(500); desc = np.zeros((500, 4), np.uint64); n = C.c_int32()
+    rc = ctx.L.vsl_detect_describe(ctx.h, view.ctypes.data_as(vsl.u8p), 752, 480, C.c_size_t(800), 500, 1, 500,
+                                   xy.ctypes.data_as(vsl.f64p), ang.ctypes.data_as(vsl.f64p),
+                                   desc.ctypes.data_as(vsl.u64p), C.byref(n))
+    assert rc == 0
+    oxy, _, odesc = orc.detect_describe(img, 500, True)
+    assert np.array_equal(xy[:n.value], oxy) and np.array_equal(desc[:n.value], odesc)
+    # capacity too small -> VSL_ERR_CAPACITY, null image -> VSL_ERR_INVALID
+    rc = ctx.L.vsl_detect_describe(ctx.h, view.ctypes.data_as(vsl.u8p), 752, 480, C.c_size_t(800), 500, 1, 3,
+                                   xy.ctypes.data_as(vsl.f64p), ang.ctypes.data_as(vsl.f64p),
+                                   desc.ctypes.data_as(vsl.u64p), C.byref(n))
+    assert rc == -4
+    rc = ctx.L.vsl_detect_describe(ctx.h, None, 752, 480, C.c_size_t(800), 500, 1, 500, None, None, None, C.byref(n))
+    assert rc == -1
+
+
+def test_frames_batch_equals_single(ctx, orc, vsl, synth):
+    # device-resident batched path == host-buffer path == oracle, for a batch of different images
+    imgs = []
+    for s in (21, 22, 23):
+        imgs.extend(synth.stereo_pair(s))
+    imgs = np.stack(imgs)
+    fr = vsl.Frames(ctx, len(imgs), 752, 480, 1500, max_pairs=3)
+    fr.upload(0, imgs)
+    fr.detect_describe(0, len(imgs), 1500, True)
+    fr.resolve_ties()
+    fr.match([[0, 1], [2, 3], [4, 5]], 70, 1.2)
+    descs = []
+    for i in range(len(imgs)):
+        xy, ang, desc = fr.keypoints(i)
+        oxy, oang, odesc = orc.detect_describe(imgs[i], 1500, True)
+        assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+        assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
+        descs.append(desc)
+    for p in range(3):
+        assert np.array_equal(fr.matches(p), orc.match_descriptors(descs[2 * p], descs[2 * p + 1], 70, 1.2))
+    nk, nm = fr.counts(len(imgs), 3)
+    assert nk.tolist() == [len(d) for d in descs] and all(nm > 50)
+    # re-running a sub-range leaves the other slots untouched
+    fr.detect_describe(2, 2, 700, True)
+    xy, _, desc = fr.keypoints(2)
+    oxy, _, odesc = orc.detect_describe(imgs[2], 700, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+    xy0, _, desc0 = fr.keypoints(0)
+    assert np.array_equal(desc0, descs[0])
+    fr.close()

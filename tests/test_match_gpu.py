@@ -1,0 +1,77 @@
+"""GPU parity: K5 Hamming matcher (visual-slam_amd/csrc/match.hip) through the C ABI vs the oracle's
+restatement of include/visnav/keypoints.h:278-369.  Integer work: bit-exact, same pairs, same order."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _planted(synth, seed, n1, n2, n_dup=200, flips=(0, 5, 20, 40, 69, 70, 71)):
+    rng = np.random.default_rng(seed)
+    d1 = synth.random_descriptors(rng, n1)
+    d2 = synth.random_descriptors(rng, n2)
+    k = min(n_dup, n1, n2)
+    idx1 = rng.choice(n1, k, replace=False)
+    idx2 = rng.choice(n2, k, replace=False)
+    for a, b in zip(idx1, idx2):
+        d2[b] = synth.flip_bits(rng, d1[a:a + 1], int(rng.choice(flips)))[0]
+    # exact duplicates inside d2 (distance ties between columns) and inside d1 (cross-check ties)
+    for _ in range(min(20, n2 // 2)):
+        a, b = rng.choice(n2, 2, replace=False)
+        d2[a] = d2[b]
+    for _ in range(min(20, n1 // 2)):
+        a, b = rng.choice(n1, 2, replace=False)
+        d1[a] = d1[b]
+    return d1, d2
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (1, 2), (63, 65), (64, 64), (300, 7), (7, 300), (1500, 1500),
+                                   (1317, 1333), (513, 2049)])
+def test_match_random_planted(ctx, orc, synth, n1, n2):
+    d1, d2 = _planted(synth, 100 + n1 + n2, n1, n2)
+    got = ctx.match_descriptors(d1, d2, 70, 1.2)
+    exp = orc.match_descriptors(d1, d2, 70, 1.2)
+    assert np.array_equal(got, exp)
+
+
+def test_match_thresholds_and_ratios(ctx, orc, synth):
+    d1, d2 = _planted(synth, 5, 700, 650)
+    for thr, ratio in ((70, 1.2), (1, 1.2), (256, 1.0), (257, 1.0), (100, 2.5), (70, 1.0)):
+        assert np.array_equal(ctx.match_descriptors(d1, d2, thr, ratio),
+                              orc.match_descriptors(d1, d2, thr, ratio)), (thr, ratio)
+
+
+def test_match_empty_and_degenerate(ctx, orc):
+    z = np.zeros((0, 4), np.uint64)
+    one = np.zeros((1, 4), np.uint64)
+    assert len(ctx.match_descriptors(z, one)) == 0
+    assert len(ctx.match_descriptors(one, z)) == 0
+    assert len(ctx.match_descriptors(z, z)) == 0
+    # all-identical descriptors: every distance 0, lowest index wins in both directions
+    same = np.tile(np.array([[1, 2, 3, 4]], np.uint64), (130, 1))
+    assert np.array_equal(ctx.match_descriptors(same, same), orc.match_descriptors(same, same))
+    # all bits different: distance 256 everywhere
+    ones = np.full((70, 4), np.uint64(0xFFFFFFFFFFFFFFFF))
+    zeros = np.zeros((70, 4), np.uint64)
+    assert np.array_equal(ctx.match_descriptors(ones, zeros, 257, 1.0), orc.match_descriptors(ones, zeros, 257, 1.0))
+
+
+def test_match_large(ctx, orc, synth):
+    d1, d2 = _planted(synth, 77, 6000, 5000, n_dup=3000)
+    assert np.array_equal(ctx.match_descriptors(d1, d2), orc.match_descriptors(d1, d2))
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_match_golden(ctx, k):
+    g = np.load(GOLDEN / ("euroc_pair%d.npz" % k))
+    assert np.array_equal(ctx.match_descriptors(g["desc0"], g["desc1"], 70, 1.2), g["matches"])
+
+
+def test_match_symmetry_property(ctx, synth):
+    # size-independent property: with the cross-check, match(d1, d2) is the transpose of match(d2, d1)
+    d1, d2 = _planted(synth, 9, 1500, 1400)
+    a = ctx.match_descriptors(d1, d2)
+    b = ctx.match_descriptors(d2, d1)
+    assert sorted(map(tuple, a.tolist())) == sorted((j, i) for i, j in b.tolist())

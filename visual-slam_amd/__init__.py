@@ -1,0 +1,391 @@
+"""visual_slam_amd -- Python plumbing over the C ABI of libvslam_hip.so (include/vslam_hip.h).
+
+The product is the shared library (hand-written HIP for gfx950 + C++ host code); this module only
+loads it with ctypes so that tests/ and bench.py can drive the C ABI.  There is NO fallback: if the
+library is missing or no MI355X is visible, `load()` / `Context()` raise.
+
+The directory is named `visual-slam_amd` (the layout the build contract asks for); it is imported
+under the module name `visual_slam_amd` -- see `__graft_entry__.load_package()`.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_SO = _DIR / "libvslam_hip.so"
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+STAGES = ["response", "select", "describe", "match", "match_finalize", "ba_linearize", "ba_schur",
+          "ba_solve", "bow_transform", "bow_score"]
+
+OK = 0
+ERR = {-1: "VSL_ERR_INVALID", -2: "VSL_ERR_HIP", -3: "VSL_ERR_NOMEM", -4: "VSL_ERR_CAPACITY",
+       -5: "VSL_ERR_NO_DEVICE", -6: "VSL_ERR_IO", -7: "VSL_ERR_NUMERIC"}
+
+
+class VslError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR.get(code, "VSL_ERR_?"), code, msg))
+        self.code = code
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int32), ("n_lms", C.c_int32), ("n_obs", C.c_int32),
+                ("cam_model", C.c_int32 * 2), ("poses", f64p), ("cam_fixed", u8p),
+                ("cam_intr", i32p), ("intr", f64p), ("points", f64p), ("obs_cam", i32p),
+                ("obs_lm", i32p), ("obs_uv", f64p)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("use_huber", C.c_int32), ("huber_parameter", C.c_double),
+                ("max_num_iterations", C.c_int32), ("verbosity", C.c_int32)]
+
+
+class BaSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("iterations", C.c_int32), ("successful_steps", C.c_int32),
+                ("termination", C.c_int32), ("linearize_ms", C.c_double),
+                ("schur_ms", C.c_double), ("solve_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+def library_path():
+    return _SO
+
+
+def load():
+    """dlopen libvslam_hip.so (raises if it has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not _SO.exists():
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % _SO)
+        L = C.CDLL(str(_SO))
+        L.vsl_version.restype = C.c_char_p
+        L.vsl_last_error.restype = C.c_char_p
+        L.vsl_last_error.argtypes = [C.c_void_p]
+        L.vsl_ctx_stream.restype = C.c_void_p
+        L.vsl_ctx_stream.argtypes = [C.c_void_p]
+        L.vsl_frames_images_dev.restype = C.c_void_p
+        L.vsl_frames_images_dev.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    return load().vsl_device_count()
+
+
+def _img(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    return img, img.ctypes.data_as(u8p), img.shape[1], img.shape[0], C.c_size_t(img.strides[0])
+
+
+class Context:
+    """vsl_ctx: one HIP stream + scratch.  `stream` = an existing hipStream_t handle (int) to borrow."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        if stream is None:
+            rc = self.L.vsl_ctx_create(int(device), C.byref(h))
+        else:
+            rc = self.L.vsl_ctx_create_on_stream(int(device), C.c_void_p(stream), C.byref(h))
+        if rc != OK:
+            raise VslError(rc, self.L.vsl_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vsl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise VslError(rc, self.L.vsl_last_error(self.h).decode())
+
+    def synchronize(self):
+        self._ck(self.L.vsl_ctx_synchronize(self.h))
+
+    def stream(self):
+        return self.L.vsl_ctx_stream(self.h)
+
+    def set_profiling(self, on):
+        self._ck(self.L.vsl_ctx_set_profiling(self.h, int(on)))
+
+    def reset_profiling(self):
+        self._ck(self.L.vsl_ctx_reset_profiling(self.h))
+
+    def stage_ms(self):
+        out = {}
+        for i, name in enumerate(STAGES):
+            ms, n = C.c_double(), C.c_int64()
+            self._ck(self.L.vsl_ctx_stage_ms(self.h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def set_tie_eps(self, eps):
+        self._ck(self.L.vsl_ctx_set_tie_eps(self.h, C.c_double(eps)))
+
+    # ---- keypoints.h drop-ins (host buffers)
+    def detect_describe(self, img, num_features=1500, rotate=True):
+        img, p, w, h, pitch = _img(img)
+        cap = num_features
+        xy = np.zeros((cap, 2), np.float64)
+        ang = np.zeros(cap, np.float64)
+        desc = np.zeros((cap, 4), np.uint64)
+        n = C.c_int32()
+        self._ck(self.L.vsl_detect_describe(self.h, p, w, h, pitch, int(num_features), int(rotate), cap,
+                                            xy.ctypes.data_as(f64p), ang.ctypes.data_as(f64p),
+                                            desc.ctypes.data_as(u64p), C.byref(n)))
+        return xy[:n.value].copy(), ang[:n.value].copy(), desc[:n.value].copy()
+
+    def detect_keypoints(self, img, num_features=1500):
+        img, p, w, h, pitch = _img(img)
+        xy = np.zeros((num_features, 2), np.float64)
+        n = C.c_int32()
+        self._ck(self.L.vsl_detect_keypoints(self.h, p, w, h, pitch, int(num_features), num_features,
+                                             xy.ctypes.data_as(f64p), C.byref(n)))
+        return xy[:n.value].copy()
+
+    def compute_angles(self, img, corners, rotate=True):
+        img, p, w, h, pitch = _img(img)
+        corners = np.ascontiguousarray(corners, np.float64).reshape(-1, 2)
+        ang = np.zeros(len(corners), np.float64)
+        self._ck(self.L.vsl_compute_angles(self.h, p, w, h, pitch, corners.ctypes.data_as(f64p),
+                                           len(corners), int(rotate), ang.ctypes.data_as(f64p)))
+        return ang
+
+    def compute_descriptors(self, img, corners, angles):
+        img, p, w, h, pitch = _img(img)
+        corners = np.ascontiguousarray(corners, np.float64).reshape(-1, 2)
+        angles = np.ascontiguousarray(angles, np.float64)
+        desc = np.zeros((len(corners), 4), np.uint64)
+        self._ck(self.L.vsl_compute_descriptors(self.h, p, w, h, pitch, corners.ctypes.data_as(f64p),
+                                                angles.ctypes.data_as(f64p), len(corners),
+                                                desc.ctypes.data_as(u64p)))
+        return desc
+
+    def min_eig_response(self, img):
+        img, p, w, h, pitch = _img(img)
+        out = np.zeros((h, w), np.float32)
+        self._ck(self.L.vsl_min_eig_response(self.h, p, w, h, pitch, out.ctypes.data_as(f32p)))
+        return out
+
+    def match_descriptors(self, d1, d2, threshold=70, dist_2_best=1.2):
+        d1 = np.ascontiguousarray(d1, np.uint64).reshape(-1, 4)
+        d2 = np.ascontiguousarray(d2, np.uint64).reshape(-1, 4)
+        pairs = np.zeros((max(1, min(len(d1), len(d2))), 2), np.int32)
+        n = C.c_int32()
+        self._ck(self.L.vsl_match_descriptors(self.h, d1.ctypes.data_as(u64p), len(d1),
+                                              d2.ctypes.data_as(u64p), len(d2), int(threshold),
+                                              C.c_double(dist_2_best), pairs.ctypes.data_as(i32p),
+                                              C.byref(n)))
+        return pairs[:n.value].copy()
+
+    # ---- bundle adjustment
+    def _ba_struct(self, arr):
+        st = BaProblem()
+        st.n_cams, st.n_lms, st.n_obs = len(arr.poses), len(arr.points), len(arr.obs_cam)
+        st.cam_model[0], st.cam_model[1] = arr.cam_model
+        st.poses = arr.poses.ctypes.data_as(f64p)
+        st.cam_fixed = arr.cam_fixed.ctypes.data_as(u8p)
+        st.cam_intr = arr.cam_intr.ctypes.data_as(i32p)
+        st.intr = arr.intr.ctypes.data_as(f64p)
+        st.points = arr.points.ctypes.data_as(f64p)
+        st.obs_cam = arr.obs_cam.ctypes.data_as(i32p)
+        st.obs_lm = arr.obs_lm.ctypes.data_as(i32p)
+        st.obs_uv = arr.obs_uv.ctypes.data_as(f64p)
+        return st
+
+    @staticmethod
+    def _ba_opts(use_huber, huber, max_iters, verbosity):
+        o = BaOptions()
+        o.use_huber, o.huber_parameter = int(use_huber), float(huber)
+        o.max_num_iterations, o.verbosity = int(max_iters), int(verbosity)
+        return o
+
+    def bundle_adjust(self, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0):
+        """arr: object with the numpy fields of include/vslam_hip.h's vsl_ba_problem (optimised in place)."""
+        st = self._ba_struct(arr)
+        o = self._ba_opts(use_huber, huber, max_iters, verbosity)
+        s = BaSummary()
+        self._ck(self.L.vsl_bundle_adjust(self.h, C.byref(st), C.byref(o), C.byref(s)))
+        return s
+
+    def ba_linearize(self, arr, use_huber=True, huber=1.0, lm_first=0, lm_count=-1):
+        st = self._ba_struct(arr)
+        o = self._ba_opts(use_huber, huber, 0, 0)
+        n = 6 * int((arr.cam_fixed == 0).sum())
+        S = np.zeros((n, n))
+        g = np.zeros(n)
+        cost, nf = C.c_double(), C.c_int32()
+        self._ck(self.L.vsl_ba_linearize(self.h, C.byref(st), C.byref(o), int(lm_first), int(lm_count),
+                                         S.ctypes.data_as(f64p), g.ctypes.data_as(f64p), C.byref(cost),
+                                         C.byref(nf)))
+        return S, g, cost.value
+
+    def ba_residuals_jacobians(self, arr):
+        st = self._ba_struct(arr)
+        n = len(arr.obs_cam)
+        r, Jp, Jl = np.zeros((n, 2)), np.zeros((n, 2, 6)), np.zeros((n, 2, 3))
+        self._ck(self.L.vsl_ba_residuals_jacobians(self.h, C.byref(st), r.ctypes.data_as(f64p),
+                                                   Jp.ctypes.data_as(f64p), Jl.ctypes.data_as(f64p)))
+        return r, Jp, Jl
+
+    # ---- DBoW2
+    def load_vocabulary(self, path):
+        return Vocabulary(self, path)
+
+    def bow_score_batch(self, q_ids, q_vals, cands):
+        """cands: list of (ids, vals).  Returns the L1 scores (float64 array)."""
+        q_ids = np.ascontiguousarray(q_ids, np.uint32)
+        q_vals = np.ascontiguousarray(q_vals, np.float64)
+        m = len(cands)
+        offs = np.zeros(m + 1, np.int32)
+        for i, (ids, _) in enumerate(cands):
+            offs[i + 1] = offs[i] + len(ids)
+        c_ids = np.concatenate([np.asarray(c[0], np.uint32) for c in cands]) if m else np.zeros(0, np.uint32)
+        c_vals = np.concatenate([np.asarray(c[1], np.float64) for c in cands]) if m else np.zeros(0)
+        c_ids = np.ascontiguousarray(c_ids, np.uint32)
+        c_vals = np.ascontiguousarray(c_vals, np.float64)
+        scores = np.zeros(max(m, 1), np.float64)
+        self._ck(self.L.vsl_bow_score_batch(self.h, q_ids.ctypes.data_as(u32p), q_vals.ctypes.data_as(f64p),
+                                            len(q_ids), c_ids.ctypes.data_as(u32p),
+                                            c_vals.ctypes.data_as(f64p), offs.ctypes.data_as(i32p), m,
+                                            scores.ctypes.data_as(f64p)))
+        return scores[:m].copy()
+
+
+class Vocabulary:
+    def __init__(self, ctx, path):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._ck(ctx.L.vsl_voc_load_text(ctx.h, os.fsencode(str(path)), C.byref(h)))
+        self.h = h
+
+    def info(self):
+        v = [C.c_int32() for _ in range(4)]
+        self.ctx._ck(self.ctx.L.vsl_voc_info(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def transform(self, desc32, levelsup=4):
+        desc32 = np.ascontiguousarray(desc32, np.uint8).reshape(-1, 32)
+        n = len(desc32)
+        ids = np.zeros(max(n, 1), np.uint32)
+        vals = np.zeros(max(n, 1), np.float64)
+        fn = np.zeros(max(n, 1), np.uint32)
+        ff = np.zeros(max(n, 1), np.uint32)
+        nnz, fvn = C.c_int32(), C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_bow_transform(self.ctx.h, self.h, desc32.ctypes.data_as(u8p), n,
+                                                  int(levelsup), ids.ctypes.data_as(u32p),
+                                                  vals.ctypes.data_as(f64p), C.byref(nnz),
+                                                  fn.ctypes.data_as(u32p), ff.ctypes.data_as(u32p),
+                                                  C.byref(fvn)))
+        return (ids[:nnz.value].copy(), vals[:nnz.value].copy(), fn[:fvn.value].copy(),
+                ff[:fvn.value].copy())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.vsl_voc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Frames:
+    """vsl_frames: device-resident batched frame store."""
+
+    def __init__(self, ctx, max_images, w, h, max_features=1500, max_pairs=None):
+        self.ctx = ctx
+        self.max_images, self.w, self.hgt, self.F = max_images, w, h, max_features
+        self.max_pairs = max_pairs if max_pairs is not None else max(1, max_images // 2)
+        hnd = C.c_void_p()
+        ctx._ck(ctx.L.vsl_frames_create(ctx.h, int(max_images), int(w), int(h), int(max_features),
+                                        int(self.max_pairs), C.byref(hnd)))
+        self.h = hnd
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.vsl_frames_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def images_dev(self):
+        return self.ctx.L.vsl_frames_images_dev(self.h)
+
+    def upload(self, first, imgs):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        if imgs.ndim == 2:
+            imgs = imgs[None]
+        n, h, w = imgs.shape
+        assert (h, w) == (self.hgt, self.w)
+        self.ctx._ck(self.ctx.L.vsl_frames_upload(self.ctx.h, self.h, int(first), n,
+                                                  imgs.ctypes.data_as(u8p), C.c_size_t(w),
+                                                  C.c_size_t(w * h)))
+        self.ctx.synchronize()
+
+    def detect_describe(self, first, n, num_features=1500, rotate=True):
+        self.ctx._ck(self.ctx.L.vsl_frames_detect_describe(self.ctx.h, self.h, int(first), int(n),
+                                                           int(num_features), int(rotate)))
+
+    def resolve_ties(self):
+        n = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_frames_resolve_ties(self.ctx.h, self.h, C.byref(n)))
+        return n.value
+
+    def match(self, slot_pairs, threshold=70, dist_2_best=1.2):
+        sp = np.ascontiguousarray(slot_pairs, np.int32).reshape(-1, 2)
+        self.ctx._ck(self.ctx.L.vsl_frames_match(self.ctx.h, self.h, sp.ctypes.data_as(i32p), len(sp),
+                                                 int(threshold), C.c_double(dist_2_best)))
+
+    def keypoints(self, slot):
+        xy = np.zeros((self.F, 2), np.float64)
+        ang = np.zeros(self.F, np.float64)
+        desc = np.zeros((self.F, 4), np.uint64)
+        n = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_frames_download_keypoints(self.ctx.h, self.h, int(slot), self.F,
+                                                              xy.ctypes.data_as(f64p),
+                                                              ang.ctypes.data_as(f64p),
+                                                              desc.ctypes.data_as(u64p), C.byref(n)))
+        return xy[:n.value].copy(), ang[:n.value].copy(), desc[:n.value].copy()
+
+    def matches(self, pair):
+        out = np.zeros((self.F, 2), np.int32)
+        n = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_frames_download_matches(self.ctx.h, self.h, int(pair), self.F,
+                                                            out.ctypes.data_as(i32p), C.byref(n)))
+        return out[:n.value].copy()
+
+    def counts(self, n_images, n_pairs):
+        nk = np.zeros(max(n_images, 1), np.int32)
+        nm = np.zeros(max(n_pairs, 1), np.int32)
+        self.ctx._ck(self.ctx.L.vsl_frames_download_counts(self.ctx.h, self.h, int(n_images),
+                                                           nk.ctypes.data_as(i32p), int(n_pairs),
+                                                           nm.ctypes.data_as(i32p)))
+        return nk[:n_images].copy(), nm[:n_pairs].copy()

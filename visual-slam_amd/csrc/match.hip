@@ -1,0 +1,229 @@
+// match.hip -- K5: brute-force Hamming matcher with ratio test and cross-check.
+//
+// Replaces visnav::matchDescriptors / isPQiffQP (include/visnav/keypoints.h:323-369, :278-313).
+//
+// Reference semantics restated:
+//   for each row descriptor, over all column descriptors in index order:
+//     best/second-best distance with strict '<'  => lowest index wins ties, and "second" is the
+//     second-smallest distance counted with multiplicity; both start at 256 / index 0;
+//   row passes iff best < threshold and !(second < best * dist_2_best)        (double compare)
+//   (i, j = best(i)) is a match iff row i passes in direction a->b, column j passes in direction
+//   b->a and best_{b->a}(j) == i.  Matches are emitted in ascending i.
+//
+// Kernel design (gfx950): a 64-row tile per workgroup, one ROW per LANE (its 256-bit descriptor sits
+// in 8 VGPRs), columns split over the workgroup's waves.  A column descriptor is wave-uniform, so it
+// is fetched with scalar loads and used as SGPR operands of v_xor / v_bcnt -- no LDS traffic and no
+// cross-lane work in the inner loop.  (distance << 23 | column) is one 32-bit key: min() keeps the
+// best with the lowest-index tie-break, med3() keeps the runner-up.  Per-wave partials are merged
+// through LDS in column order.  Both directions and all pairs of a batch are one launch.
+//
+// Algorithmic bytes per pair: (n_a + n_b) * 32 B read + 8 B per match written.
+#include "vsl_common.h"
+
+#define KEY_SHIFT 23
+#define KEY_INIT ((256u << KEY_SHIFT) | 0u)
+
+// v_med3_u32: median of three unsigned values (one VALU op; no clang builtin for the integer form)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void hamming_best2_kernel(
+    const uint64_t* __restrict__ desc, const int32_t* __restrict__ kp_count,
+    const int32_t* __restrict__ pair_slots, uint32_t* __restrict__ best_key,
+    uint32_t* __restrict__ second_key, int F) {
+  const int pair = blockIdx.z, dir = blockIdx.y;
+  const int slot_r = pair_slots[2 * pair + dir];      // rows
+  const int slot_c = pair_slots[2 * pair + 1 - dir];  // columns
+  const int n_r = kp_count[slot_r], n_c = kp_count[slot_c];
+  const int row0 = blockIdx.x * 64;
+  if (row0 >= n_r) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = row0 + lane;
+
+  uint32_t r[8];
+  {
+    const uint32_t* p = (const uint32_t*)(desc + ((size_t)slot_r * F + (row < n_r ? row : 0)) * 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = p[k];
+  }
+  // column range of this wave, a multiple of 4 columns
+  int chunk = (n_c + WAVES - 1) / WAVES;
+  chunk = (chunk + 3) & ~3;
+  const int c0 = wave * chunk;
+  const int c1 = min(n_c, c0 + chunk);
+  const uint32_t* __restrict__ cbase = (const uint32_t*)(desc + (size_t)slot_c * F * 4);
+
+  uint32_t b = KEY_INIT, s = KEY_INIT;
+  int j = c0;
+  for (; j + 4 <= c1; j += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t* __restrict__ c = cbase + (size_t)(j + u) * 8;
+      uint32_t d = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) d += __builtin_popcount(r[k] ^ c[k]);
+      const uint32_t key = (d << KEY_SHIFT) | (uint32_t)(j + u);
+      s = umed3(b, key, s);
+      b = min(b, key);
+    }
+  }
+  for (; j < c1; j++) {
+    const uint32_t* __restrict__ c = cbase + (size_t)j * 8;
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d += __builtin_popcount(r[k] ^ c[k]);
+    const uint32_t key = (d << KEY_SHIFT) | (uint32_t)j;
+    s = umed3(b, key, s);
+    b = min(b, key);
+  }
+
+  __shared__ uint32_t sb[WAVES][64], ss[WAVES][64];
+  sb[wave][lane] = b;
+  ss[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && row < n_r) {
+    // merge (b, s) pairs in column order: second = min(med3(b1, b2, s1), s2)
+#pragma unroll
+    for (int w = 1; w < WAVES; w++) {
+      const uint32_t b2 = sb[w][lane], s2 = ss[w][lane];
+      s = min(umed3(b, b2, s), s2);
+      b = min(b, b2);
+    }
+    const size_t o = ((size_t)pair * 2 + dir) * F + row;
+    best_key[o] = b;
+    second_key[o] = s;
+  }
+}
+
+// Ratio test + cross-check + ordered emit.  One workgroup per pair.
+__global__ __launch_bounds__(1024) void match_finalize_kernel(
+    const int32_t* __restrict__ kp_count, const int32_t* __restrict__ pair_slots,
+    const uint32_t* __restrict__ best_key, const uint32_t* __restrict__ second_key,
+    int32_t* __restrict__ matches, int32_t* __restrict__ match_count, int F, int threshold,
+    double dist_2_best) {
+  const int pair = blockIdx.x;
+  const int n_a = kp_count[pair_slots[2 * pair]];
+  const int n_b = kp_count[pair_slots[2 * pair + 1]];
+  const uint32_t* bk0 = best_key + ((size_t)pair * 2) * F;
+  const uint32_t* sk0 = second_key + ((size_t)pair * 2) * F;
+  const uint32_t* bk1 = bk0 + F;
+  const uint32_t* sk1 = sk0 + F;
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n_a; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    bool ok = false;
+    int jbest = 0;
+    if (i < n_a && n_b > 0) {
+      const uint32_t b = bk0[i];
+      const int d1 = (int)(b >> KEY_SHIFT);
+      const int d2 = (int)(sk0[i] >> KEY_SHIFT);
+      jbest = (int)(b & ((1u << KEY_SHIFT) - 1));
+      if (d1 < threshold && !((double)d2 < (double)d1 * dist_2_best)) {
+        const uint32_t rb = bk1[jbest];
+        const int e1 = (int)(rb >> KEY_SHIFT);
+        const int e2 = (int)(sk1[jbest] >> KEY_SHIFT);
+        const int ri = (int)(rb & ((1u << KEY_SHIFT) - 1));
+        ok = (e1 < threshold) && !((double)e2 < (double)e1 * dist_2_best) && ri == i;
+      }
+    }
+    const unsigned long long m = __ballot(ok);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    if (ok) {
+      matches[((size_t)pair * F + off + within) * 2] = i;
+      matches[((size_t)pair * F + off + within) * 2 + 1] = jbest;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += wave_tot[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) match_count[pair] = base_s;
+}
+
+int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best) {
+  if (n_pairs <= 0) return VSL_OK;
+  constexpr int WAVES = 8;
+  {
+    VslStage st(ctx, VSL_STAGE_MATCH);
+    dim3 grid((f->F + 63) / 64, 2, n_pairs);
+    hipLaunchKernelGGL(hamming_best2_kernel<WAVES>, grid, dim3(64 * WAVES), 0, ctx->stream, f->kp_desc,
+                       f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  {
+    VslStage st(ctx, VSL_STAGE_MATCH_FIN);
+    hipLaunchKernelGGL(match_finalize_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, f->kp_count,
+                       f->pair_slots, f->best_key, f->second_key, f->matches, f->match_count, f->F, threshold,
+                       dist_2_best);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  return VSL_OK;
+}
+
+// The pair list of a steady-state pipeline never changes (slot 2k <-> 2k+1), so it is uploaded only
+// when it differs from the cached copy (synchronously: the caller's array may be reused at once).
+int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_pairs) {
+  const size_t n = 2 * (size_t)n_pairs;
+  if (f->pair_cache.size() >= n && memcmp(f->pair_cache.data(), slot_pairs, n * sizeof(int32_t)) == 0) return VSL_OK;
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VSL_HIP(ctx, hipMemcpy(f->pair_slots, slot_pairs, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  f->pair_cache.assign(slot_pairs, slot_pairs + n);
+  return VSL_OK;
+}
+
+extern "C" int vsl_frames_match(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_pairs, int threshold,
+                                double dist_2_best) {
+  if (!ctx || !f || (n_pairs > 0 && !slot_pairs) || n_pairs < 0 || n_pairs > f->max_pairs)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_match: bad arguments (n_pairs=%d, max_pairs=%d)", n_pairs, f ? f->max_pairs : -1);
+  for (int i = 0; i < 2 * n_pairs; i++)
+    if (slot_pairs[i] < 0 || slot_pairs[i] >= f->max_images)
+      return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_match: slot %d out of range", slot_pairs[i]);
+  if (n_pairs == 0) return VSL_OK;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = vsl_set_pairs(ctx, f, slot_pairs, n_pairs);
+  if (rc) return rc;
+  return vsl_launch_match(ctx, f, n_pairs, threshold, dist_2_best);
+}
+
+extern "C" int vsl_match_descriptors(vsl_ctx* ctx, const uint64_t* d1, int n1, const uint64_t* d2, int n2,
+                                     int threshold, double dist_2_best, int32_t* pairs, int* n_out) {
+  if (!ctx || !n_out || n1 < 0 || n2 < 0 || (n1 > 0 && !d1) || (n2 > 0 && !d2))
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_match_descriptors: bad arguments");
+  *n_out = 0;
+  if (n1 == 0 || n2 == 0) return VSL_OK;  // best stays 256 >= threshold for every row
+  if (n1 >= (1 << KEY_SHIFT) || n2 >= (1 << KEY_SHIFT))
+    return vsl_fail(ctx, VSL_ERR_CAPACITY, "vsl_match_descriptors: at most %d descriptors per set", (1 << KEY_SHIFT) - 1);
+  if (!pairs) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_match_descriptors: pairs is null");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  vsl_frames* f = nullptr;
+  const int feat = n1 > n2 ? n1 : n2;
+  int rc = vsl_ctx_scratch_frames(ctx, ctx->scratch ? ctx->scratch_w : 64, ctx->scratch ? ctx->scratch_h : 64,
+                                  feat > (ctx->scratch ? ctx->scratch_feat : 0) ? feat : ctx->scratch_feat, &f);
+  if (rc) return rc;
+  const int32_t counts[2] = {n1, n2};
+  const int32_t slots[2] = {0, 1};
+  VSL_HIP(ctx, hipMemcpyAsync(f->kp_desc, d1, 32 * (size_t)n1, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(f->kp_desc + (size_t)f->F * 4, d2, 32 * (size_t)n2, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(f->kp_count, counts, sizeof(counts), hipMemcpyHostToDevice, ctx->stream));
+  rc = vsl_set_pairs(ctx, f, slots, 1);
+  if (rc) return rc;
+  rc = vsl_launch_match(ctx, f, 1, threshold, dist_2_best);
+  if (rc) return rc;
+  return vsl_frames_download_matches(ctx, f, 0, n1 < n2 ? n1 : n2, pairs, n_out);
+}

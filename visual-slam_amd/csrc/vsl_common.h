@@ -1,0 +1,129 @@
+// vsl_common.h -- internal definitions shared by the HIP translation units of libvslam_hip.so.
+// Written for gfx950 (MI355X) only: 64-lane wavefronts are assumed everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vslam_hip.h"
+
+#define VSL_WAVE 64
+
+struct vsl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  char err[512] = {0};
+  // per-stage profiling
+  bool profiling = false;
+  struct StageEv {
+    hipEvent_t a, b;
+    int stage;
+  };
+  std::vector<StageEv> pending;
+  std::vector<hipEvent_t> ev_pool;
+  double stage_ms[VSL_STAGE_COUNT] = {0};
+  int64_t stage_launches[VSL_STAGE_COUNT] = {0};
+  // scratch frame store used by the host-buffer entry points (lazily created)
+  struct vsl_frames* scratch = nullptr;
+  int scratch_w = 0, scratch_h = 0, scratch_feat = 0;
+  // generic device / pinned scratch
+  void* dscratch = nullptr;
+  size_t dscratch_cap = 0;
+  void* hpinned = nullptr;
+  size_t hpinned_cap = 0;
+  bool select_attr_set = false;
+  double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
+};
+
+int vsl_fail(vsl_ctx* ctx, int code, const char* fmt, ...);
+
+#define VSL_HIP(ctx, call)                                                                        \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return vsl_fail((ctx), VSL_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,            \
+                      hipGetErrorString(e_));                                                     \
+  } while (0)
+
+#define VSL_CHECK_LAUNCH(ctx)                                                                     \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess)                                                                         \
+      return vsl_fail((ctx), VSL_ERR_HIP, "%s:%d kernel launch -> %s", __FILE__, __LINE__,        \
+                      hipGetErrorString(e_));                                                     \
+  } while (0)
+
+// Grow-only device / pinned-host scratch owned by the context.
+int vsl_ctx_dscratch(vsl_ctx* ctx, size_t bytes, void** out);
+int vsl_ctx_hpinned(vsl_ctx* ctx, size_t bytes, void** out);
+
+// RAII stage timer: records events around a stage when profiling is enabled.
+struct VslStage {
+  vsl_ctx* ctx;
+  int idx = -1;
+  VslStage(vsl_ctx* c, int stage);
+  ~VslStage();
+};
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident frame store (see include/vslam_hip.h "device-resident batched frame store").
+// SoA per image slot; F = max_features; every array is dense so a range of slots is one launch.
+struct vsl_frames {
+  int device = 0;
+  int max_images = 0, w = 0, h = 0, F = 0, max_pairs = 0;
+  size_t cand_cap = 0;          // candidate capacity per image (w*h: every pixel may be a candidate)
+  uint8_t* images = nullptr;    // [max_images][h][w]
+  float* response = nullptr;    // [max_images][h][w]            K1 output
+  int32_t* resp_max = nullptr;  // [max_images] order-preserving int encoding of the fp32 maximum
+  uint64_t* cand = nullptr;     // [max_images][cand_cap]        (fp32 bits << 32 | pixel index)
+  int32_t* cand_count = nullptr;  // [max_images]
+  int32_t* kp_xy = nullptr;     // [max_images][F][2]            selected corners, response-descending
+  int32_t* kp_count = nullptr;  // [max_images]
+  int32_t* kp_moments = nullptr;  // [max_images][F][2]          (m01, m10), exact
+  double* kp_angle = nullptr;   // [max_images][F]
+  uint64_t* kp_desc = nullptr;  // [max_images][F][4]
+  // matcher
+  int32_t* pair_slots = nullptr;   // [max_pairs][2]
+  uint32_t* best_key = nullptr;    // [max_pairs][2][F]   (distance << 23 | index), direction 0: a->b
+  uint32_t* second_key = nullptr;  // [max_pairs][2][F]
+  int32_t* matches = nullptr;      // [max_pairs][F][2]
+  int32_t* match_count = nullptr;  // [max_pairs]
+  // rBRIEF near-tie records (see describe.hip)
+  int32_t* tie_count = nullptr;    // [1]
+  int32_t* tie_rec = nullptr;      // [tie_cap][4]  (slot, keypoint, bit, unused)
+  int tie_cap = 0;
+  bool ties_pending = false, ties_from_angles = false;
+  std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
+};
+
+int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_pairs, vsl_frames** out);
+
+// internal launchers (asynchronous on ctx->stream)
+int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features);
+int vsl_launch_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, int rotate_features,
+                        int from_angles);
+int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best);
+int vsl_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
+int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_pairs);
+
+// scratch store of the host-buffer API
+int vsl_ctx_scratch_frames(vsl_ctx* ctx, int w, int h, int feat, vsl_frames** out);
+
+// order-preserving float <-> int mapping for atomicMax on fp32 values of any sign
+__host__ __device__ inline int32_t vsl_float_to_ordered(float f) {
+  int32_t i;
+  memcpy(&i, &f, 4);
+  return i >= 0 ? i : (int32_t)(i ^ 0x7fffffff);
+}
+__host__ __device__ inline float vsl_ordered_to_float(int32_t i) {
+  int32_t j = i >= 0 ? i : (int32_t)(i ^ 0x7fffffff);
+  float f;
+  memcpy(&f, &j, 4);
+  return f;
+}
