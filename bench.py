@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native visual-SLAM hot path.
+
+Metric (BASELINE.json): stereo frames/sec on synthetic 752x480 stereo, 1500 features per frame
+(configs[1]); one rank per GPU, every rank owns independent streams (configs[3]: weak scaling, no
+data-path collective).
+
+One STEP = one pass of the per-frame hot path over a batch of B stereo frames already resident in
+HBM:   detectKeypointsAndDescriptors on 2B images (K1 response, K2 selection, K3+K4 orientation +
+rBRIEF-256)  ->  exactness guard (vsl_frames_resolve_ties: one stream sync + 4-byte readback)  ->
+matchDescriptors(left, right, 70, 1.2) on B pairs (K5).  Outputs stay in HBM (the PCIe-inclusive
+host-buffer rate is reported in DESIGN.md, never as `value`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel stage, timed with HIP events on
+the stream the kernels run on; `cpu_baseline` is the CPU oracle (a port of the reference's path, the
+reference itself cannot be built offline) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as entry  # noqa: E402
+
+W, H, NUM_FEATURES = 752, 480, 1500
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achievable)
+
+
+def stage_algorithmic_bytes(stage, n_img, n_pairs, kp_total, cand_total, match_total):
+    """Compulsory bytes of one launch of a stage over the whole batch (DESIGN.md 'Kernels')."""
+    px = W * H
+    if stage == "response":      # K1 + K2a: image in, fp32 response out and back in, candidate keys out
+        return n_img * (px + 4 * px + 4 * px) + 8 * cand_total
+    if stage == "select":        # K2b: candidate keys in, selected corners out
+        return 8 * cand_total + 8 * kp_total
+    if stage == "describe":      # K3+K4: 709-px disc + position in, moments/angle/descriptor out
+        return kp_total * (709 + 8 + 8 + 8 + 32)
+    if stage == "match":         # K5: both descriptor sets in, best/second keys out (both directions)
+        return kp_total * 32 + kp_total * 8
+    if stage == "match_finalize":
+        return kp_total * 8 + match_total * 8
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="stereo frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs per rank")
+    ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    vsl = entry.load_package()
+    synth = importlib.import_module("visual_slam_amd.synth")
+    B = args.batch
+    n_img = 2 * B
+
+    stream = torch.cuda.Stream()
+    ctx = vsl.Context(local_rank, stream=stream.cuda_stream)
+    frames = vsl.Frames(ctx, n_img, W, H, NUM_FEATURES, max_pairs=B)
+    pairs_img = [synth.stereo_pair(1000 * rank + 10 + i) for i in range(args.distinct)]
+    batch = np.stack([pairs_img[(k // 2) % args.distinct][k % 2] for k in range(n_img)])
+    frames.upload(0, batch)  # inputs resident in HBM before the timed region
+    slot_pairs = np.array([[2 * k, 2 * k + 1] for k in range(B)], np.int32)
+
+    def step():
+        frames.detect_describe(0, n_img, NUM_FEATURES, True)
+        frames.resolve_ties()
+        frames.match(slot_pairs, 70, 1.2)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    nk, nm = frames.counts(n_img, B)
+    if not (nk.min() > 0 and nm.min() > 0):
+        raise SystemExit("benchmark produced empty outputs: keypoints %s matches %s" % (nk.min(), nm.min()))
+
+    out = None
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        out = {
+            "metric": "stereo frames/sec, detect+describe (1500 feats) + stereo match, 752x480",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic 752x480 stereo, 1500 feats/frame (BASELINE configs[1]); "
+                                   "independent streams per GPU (configs[3])",
+                       "stereo_frames_per_step_per_gpu": B, "num_features": NUM_FEATURES,
+                       "match": "threshold 70, ratio 1.2, cross-check",
+                       "mean_keypoints_per_image": round(float(nk.mean()), 1),
+                       "mean_matches_per_pair": round(float(nm.mean()), 1)},
+        }
+
+        # ---- per-stage device time (HIP events on the kernels' stream), outside the timed region
+        ctx.set_profiling(True)
+        ctx.reset_profiling()
+        for _ in range(args.profile_steps):
+            step()
+        st = ctx.stage_ms()
+        ctx.set_profiling(False)
+        stages = {k: (ms / max(n, 1)) for k, (ms, n) in st.items() if n > 0}
+        dom = max(stages, key=stages.get)
+        # candidate counts for the byte model: read back once
+        kp_total, match_total = int(nk.sum()), int(nm.sum())
+        cand_total = int(frames.candidate_counts(n_img).sum())
+        out["config"]["mean_candidates_per_image"] = round(cand_total / n_img, 1)
+        ab = stage_algorithmic_bytes(dom, n_img, B, kp_total, cand_total, match_total)
+        achieved = ab / (stages[dom] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "algorithmic_bytes_per_launch": int(ab),
+                           "avg_launch_ms": round(stages[dom], 5)}
+        out["stage_ms_per_step"] = {k: round(v, 5) for k, v in stages.items()}
+
+        # ---- CPU baseline: the oracle (port of the reference path), 1 core, bounded sample
+        if args.cpu_frames > 0:
+            orc = entry.load_oracle()
+            t0 = time.perf_counter()
+            n_done = 0
+            while n_done < args.cpu_frames:
+                left, right = pairs_img[n_done % args.distinct]
+                _, _, d1 = orc.detect_describe(left, NUM_FEATURES, True)
+                _, _, d2 = orc.detect_describe(right, NUM_FEATURES, True)
+                orc.match_descriptors(d1, d2, 70, 1.2)
+                n_done += 1
+            cpu_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(n_done / cpu_s, 3), "unit": "frames/s", "cores": 1,
+                                   "kind": "port",
+                                   "sample": "%d synthetic stereo frames (same generator), oracle "
+                                             "detect+describe x2 + match, single thread (the reference's "
+                                             "keypoints.h path has no parallel loops)" % n_done}
+            out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+
+    frames.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -182,6 +182,11 @@ int vsl_frames_download_matches(vsl_ctx* ctx, vsl_frames* f, int pair, int cap_p
 int vsl_frames_download_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_t* n_keypoints,
                                int n_pairs, int32_t* n_matches);
 
+/* Diagnostic: number of corner candidates (3x3 local maxima above the quality threshold) each of
+ * the first n_images slots produced in its last detect call -- the input size of the selection
+ * stage, needed to price its traffic. */
+int vsl_frames_download_candidate_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_t* n_candidates);
+
 /* -------------------------------------------------------- bundle adjustment */
 /*
  * Replaces visnav::bundle_adjustment (include/visnav/map_utils.h:337-421) and

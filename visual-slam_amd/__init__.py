@@ -382,6 +382,12 @@ class Frames:
                                                             out.ctypes.data_as(i32p), C.byref(n)))
         return out[:n.value].copy()
 
+    def candidate_counts(self, n_images):
+        nc = np.zeros(max(n_images, 1), np.int32)
+        self.ctx._ck(self.ctx.L.vsl_frames_download_candidate_counts(self.ctx.h, self.h, int(n_images),
+                                                                     nc.ctypes.data_as(i32p)))
+        return nc[:n_images].copy()
+
     def counts(self, n_images, n_pairs):
         nk = np.zeros(max(n_images, 1), np.int32)
         nm = np.zeros(max(n_pairs, 1), np.int32)

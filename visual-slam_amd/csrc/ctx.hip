@@ -207,9 +207,8 @@ int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_
   bool ok = true;
   ok = ok && dalloc(&f->images, M * px) == hipSuccess;
   ok = ok && dalloc(&f->response, M * px) == hipSuccess;
-  ok = ok && dalloc(&f->resp_max, M) == hipSuccess;
+  ok = ok && dalloc(&f->meta, M * VSL_META_STRIDE) == hipSuccess;
   ok = ok && dalloc(&f->cand, M * f->cand_cap) == hipSuccess;
-  ok = ok && dalloc(&f->cand_count, M) == hipSuccess;
   ok = ok && dalloc(&f->kp_xy, M * F * 2) == hipSuccess;
   ok = ok && dalloc(&f->kp_count, M) == hipSuccess;
   ok = ok && dalloc(&f->kp_moments, M * F * 2) == hipSuccess;
@@ -243,7 +242,7 @@ extern "C" int vsl_frames_destroy(vsl_frames* f) {
   if (!f) return VSL_OK;
   (void)hipSetDevice(f->device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {f->images, f->response, f->resp_max, f->cand, f->cand_count, f->kp_xy, f->kp_count,
+  void* ptrs[] = {f->images, f->response, f->meta, f->cand, f->kp_xy, f->kp_count,
                   f->kp_moments, f->kp_angle, f->kp_desc, f->pair_slots, f->best_key, f->second_key,
                   f->matches, f->match_count, f->tie_count, f->tie_rec};
   for (void* p : ptrs)
@@ -291,6 +290,17 @@ extern "C" int vsl_frames_download_counts(vsl_ctx* ctx, vsl_frames* f, int n_ima
   if (n_pairs > 0 && n_matches)
     VSL_HIP(ctx, hipMemcpyAsync(n_matches, f->match_count, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VSL_OK;
+}
+
+extern "C" int vsl_frames_download_candidate_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_t* n_candidates) {
+  if (!ctx || !f || n_images < 0 || n_images > f->max_images || !n_candidates)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_download_candidate_counts: bad arguments");
+  if (n_images == 0) return VSL_OK;
+  std::vector<int32_t> m((size_t)n_images * VSL_META_STRIDE);
+  VSL_HIP(ctx, hipMemcpyAsync(m.data(), f->meta, sizeof(int32_t) * m.size(), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n_images; i++) n_candidates[i] = m[(size_t)i * VSL_META_STRIDE + VSL_META_NCAND];
   return VSL_OK;
 }
 

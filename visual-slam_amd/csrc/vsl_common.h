@@ -13,6 +13,9 @@
 #include "../../include/vslam_hip.h"
 
 #define VSL_WAVE 64
+#define VSL_META_STRIDE 32  // ints: 128 bytes per image
+#define VSL_META_MAX 0      // order-preserving int encoding of the fp32 response maximum
+#define VSL_META_NCAND 1    // number of corner candidates
 
 struct vsl_ctx {
   int device = 0;
@@ -80,9 +83,8 @@ struct vsl_frames {
   size_t cand_cap = 0;          // candidate capacity per image (w*h: every pixel may be a candidate)
   uint8_t* images = nullptr;    // [max_images][h][w]
   float* response = nullptr;    // [max_images][h][w]            K1 output
-  int32_t* resp_max = nullptr;  // [max_images] order-preserving int encoding of the fp32 maximum
+  int32_t* meta = nullptr;      // [max_images][VSL_META_STRIDE]: per-image counters on their own 128-B lines
   uint64_t* cand = nullptr;     // [max_images][cand_cap]        (fp32 bits << 32 | pixel index)
-  int32_t* cand_count = nullptr;  // [max_images]
   int32_t* kp_xy = nullptr;     // [max_images][F][2]            selected corners, response-descending
   int32_t* kp_count = nullptr;  // [max_images]
   int32_t* kp_moments = nullptr;  // [max_images][F][2]          (m01, m10), exact
