@@ -1,0 +1,136 @@
+"""GPU parity: K6/K7 + LM loop (visual-slam_amd/csrc/ba.hip) through the C ABI vs the oracle.
+
+Floating point (f64).  Tolerances, stated per quantity:
+  * residuals: 1e-11 px absolute (same formula, different evaluation order);
+  * Jacobian blocks: 1e-9 relative to the block's largest entry (closed form vs dual numbers);
+  * S, g of one linearisation: 1e-9 relative to max|S| / max|g| (fixed-order sums on both sides);
+  * bundle_adjust: same number of LM iterations and termination reason, final cost 1e-7 relative,
+    poses / landmarks within 1e-6 (m, unit-quaternion components) -- LM is iterative, so rounding-level
+    differences in the linear algebra are amplified by the condition of the reduced system.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INTR = {0: [350.0, 348.0, 365.0, 249.0, -0.24, 0.57, 0, 0],
+        1: [350.0, 348.0, 365.0, 249.0, 0, 0, 0, 0],
+        2: [350.0, 348.0, 365.0, 249.0, 0.6, 1.1, 0, 0],
+        3: [350.0, 348.0, 365.0, 249.0, 0.01, -0.004, 0.002, -0.0005]}
+
+
+def _arr(orc, d):
+    return orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"], d["obs_cam"],
+                        d["obs_lm"], d["obs_uv"], d["cam_model"])
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+def test_residual_and_jacobian_blocks(ctx, orc, synth, model):
+    d = synth.ba_problem(10 + model, n_kf=3, n_lms=400)
+    d["intr"] = np.array([INTR[model], INTR[model]])
+    d["cam_model"] = (model, model)
+    # shuffle the observation order: the C ABI must return blocks in the CALLER's order
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(d["obs_cam"]))
+    for k in ("obs_cam", "obs_lm", "obs_uv"):
+        d[k] = d[k][perm]
+    arr = _arr(orc, d)
+    r, Jp, Jl = ctx.ba_residuals_jacobians(arr)
+    for i in range(0, len(arr.obs_cam), 7):
+        c, l = arr.obs_cam[i], arr.obs_lm[i]
+        er, eJp, eJl = orc.ba_residual_jacobian(model, arr.poses[c], arr.points[l], arr.intr[arr.cam_intr[c]], arr.obs_uv[i])
+        assert np.allclose(r[i], er, rtol=0, atol=1e-11)
+        assert np.allclose(Jp[i], eJp, rtol=0, atol=1e-9 * np.abs(eJp).max())
+        assert np.allclose(Jl[i], eJl, rtol=0, atol=1e-9 * np.abs(eJl).max())
+
+
+@pytest.mark.parametrize("huber", [True, False])
+def test_linearize_S_g_cost(ctx, orc, synth, huber):
+    d = synth.ba_problem(21, n_kf=5, n_lms=1500)
+    arr = _arr(orc, d)
+    S, g, c = ctx.ba_linearize(arr, use_huber=huber)
+    eS, eg, ec = orc.ba_linearize(arr, use_huber=huber)
+    assert c == pytest.approx(ec, rel=1e-12)
+    assert np.allclose(S, eS, rtol=0, atol=1e-9 * np.abs(eS).max())
+    assert np.allclose(g, eg, rtol=0, atol=1e-9 * np.abs(eg).max())
+
+
+def test_linearize_partition_is_additive(ctx, orc, synth):
+    d = synth.ba_problem(22, n_kf=4, n_lms=900)
+    arr = _arr(orc, d)
+    S, g, c = ctx.ba_linearize(arr)
+    L = len(arr.points)
+    cuts = [0, L // 4, L // 4, L // 2 + 3, L]  # includes an empty range
+    Ss, gs, cs = 0, 0, 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        S1, g1, c1 = ctx.ba_linearize(arr, lm_first=a, lm_count=b - a)
+        eS1, eg1, ec1 = orc.ba_linearize(arr, lm_first=a, lm_count=b - a)
+        assert np.allclose(S1, eS1, rtol=0, atol=1e-9 * max(np.abs(eS1).max(), 1.0))
+        assert c1 == pytest.approx(ec1, rel=1e-12, abs=1e-12)
+        Ss, gs, cs = Ss + S1, gs + g1, cs + c1
+    assert np.allclose(Ss, S, rtol=0, atol=1e-9 * np.abs(S).max())
+    assert np.allclose(gs, g, rtol=0, atol=1e-9 * np.abs(g).max())
+    assert cs == pytest.approx(c, rel=1e-12)
+
+
+@pytest.mark.parametrize("seed,n_kf,n_lms", [(31, 3, 300), (32, 7, 3000), (33, 10, 2000)])
+def test_bundle_adjust_matches_oracle(ctx, orc, synth, seed, n_kf, n_lms):
+    d = synth.ba_problem(seed, n_kf=n_kf, n_lms=n_lms)
+    a_gpu, a_cpu = _arr(orc, d), _arr(orc, d)
+    s_gpu = ctx.bundle_adjust(a_gpu, max_iters=20)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=20)
+    assert s_gpu.initial_cost == pytest.approx(s_cpu.initial_cost, rel=1e-12)
+    assert (s_gpu.iterations, s_gpu.termination, s_gpu.successful_steps) == \
+           (s_cpu.iterations, s_cpu.termination, s_cpu.successful_steps)
+    assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
+    assert np.allclose(a_gpu.poses, a_cpu.poses, rtol=0, atol=1e-6)
+    assert np.allclose(a_gpu.points, a_cpu.points, rtol=0, atol=1e-6)
+    assert s_gpu.final_cost < s_gpu.initial_cost
+    fixed = d["cam_fixed"].astype(bool)
+    assert np.array_equal(a_gpu.poses[fixed], d["poses"][fixed])
+
+
+def test_bundle_adjust_no_huber_and_iteration_cap(ctx, orc, synth):
+    d = synth.ba_problem(41, n_kf=4, n_lms=600, outlier_frac=0.0)
+    a_gpu, a_cpu = _arr(orc, d), _arr(orc, d)
+    s_gpu = ctx.bundle_adjust(a_gpu, use_huber=False, max_iters=3)
+    s_cpu = orc.bundle_adjust(a_cpu, use_huber=False, max_iters=3)
+    assert s_gpu.iterations == s_cpu.iterations == 3
+    assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-8)
+    assert np.allclose(a_gpu.points, a_cpu.points, rtol=0, atol=1e-7)
+
+
+def test_bundle_adjust_is_run_to_run_reproducible(ctx, orc, synth):
+    # small-system path: fixed-order reductions, no floating-point atomics -> bit-identical reruns
+    d = synth.ba_problem(51, n_kf=6, n_lms=2500)
+    a1, a2 = _arr(orc, d), _arr(orc, d)
+    ctx.bundle_adjust(a1, max_iters=8)
+    ctx.bundle_adjust(a2, max_iters=8)
+    assert np.array_equal(a1.poses, a2.poses) and np.array_equal(a1.points, a2.points)
+
+
+def test_large_system_path(ctx, orc, synth):
+    # > 21 free cameras: wavefront-per-landmark atomics + blocked dense Cholesky (global-BA path)
+    d = synth.ba_problem(61, n_kf=40, n_lms=6000, loop_radius=6.0)
+    arr = _arr(orc, d)
+    assert arr.n_free * 6 > 128
+    S, g, c = ctx.ba_linearize(arr)
+    eS, eg, ec = orc.ba_linearize(arr)
+    assert c == pytest.approx(ec, rel=1e-12)
+    assert np.allclose(S, eS, rtol=0, atol=1e-9 * np.abs(eS).max())
+    assert np.allclose(g, eg, rtol=0, atol=1e-9 * np.abs(eg).max())
+    a_gpu, a_cpu = _arr(orc, d), _arr(orc, d)
+    s_gpu = ctx.bundle_adjust(a_gpu, max_iters=6)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=6)
+    assert s_gpu.iterations == s_cpu.iterations
+    assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-6)
+    assert np.allclose(a_gpu.points, a_cpu.points, rtol=0, atol=1e-5)
+
+
+def test_bad_arguments(ctx, orc, synth, vsl):
+    d = synth.ba_problem(71, n_kf=3, n_lms=100)
+    arr = _arr(orc, d)
+    arr.obs_cam[0] = 99
+    with pytest.raises(vsl.VslError) as e:
+        ctx.bundle_adjust(arr)
+    assert e.value.code == -1

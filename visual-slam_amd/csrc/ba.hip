@@ -1,0 +1,1355 @@
+// ba.hip -- K6 (reprojection residual + Jacobian blocks) and K7 (Schur-complement reduction) plus the
+// Levenberg-Marquardt loop that drives them.
+//
+// Replaces visnav::bundle_adjustment (include/visnav/map_utils.h:337-421) and
+// visnav::global_bundle_adjustment (include/visnav/loop_closure_utils.h:672-748), i.e. what
+// ceres::Solve does with BundleAdjustmentReprojectionCostFunctor (include/visnav/reprojection.h:81-105),
+// the four camera models (include/visnav/camera_models.h), LocalParameterizationSE3
+// (include/visnav/local_parameterization_se3.hpp:43-63), HuberLoss and SPARSE_SCHUR.
+//
+// Differences in HOW (the WHAT is the same optimisation problem and the same LM policy, restated in
+// oracle/orc_ba.cpp from [upstream] Ceres 2.0/2.1):
+//   * derivatives are closed-form 2x6 / 2x3 blocks in the tangent space of T*exp(delta), not dual
+//     numbers through the quaternion followed by the 7x6 plus-Jacobian;
+//   * observations are stored sorted by landmark; every reduction runs in a fixed order (per-landmark
+//     loops, per-camera tree reductions, thread-owned Schur entries), so a solve is bit-reproducible
+//     from run to run -- no floating-point atomics on the small-system path;
+//   * Schur complement, small systems (6*free cameras <= 128, the local-BA window): each of the
+//     (6C)^2 entries of S is OWNED by one thread of a 1024-thread workgroup, which keeps it in a
+//     register while the workgroup streams its share of the landmarks through LDS (per landmark:
+//     W = F^T E and Y = W P^-1 per observation, plus a camera->observation slot table).  Per-workgroup
+//     partial matrices are summed in a fixed order afterwards.
+//   * large systems (global BA): one wavefront per landmark, fp64 hardware atomics into the dense S,
+//     blocked dense Cholesky (chol.hip).
+//
+// Algorithmic bytes per LM iteration: n_obs*(16 + 8) + n_lms*24 + n_cams*56 + 128 in;
+// (6C)^2*8 + 6C*8 + n_lms*96 out.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <numeric>
+
+#include "vsl_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- device helpers
+struct Proj {
+  double u, v;
+  double J[6];  // d(u,v)/d(x,y,z) row-major 2x3
+};
+
+// camera_models.h project() of the four models + closed-form derivative.
+__device__ __forceinline__ void project_jac(int model, const double* __restrict__ ip, double x, double y, double z,
+                                            Proj& o, bool want_jac) {
+  const double fx = ip[0], fy = ip[1], cx = ip[2], cy = ip[3];
+  if (model == VSL_CAM_PINHOLE) {
+    o.u = fx * x / z + cx;
+    o.v = fy * y / z + cy;
+    if (want_jac) {
+      const double iz = 1.0 / z;
+      o.J[0] = fx * iz; o.J[1] = 0; o.J[2] = -fx * x * iz * iz;
+      o.J[3] = 0; o.J[4] = fy * iz; o.J[5] = -fy * y * iz * iz;
+    }
+  } else if (model == VSL_CAM_EUCM) {
+    const double alpha = ip[4], beta = ip[5];
+    const double d = sqrt(beta * (x * x + y * y) + z * z);
+    const double den = alpha * d + (1.0 - alpha) * z;
+    o.u = fx * x / den + cx;
+    o.v = fy * y / den + cy;
+    if (want_jac) {
+      const double dd[3] = {beta * x / d, beta * y / d, z / d};
+      const double dn[3] = {alpha * dd[0], alpha * dd[1], alpha * dd[2] + (1.0 - alpha)};
+      const double id = 1.0 / den, id2 = id * id;
+      o.J[0] = fx * (id - x * dn[0] * id2); o.J[1] = -fx * x * dn[1] * id2; o.J[2] = -fx * x * dn[2] * id2;
+      o.J[3] = -fy * y * dn[0] * id2; o.J[4] = fy * (id - y * dn[1] * id2); o.J[5] = -fy * y * dn[2] * id2;
+    }
+  } else if (model == VSL_CAM_KB4) {
+    const double k1 = ip[4], k2 = ip[5], k3 = ip[6], k4 = ip[7];
+    const double r = sqrt(x * x + y * y);
+    const double th = atan2(r, z);
+    const double t2 = th * th;
+    const double d = th + k1 * th * th * th + k2 * th * th * th * th * th + k3 * th * th * th * th * th * th * th +
+                     k4 * th * th * th * th * th * th * th * th * th;
+    if (r == 0.0) {
+      o.u = cx;
+      o.v = cy;
+      if (want_jac) {  // limit r -> 0: d/r -> 1/z
+        o.J[0] = fx / z; o.J[1] = 0; o.J[2] = 0;
+        o.J[3] = 0; o.J[4] = fy / z; o.J[5] = 0;
+      }
+    } else {
+      o.u = fx * d * x / r + cx;
+      o.v = fy * d * y / r + cy;
+      if (want_jac) {
+        const double dp = 1.0 + t2 * (3 * k1 + t2 * (5 * k2 + t2 * (7 * k3 + t2 * 9 * k4)));
+        const double n2 = r * r + z * z;
+        const double dth[3] = {z * x / (r * n2), z * y / (r * n2), -r / n2};
+        const double ir = 1.0 / r, ir3 = ir * ir * ir;
+        const double xr[3] = {y * y * ir3, -x * y * ir3, 0.0};  // d(x/r)
+        const double yr[3] = {-x * y * ir3, x * x * ir3, 0.0};  // d(y/r)
+        for (int k = 0; k < 3; k++) {
+          o.J[k] = fx * (x * ir * dp * dth[k] + d * xr[k]);
+          o.J[3 + k] = fy * (y * ir * dp * dth[k] + d * yr[k]);
+        }
+      }
+    }
+  } else {  // double sphere
+    const double xi = ip[4], alpha = ip[5];
+    const double d1 = sqrt(x * x + y * y + z * z);
+    const double k = xi * d1 + z;
+    const double d2 = sqrt(x * x + y * y + k * k);
+    const double den = alpha * d2 + (1.0 - alpha) * k;
+    o.u = fx * x / den + cx;
+    o.v = fy * y / den + cy;
+    if (want_jac) {
+      const double id1 = 1.0 / d1;
+      const double dk[3] = {xi * x * id1, xi * y * id1, xi * z * id1 + 1.0};
+      const double id2 = 1.0 / d2;
+      const double dd2[3] = {(x + k * dk[0]) * id2, (y + k * dk[1]) * id2, (k * dk[2]) * id2};
+      const double dn[3] = {alpha * dd2[0] + (1.0 - alpha) * dk[0], alpha * dd2[1] + (1.0 - alpha) * dk[1],
+                            alpha * dd2[2] + (1.0 - alpha) * dk[2]};
+      const double id = 1.0 / den, idd = id * id;
+      o.J[0] = fx * (id - x * dn[0] * idd); o.J[1] = -fx * x * dn[1] * idd; o.J[2] = -fx * x * dn[2] * idd;
+      o.J[3] = -fy * y * dn[0] * idd; o.J[4] = fy * (id - y * dn[1] * idd); o.J[5] = -fy * y * dn[2] * idd;
+    }
+  }
+}
+
+__device__ __forceinline__ void quat_R(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// residual r = uv - project(R^T (p - t));  F = dr/d(upsilon, omega) (2x6), E = dr/dp_w (2x3)
+__device__ __forceinline__ void residual_blocks(int model, const double* __restrict__ intr, const double* pose,
+                                                const double* pw, const double* uv, double* r, double* F, double* E,
+                                                bool want_jac) {
+  double R[9];
+  quat_R(pose, R);
+  const double d[3] = {pw[0] - pose[4], pw[1] - pose[5], pw[2] - pose[6]};
+  const double pc[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
+                        R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
+  Proj pj;
+  project_jac(model, intr, pc[0], pc[1], pc[2], pj, want_jac);
+  r[0] = uv[0] - pj.u;
+  r[1] = uv[1] - pj.v;
+  if (!want_jac) return;
+  const double* J = pj.J;
+  // d p_c / d(upsilon, omega) = [-I | [p_c]x]  =>  F = [J | -J [p_c]x]
+  for (int a = 0; a < 2; a++) {
+    const double j0 = J[3 * a], j1 = J[3 * a + 1], j2 = J[3 * a + 2];
+    F[6 * a + 0] = j0;
+    F[6 * a + 1] = j1;
+    F[6 * a + 2] = j2;
+    // -J [p]x, [p]x = [0 -pz py; pz 0 -px; -py px 0]
+    F[6 * a + 3] = -(j1 * pc[2] - j2 * pc[1]);
+    F[6 * a + 4] = -(-j0 * pc[2] + j2 * pc[0]);
+    F[6 * a + 5] = -(j0 * pc[1] - j1 * pc[0]);
+    // E = -J R^T
+    for (int k = 0; k < 3; k++) E[3 * a + k] = -(j0 * R[3 * k] + j1 * R[3 * k + 1] + j2 * R[3 * k + 2]);
+  }
+}
+
+__device__ __forceinline__ void huber(double s, double a, double& rho0, double& rho1) {
+  const double b = a * a;
+  if (s > b) {
+    const double r = sqrt(s);
+    rho0 = 2 * a * r - b;
+    rho1 = fmax(2.2250738585072014e-308, a / r);
+  } else {
+    rho0 = s;
+    rho1 = 1.0;
+  }
+}
+
+// deterministic workgroup sum (256 threads): value returned in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  return sh[0];
+}
+
+struct BaDims {
+  int C, L, O, nfree, n;
+  int model0, model1;
+  int use_huber;
+  double huber;
+};
+
+// ---------------------------------------------------------------------------------------- kernels
+// K6.  One thread per observation (observations sorted by landmark).  Writes the robustified (and, when
+// scale_c/scale_l are given, Jacobi-scaled) blocks and a per-workgroup cost partial.
+__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDims D, const double* __restrict__ poses,
+                                                           const double* __restrict__ points,
+                                                           const double* __restrict__ intr,
+                                                           const int* __restrict__ cam_intr,
+                                                           const int* __restrict__ cam_free,
+                                                           const int* __restrict__ obs_cam,
+                                                           const int* __restrict__ obs_lm,
+                                                           const double* __restrict__ obs_uv,
+                                                           const double* __restrict__ scale_c,
+                                                           const double* __restrict__ scale_l, double* __restrict__ r_out,
+                                                           double* __restrict__ F_out, double* __restrict__ E_out,
+                                                           double* __restrict__ partials, int robust) {
+  __shared__ double sh[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double c = 0;
+  if (i < D.O) {
+    const int cam = obs_cam[i], lm = obs_lm[i], k = cam_intr[cam];
+    double r[2], F[12], E[6];
+    residual_blocks(k ? D.model1 : D.model0, intr + 8 * k, poses + 7 * cam, points + 3 * lm, obs_uv + 2 * i, r, F, E,
+                    true);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    double rho0 = s, rho1 = 1.0;
+    if (D.use_huber) huber(s, D.huber, rho0, rho1);
+    c = 0.5 * rho0;
+    const double sr = robust ? sqrt(rho1) : 1.0;
+    r_out[2 * (size_t)i] = r[0] * sr;
+    r_out[2 * (size_t)i + 1] = r[1] * sr;
+    const int fc = cam_free[cam];
+    for (int j = 0; j < 6; j++) {
+      const double sc = (scale_c && fc >= 0) ? scale_c[6 * fc + j] : 1.0;
+      F_out[12 * (size_t)i + j] = F[j] * sr * sc;
+      F_out[12 * (size_t)i + 6 + j] = F[6 + j] * sr * sc;
+    }
+    for (int j = 0; j < 3; j++) {
+      const double sc = scale_l ? scale_l[3 * lm + j] : 1.0;
+      E_out[6 * (size_t)i + j] = E[j] * sr * sc;
+      E_out[6 * (size_t)i + 3 + j] = E[3 + j] * sr * sc;
+    }
+  }
+  const double t = block_sum_256(c, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// cost only, at candidate parameters
+__global__ __launch_bounds__(256) void ba_cost_kernel(BaDims D, const double* __restrict__ poses,
+                                                      const double* __restrict__ points, const double* __restrict__ intr,
+                                                      const int* __restrict__ cam_intr, const int* __restrict__ obs_cam,
+                                                      const int* __restrict__ obs_lm, const double* __restrict__ obs_uv,
+                                                      int o_first, int o_count, double* __restrict__ partials) {
+  __shared__ double sh[256];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  double c = 0;
+  if (t < o_count) {
+    const int i = o_first + t;
+    const int cam = obs_cam[i], lm = obs_lm[i], k = cam_intr[cam];
+    double r[2];
+    residual_blocks(k ? D.model1 : D.model0, intr + 8 * k, poses + 7 * cam, points + 3 * lm, obs_uv + 2 * i, r, nullptr,
+                    nullptr, false);
+    const double s = r[0] * r[0] + r[1] * r[1];
+    double rho0 = s, rho1 = 1.0;
+    if (D.use_huber) huber(s, D.huber, rho0, rho1);
+    c = 0.5 * rho0;
+  }
+  const double v = block_sum_256(c, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+
+// scalars[slot] = sum / max of partials[0..n) in a fixed order (one workgroup)
+__global__ __launch_bounds__(256) void ba_reduce_kernel(const double* __restrict__ partials, int n,
+                                                        double* __restrict__ scalars, int slot, int is_max) {
+  __shared__ double sh[256];
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += 256) v = is_max ? fmax(v, partials[i]) : v + partials[i];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + o]) : sh[threadIdx.x] + sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scalars[slot] = sh[0];
+}
+
+// per-landmark column statistics: squared column norms of E and E^T r
+__global__ __launch_bounds__(256) void ba_lm_cols_kernel(BaDims D, const int* __restrict__ lm_start,
+                                                         const double* __restrict__ r, const double* __restrict__ E,
+                                                         double* __restrict__ n2l, double* __restrict__ grad_l) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= D.L) return;
+  double n2[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+  for (int i = lm_start[l]; i < lm_start[l + 1]; i++) {
+    const double* e = E + 6 * (size_t)i;
+    const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+    for (int j = 0; j < 3; j++) {
+      n2[j] += e[j] * e[j] + e[3 + j] * e[3 + j];
+      g[j] += e[j] * r0 + e[3 + j] * r1;
+    }
+  }
+  for (int j = 0; j < 3; j++) {
+    n2l[3 * (size_t)l + j] = n2[j];
+    grad_l[3 * (size_t)l + j] = g[j];
+  }
+}
+
+// per-camera normal-equation block: H = sum F^T F (6x6) and g = sum F^T r over the camera's
+// observations (camera CSR), one workgroup per free camera, fixed-order tree reduction.
+__global__ __launch_bounds__(256) void ba_cam_block_kernel(const int* __restrict__ free_cams,
+                                                           const int* __restrict__ cam_start,
+                                                           const int* __restrict__ cam_obs, const double* __restrict__ r,
+                                                           const double* __restrict__ F, double* __restrict__ H,
+                                                           double* __restrict__ g) {
+  __shared__ double sh[256];
+  const int fc = blockIdx.x;
+  const int cam = free_cams[fc];
+  double acc[27];
+  for (int k = 0; k < 27; k++) acc[k] = 0;
+  for (int q = cam_start[cam] + threadIdx.x; q < cam_start[cam + 1]; q += 256) {
+    const int i = cam_obs[q];
+    const double* f = F + 12 * (size_t)i;
+    const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+      for (int b = a; b < 6; b++) acc[k++] += f[a] * f[b] + f[6 + a] * f[6 + b];
+    for (int a = 0; a < 6; a++) acc[21 + a] += f[a] * r0 + f[6 + a] * r1;
+  }
+  double tot[27];
+  for (int k = 0; k < 27; k++) {
+    tot[k] = block_sum_256(acc[k], sh);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+      for (int b = a; b < 6; b++) {
+        H[36 * (size_t)fc + 6 * a + b] = tot[k];
+        H[36 * (size_t)fc + 6 * b + a] = tot[k];
+        k++;
+      }
+    for (int a = 0; a < 6; a++) g[6 * (size_t)fc + a] = tot[21 + a];
+  }
+}
+
+// Jacobi scaling (computed once): scale = 1 / (1 + sqrt(column norm^2)); for cameras from diag(H)
+__global__ void ba_make_scale_kernel(int nfree, int L, const double* __restrict__ H, const double* __restrict__ n2l,
+                                     double* __restrict__ scale_c, double* __restrict__ scale_l) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * nfree) scale_c[i] = 1.0 / (1.0 + sqrt(H[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+  if (i < 3 * L) scale_l[i] = 1.0 / (1.0 + sqrt(n2l[i]));
+}
+
+__global__ void ba_apply_scale_kernel(int O, const int* __restrict__ cam_free, const int* __restrict__ obs_cam,
+                                      const int* __restrict__ obs_lm, const double* __restrict__ scale_c,
+                                      const double* __restrict__ scale_l, double* __restrict__ F, double* __restrict__ E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O) return;
+  const int fc = cam_free[obs_cam[i]], lm = obs_lm[i];
+  if (fc >= 0)
+    for (int j = 0; j < 6; j++) {
+      F[12 * (size_t)i + j] *= scale_c[6 * fc + j];
+      F[12 * (size_t)i + 6 + j] *= scale_c[6 * fc + j];
+    }
+  for (int j = 0; j < 3; j++) {
+    E[6 * (size_t)i + j] *= scale_l[3 * lm + j];
+    E[6 * (size_t)i + 3 + j] *= scale_l[3 * lm + j];
+  }
+}
+
+// gradient max-norm of the UNSCALED problem: |g_scaled / scale|, and LM diagonals
+//   diag = clamp(col norm^2, 1e-6, 1e32) (kept when reuse != 0), D2 = diag / radius
+__global__ void ba_diag_kernel(int nfree, int L, const double* __restrict__ H, const double* __restrict__ n2l,
+                               const double* __restrict__ g_c, const double* __restrict__ grad_l,
+                               const double* __restrict__ scale_c, const double* __restrict__ scale_l,
+                               double* __restrict__ diag_c, double* __restrict__ diag_l, double* __restrict__ gabs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nc = 6 * nfree, nl = 3 * L;
+  if (i < nc) {
+    diag_c[i] = fmin(fmax(H[36 * (size_t)(i / 6) + 7 * (i % 6)], 1e-6), 1e32);
+    gabs[i] = fabs(g_c[i] / scale_c[i]);
+  }
+  if (i < nl) {
+    diag_l[i] = fmin(fmax(n2l[i], 1e-6), 1e32);
+    gabs[nc + i] = fabs(grad_l[i] / scale_l[i]);
+  }
+}
+
+inline __device__ bool inv3(const double* P, double* Pi) {
+  const double a = P[0], b = P[1], c = P[2], d = P[4], e = P[5], f = P[8];
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (!(fabs(det) > 0.0) || !isfinite(det)) return false;
+  const double id = 1.0 / det;
+  Pi[0] = c00 * id; Pi[1] = c01 * id; Pi[2] = c02 * id;
+  Pi[3] = Pi[1]; Pi[4] = (a * f - c * c) * id; Pi[5] = (b * c - a * e) * id;
+  Pi[6] = Pi[2]; Pi[7] = Pi[5]; Pi[8] = (a * d - b * b) * id;
+  return true;
+}
+
+// K7, small systems.  See the file header.  LB landmarks are staged per barrier pair.
+#define SCH_THREADS 1024
+#define SCH_LB 8
+#define SCH_KMAX 24   // observations of one landmark that hit FREE cameras (<= free cameras <= 21)
+#define SCH_EPT 16    // owned entries per thread: n <= 128
+#define SCH_CMAX 22   // free cameras
+
+__global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
+    BaDims D, const int* __restrict__ lm_start, const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
+    const double* __restrict__ r, const double* __restrict__ F, const double* __restrict__ E,
+    const double* __restrict__ diag_l, double inv_radius, int l_first, int l_count, int lm_per_wg,
+    double* __restrict__ S_part, double* __restrict__ rhs_part, double* __restrict__ Pinv_out,
+    double* __restrict__ bl_out) {
+  __shared__ double W[SCH_LB][SCH_KMAX][18];
+  __shared__ double Y[SCH_LB][SCH_KMAX][18];
+  __shared__ double Pi_s[SCH_LB][9];
+  __shared__ double b_s[SCH_LB][3];
+  __shared__ int slot[SCH_LB][SCH_CMAX];
+  __shared__ int kcnt[SCH_LB];
+  __shared__ int ok_s[SCH_LB];
+  const int n = D.n, tid = threadIdx.x;
+  const int wl0 = l_first + blockIdx.x * lm_per_wg;
+  const int wl1 = min(l_first + l_count, wl0 + lm_per_wg);
+  double acc[SCH_EPT];
+  int ei[SCH_EPT];  // packed (c1, x, c2, y) of the owned entries
+#pragma unroll
+  for (int e = 0; e < SCH_EPT; e++) {
+    acc[e] = 0;
+    const int idx = tid + e * SCH_THREADS;
+    if (idx < n * n) {
+      const int i = idx / n, j = idx - i * n;
+      ei[e] = (i / 6) | ((i % 6) << 8) | ((j / 6) << 16) | ((j % 6) << 24);
+    } else {
+      ei[e] = -1;
+    }
+  }
+  double racc = 0;  // thread tid < n owns rhs[tid]
+  for (int s0 = wl0; s0 < wl1; s0 += SCH_LB) {
+    const int nl = min(SCH_LB, wl1 - s0);
+    // phase A: per landmark P, b, P^-1 and the slot table (one thread per landmark)
+    if (tid < nl) {
+      const int l = s0 + tid;
+      double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+      if (diag_l) {
+        P[0] = diag_l[3 * (size_t)l] * inv_radius;
+        P[4] = diag_l[3 * (size_t)l + 1] * inv_radius;
+        P[8] = diag_l[3 * (size_t)l + 2] * inv_radius;
+      }
+      for (int c = 0; c < SCH_CMAX; c++) slot[tid][c] = -1;
+      int k = 0;
+      for (int i = lm_start[l]; i < lm_start[l + 1]; i++) {
+        const double* e = E + 6 * (size_t)i;
+        const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+        for (int x = 0; x < 3; x++) {
+          for (int y = 0; y < 3; y++) P[3 * x + y] += e[x] * e[y] + e[3 + x] * e[3 + y];
+          bb[x] += e[x] * r0 + e[3 + x] * r1;
+        }
+        const int fc = cam_free[obs_cam[i]];
+        if (fc >= 0 && k < SCH_KMAX) {
+          slot[tid][fc] = k;
+          k++;
+        }
+      }
+      double Pi[9];
+      const bool ok = lm_start[l + 1] > lm_start[l] && inv3(P, Pi);
+      ok_s[tid] = ok;
+      kcnt[tid] = ok ? k : 0;
+      for (int q = 0; q < 9; q++) Pi_s[tid][q] = ok ? Pi[q] : 0.0;
+      for (int q = 0; q < 3; q++) b_s[tid][q] = ok ? bb[q] : 0.0;
+      if (Pinv_out)
+        for (int q = 0; q < 9; q++) Pinv_out[9 * (size_t)l + q] = ok ? Pi[q] : 0.0;
+      if (bl_out)
+        for (int q = 0; q < 3; q++) bl_out[3 * (size_t)l + q] = ok ? bb[q] : 0.0;
+    }
+    __syncthreads();
+    // phase B: W = F^T E (6x3) and Y = W P^-1 for every free-camera observation of the staged landmarks
+    for (int item = tid; item < nl * SCH_KMAX * 6; item += SCH_THREADS) {
+      const int li = item / (SCH_KMAX * 6), rem = item - li * (SCH_KMAX * 6);
+      const int q = rem / 6, x = rem - q * 6;
+      if (q >= kcnt[li]) continue;
+      // find the q-th free-camera observation of landmark s0+li
+      const int l = s0 + li;
+      int i = lm_start[l], seen = -1;
+      for (; i < lm_start[l + 1]; i++) {
+        if (cam_free[obs_cam[i]] >= 0) seen++;
+        if (seen == q) break;
+      }
+      const double* f = F + 12 * (size_t)i;
+      const double* e = E + 6 * (size_t)i;
+      double w[3];
+      for (int y = 0; y < 3; y++) w[y] = f[x] * e[y] + f[6 + x] * e[3 + y];
+      const double* Pi = Pi_s[li];
+      for (int y = 0; y < 3; y++) {
+        W[li][q][3 * x + y] = w[y];
+        Y[li][q][3 * x + y] = w[0] * Pi[y] + w[1] * Pi[3 + y] + w[2] * Pi[6 + y];
+      }
+    }
+    __syncthreads();
+    // phase C: owned entries
+    for (int li = 0; li < nl; li++) {
+      if (!ok_s[li]) continue;
+#pragma unroll
+      for (int e = 0; e < SCH_EPT; e++) {
+        const int pk = ei[e];
+        if (pk < 0) continue;
+        const int q1 = slot[li][pk & 0xFF], q2 = slot[li][(pk >> 16) & 0xFF];
+        if (q1 < 0 || q2 < 0) continue;
+        const double* y1 = &Y[li][q1][3 * ((pk >> 8) & 0xFF)];
+        const double* w2 = &W[li][q2][3 * ((pk >> 24) & 0xFF)];
+        acc[e] -= y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2];
+      }
+      if (tid < n) {
+        const int q1 = slot[li][tid / 6];
+        if (q1 >= 0) {
+          const double* y1 = &Y[li][q1][3 * (tid % 6)];
+          racc -= y1[0] * b_s[li][0] + y1[1] * b_s[li][1] + y1[2] * b_s[li][2];
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < SCH_EPT; e++) {
+    const int idx = tid + e * SCH_THREADS;
+    if (idx < n * n) S_part[(size_t)blockIdx.x * n * n + idx] = acc[e];
+  }
+  if (tid < n) rhs_part[(size_t)blockIdx.x * n + tid] = racc;
+}
+
+// S = sum_g S_part[g] (fixed order) + blockdiag(H) + diag(D2_c);  rhs = sum_g rhs_part[g] + g_c
+__global__ void ba_schur_finish_kernel(int n, int G, const double* __restrict__ S_part, const double* __restrict__ rhs_part,
+                                       const double* __restrict__ H, const double* __restrict__ g_c,
+                                       const double* __restrict__ diag_c, double inv_radius, double* __restrict__ S,
+                                       double* __restrict__ rhs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n * n) {
+    double v = 0;
+    for (int g = 0; g < G; g++) v += S_part[(size_t)g * n * n + idx];
+    const int i = idx / n, j = idx - i * n;
+    if (i / 6 == j / 6) v += H[36 * (size_t)(i / 6) + 6 * (i % 6) + (j % 6)];
+    if (i == j && diag_c) v += diag_c[i] * inv_radius;
+    S[idx] = v;
+  }
+  if (idx < n) {
+    double v = 0;
+    for (int g = 0; g < G; g++) v += rhs_part[(size_t)g * n + idx];
+    rhs[idx] = v + g_c[idx];
+  }
+}
+
+// K7, large systems: one wavefront per landmark, fp64 hardware atomics into the dense S.
+__global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const int* __restrict__ lm_start,
+                                                              const int* __restrict__ obs_cam,
+                                                              const int* __restrict__ cam_free, const double* __restrict__ r,
+                                                              const double* __restrict__ F, const double* __restrict__ E,
+                                                              const double* __restrict__ diag_l, double inv_radius,
+                                                              int l_first, int l_count, double* __restrict__ S,
+                                                              double* __restrict__ rhs, double* __restrict__ Pinv_out,
+                                                              double* __restrict__ bl_out) {
+  constexpr int KM = 64;
+  __shared__ double Ws[4][KM][18];
+  __shared__ double Ys[4][KM][18];
+  __shared__ int cs[4][KM];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = l_first + blockIdx.x * 4 + wave;
+  if (l >= l_first + l_count) return;
+  const int a = lm_start[l], b = lm_start[l + 1];
+  if (a == b) return;
+  const int n = D.n;
+  // P and b: lanes stride the observations, xor-shuffle tree reduction (fixed order)
+  double P[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};  // P upper: 00 01 02 11 12 22
+  for (int i = a + lane; i < b; i += 64) {
+    const double* e = E + 6 * (size_t)i;
+    const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+    P[0] += e[0] * e[0] + e[3] * e[3];
+    P[1] += e[0] * e[1] + e[3] * e[4];
+    P[2] += e[0] * e[2] + e[3] * e[5];
+    P[3] += e[1] * e[1] + e[4] * e[4];
+    P[4] += e[1] * e[2] + e[4] * e[5];
+    P[5] += e[2] * e[2] + e[5] * e[5];
+    for (int x = 0; x < 3; x++) bb[x] += e[x] * r0 + e[3 + x] * r1;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int q = 0; q < 6; q++) P[q] += __shfl_xor(P[q], o);
+    for (int q = 0; q < 3; q++) bb[q] += __shfl_xor(bb[q], o);
+  }
+  double Pf[9] = {P[0], P[1], P[2], P[1], P[3], P[4], P[2], P[4], P[5]};
+  if (diag_l) {
+    Pf[0] += diag_l[3 * (size_t)l] * inv_radius;
+    Pf[4] += diag_l[3 * (size_t)l + 1] * inv_radius;
+    Pf[8] += diag_l[3 * (size_t)l + 2] * inv_radius;
+  }
+  double Pi[9];
+  const bool ok = inv3(Pf, Pi);
+  if (lane == 0) {
+    if (Pinv_out)
+      for (int q = 0; q < 9; q++) Pinv_out[9 * (size_t)l + q] = ok ? Pi[q] : 0.0;
+    if (bl_out)
+      for (int q = 0; q < 3; q++) bl_out[3 * (size_t)l + q] = ok ? bb[q] : 0.0;
+  }
+  if (!ok) return;
+  // observations in chunks of KM free-camera hits (a landmark seen by more than KM free cameras is
+  // processed chunk x chunk)
+  for (int qa = a; qa < b; qa += KM) {
+    const int na = min(KM, b - qa);
+    for (int qb = a; qb < b; qb += KM) {
+      const int nb = min(KM, b - qb);
+      // stage Y of chunk a and W of chunk b
+      for (int item = lane; item < na * 6; item += 64) {
+        const int q = item / 6, x = item - q * 6, i = qa + q;
+        const double* f = F + 12 * (size_t)i;
+        const double* e = E + 6 * (size_t)i;
+        double w[3];
+        for (int y = 0; y < 3; y++) w[y] = f[x] * e[y] + f[6 + x] * e[3 + y];
+        for (int y = 0; y < 3; y++) Ys[wave][q][3 * x + y] = w[0] * Pi[y] + w[1] * Pi[3 + y] + w[2] * Pi[6 + y];
+        if (x == 0) cs[wave][q] = cam_free[obs_cam[i]];
+      }
+      for (int item = lane; item < nb * 6; item += 64) {
+        const int q = item / 6, x = item - q * 6, i = qb + q;
+        const double* f = F + 12 * (size_t)i;
+        const double* e = E + 6 * (size_t)i;
+        for (int y = 0; y < 3; y++) Ws[wave][q][3 * x + y] = f[x] * e[y] + f[6 + x] * e[3 + y];
+      }
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      for (int item = lane; item < na * nb * 36; item += 64) {
+        const int q1 = item / (nb * 36), rem = item - q1 * (nb * 36);
+        const int q2 = rem / 36, xy = rem - q2 * 36, x = xy / 6, y = xy - x * 6;
+        const int c1 = cs[wave][q1], c2 = cam_free[obs_cam[qb + q2]];
+        if (c1 < 0 || c2 < 0) continue;
+        const double* y1 = &Ys[wave][q1][3 * x];
+        const double* w2 = &Ws[wave][q2][3 * y];
+        unsafeAtomicAdd(&S[(size_t)(6 * c1 + x) * n + 6 * c2 + y], -(y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2]));
+      }
+      if (qb == a) {
+        for (int item = lane; item < na * 6; item += 64) {
+          const int q = item / 6, x = item - q * 6;
+          const int c1 = cs[wave][q];
+          if (c1 < 0) continue;
+          const double* y1 = &Ys[wave][q][3 * x];
+          unsafeAtomicAdd(&rhs[6 * c1 + x], -(y1[0] * bb[0] + y1[1] * bb[1] + y1[2] * bb[2]));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// S += blockdiag(H) + diag(D2); rhs += g_c   (large-system path, S pre-zeroed before the atomics)
+__global__ void ba_add_cam_blocks_kernel(int nfree, const double* __restrict__ H, const double* __restrict__ g_c,
+                                         const double* __restrict__ diag_c, double inv_radius, double* __restrict__ S,
+                                         double* __restrict__ rhs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = 6 * nfree;
+  if (t < nfree * 36) {
+    const int fc = t / 36, x = (t % 36) / 6, y = t % 6;
+    double v = H[t];
+    if (x == y && diag_c) v += diag_c[6 * fc + x] * inv_radius;
+    S[(size_t)(6 * fc + x) * n + 6 * fc + y] += v;
+  }
+  if (t < n) rhs[t] += g_c[t];
+}
+
+// dense Cholesky solve in LDS, one workgroup; n <= 128.  dc = -(S^-1 rhs); flag = 0 on failure.
+__global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double* __restrict__ S, const double* __restrict__ rhs,
+                                                            double* __restrict__ dc, int* __restrict__ ok_flag) {
+  __shared__ double A[128 * 128 + 128];  // static: dynamic LDS above 64 KiB is refused by the runtime
+  double* bvec = A + n * n;
+  __shared__ int ok;
+  for (int i = threadIdx.x; i < n * n; i += 256) A[i] = S[i];
+  for (int i = threadIdx.x; i < n; i += 256) bvec[i] = rhs[i];
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  for (int j = 0; j < n; j++) {
+    if (threadIdx.x == 0) {
+      const double d = A[j * n + j];
+      if (!(d > 0.0) || !isfinite(d)) ok = 0;
+      A[j * n + j] = sqrt(d);
+    }
+    __syncthreads();
+    if (!ok) break;
+    const double djj = A[j * n + j];
+    for (int i = j + 1 + threadIdx.x; i < n; i += 256) A[i * n + j] /= djj;
+    __syncthreads();
+    // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i
+    const int m = n - j - 1;
+    for (int t = threadIdx.x; t < m * m; t += 256) {
+      const int i = j + 1 + t / m, k = j + 1 + t % m;
+      if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < n; i++) {
+        double s = bvec[i];
+        for (int k = 0; k < i; k++) s -= A[i * n + k] * bvec[k];
+        bvec[i] = s / A[i * n + i];
+      }
+      for (int i = n - 1; i >= 0; i--) {
+        double s = bvec[i];
+        for (int k = i + 1; k < n; k++) s -= A[k * n + i] * bvec[k];
+        bvec[i] = s / A[i * n + i];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) dc[i] = -bvec[i];
+  }
+  if (threadIdx.x == 0) *ok_flag = ok;
+}
+
+__global__ void ba_negate_kernel(int n, const double* __restrict__ y, double* __restrict__ dc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dc[i] = -y[i];
+}
+
+// delta_l = -P^-1 (b_l + sum_q W_q^T delta_c)
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims D, const int* __restrict__ lm_start,
+                                                         const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
+                                                         const double* __restrict__ F, const double* __restrict__ E,
+                                                         const double* __restrict__ Pinv, const double* __restrict__ bl,
+                                                         const double* __restrict__ dc, double* __restrict__ dl) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= D.L) return;
+  double t[3] = {bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2]};
+  for (int i = lm_start[l]; i < lm_start[l + 1]; i++) {
+    const int fc = cam_free[obs_cam[i]];
+    if (fc < 0) continue;
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    double fd0 = 0, fd1 = 0;
+    for (int j = 0; j < 6; j++) {
+      fd0 += f[j] * dc[6 * fc + j];
+      fd1 += f[6 + j] * dc[6 * fc + j];
+    }
+    for (int j = 0; j < 3; j++) t[j] += e[j] * fd0 + e[3 + j] * fd1;
+  }
+  const double* Pi = Pinv + 9 * (size_t)l;
+  for (int j = 0; j < 3; j++) dl[3 * (size_t)l + j] = -(Pi[3 * j] * t[0] + Pi[3 * j + 1] * t[1] + Pi[3 * j + 2] * t[2]);
+}
+
+// model cost change partials: -(J d)^T (r + J d / 2)
+__global__ __launch_bounds__(256) void ba_model_kernel(BaDims D, const int* __restrict__ obs_cam,
+                                                       const int* __restrict__ obs_lm, const int* __restrict__ cam_free,
+                                                       const double* __restrict__ r, const double* __restrict__ F,
+                                                       const double* __restrict__ E, const double* __restrict__ dc,
+                                                       const double* __restrict__ dl, double* __restrict__ partials) {
+  __shared__ double sh[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double v = 0;
+  if (i < D.O) {
+    const int fc = cam_free[obs_cam[i]], lm = obs_lm[i];
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    double m0 = 0, m1 = 0;
+    if (fc >= 0)
+      for (int j = 0; j < 6; j++) {
+        m0 += f[j] * dc[6 * fc + j];
+        m1 += f[6 + j] * dc[6 * fc + j];
+      }
+    for (int j = 0; j < 3; j++) {
+      m0 += e[j] * dl[3 * (size_t)lm + j];
+      m1 += e[3 + j] * dl[3 * (size_t)lm + j];
+    }
+    v = -(m0 * (r[2 * (size_t)i] + m0 / 2.0) + m1 * (r[2 * (size_t)i + 1] + m1 / 2.0));
+  }
+  const double t = block_sum_256(v, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// candidate = Plus(x, step .* scale): T * exp(delta) for poses (local_parameterization_se3.hpp:43-50),
+// x + delta for points.  Per-workgroup partials: [0..nb) squared step norm, [nb..2nb) squared x norm
+// (of the CURRENT x, non-constant blocks only).
+__global__ __launch_bounds__(256) void ba_update_kernel(BaDims D, const int* __restrict__ cam_free,
+                                                        const double* __restrict__ poses, const double* __restrict__ points,
+                                                        const double* __restrict__ dc, const double* __restrict__ dl,
+                                                        const double* __restrict__ scale_c, const double* __restrict__ scale_l,
+                                                        double* __restrict__ cand_poses, double* __restrict__ cand_points,
+                                                        double* __restrict__ partials, int nb) {
+  __shared__ double sh[256];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  double step2 = 0, x2 = 0;
+  if (t < D.C) {
+    const int fc = cam_free[t];
+    const double* T = poses + 7 * (size_t)t;
+    double* o = cand_poses + 7 * (size_t)t;
+    if (fc < 0) {
+      for (int j = 0; j < 7; j++) o[j] = T[j];
+    } else {
+      double d[6];
+      for (int j = 0; j < 6; j++) {
+        d[j] = dc[6 * fc + j] * scale_c[6 * fc + j];
+        step2 += d[j] * d[j];
+      }
+      for (int j = 0; j < 7; j++) x2 += T[j] * T[j];
+      // [upstream] Sophus SE3::exp
+      const double wx = d[3], wy = d[4], wz = d[5];
+      const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+      double imag, real;
+      if (th < 1e-10) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+        real = 1.0 - th2 / 8.0 + th4 / 384.0;
+      } else {
+        imag = sin(0.5 * th) / th;
+        real = cos(0.5 * th);
+      }
+      const double dq[4] = {imag * wx, imag * wy, imag * wz, real};
+      double V[9];
+      if (th < 1e-10) {
+        quat_R(dq, V);
+      } else {
+        const double a = (1 - cos(th)) / th2, b = (th - sin(th)) / (th2 * th);
+        const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += O[3 * i + k] * O[3 * k + j];
+            V[3 * i + j] = (i == j ? 1.0 : 0.0) + a * O[3 * i + j] + b * s;
+          }
+      }
+      double Vu[3];
+      for (int i = 0; i < 3; i++) Vu[i] = V[3 * i] * d[0] + V[3 * i + 1] * d[1] + V[3 * i + 2] * d[2];
+      double R[9];
+      quat_R(T, R);
+      for (int i = 0; i < 3; i++) o[4 + i] = T[4 + i] + R[3 * i] * Vu[0] + R[3 * i + 1] * Vu[1] + R[3 * i + 2] * Vu[2];
+      const double qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+      double nq[4];
+      nq[0] = qw * dq[0] + qx * dq[3] + qy * dq[2] - qz * dq[1];
+      nq[1] = qw * dq[1] - qx * dq[2] + qy * dq[3] + qz * dq[0];
+      nq[2] = qw * dq[2] + qx * dq[1] - qy * dq[0] + qz * dq[3];
+      nq[3] = qw * dq[3] - qx * dq[0] - qy * dq[1] - qz * dq[2];
+      const double nn = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+      for (int i = 0; i < 4; i++) o[i] = nq[i] / nn;
+    }
+  }
+  if (t < D.L) {
+    for (int j = 0; j < 3; j++) {
+      const double dd = dl[3 * (size_t)t + j] * scale_l[3 * (size_t)t + j];
+      step2 += dd * dd;
+      const double xv = points[3 * (size_t)t + j];
+      x2 += xv * xv;
+      cand_points[3 * (size_t)t + j] = xv + dd;
+    }
+  }
+  const double a = block_sum_256(step2, sh);
+  __syncthreads();
+  const double b = block_sum_256(x2, sh);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = a;
+    partials[nb + blockIdx.x] = b;
+  }
+}
+
+__global__ void ba_all_finite_kernel(int n, const double* __restrict__ v, int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !isfinite(v[i])) *flag = 0;
+}
+
+// raw per-observation residual / Jacobian blocks in the caller's observation order (parity hook)
+__global__ void ba_raw_blocks_kernel(BaDims D, const double* __restrict__ poses, const double* __restrict__ points,
+                                     const double* __restrict__ intr, const int* __restrict__ cam_intr,
+                                     const int* __restrict__ obs_cam, const int* __restrict__ obs_lm,
+                                     const double* __restrict__ obs_uv, double* __restrict__ r, double* __restrict__ F,
+                                     double* __restrict__ E) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.O) return;
+  const int cam = obs_cam[i], lm = obs_lm[i], k = cam_intr[cam];
+  double rr[2], FF[12], EE[6];
+  residual_blocks(k ? D.model1 : D.model0, intr + 8 * k, poses + 7 * cam, points + 3 * lm, obs_uv + 2 * i, rr, FF, EE, true);
+  r[2 * (size_t)i] = rr[0];
+  r[2 * (size_t)i + 1] = rr[1];
+  for (int j = 0; j < 12; j++) F[12 * (size_t)i + j] = FF[j];
+  for (int j = 0; j < 6; j++) E[6 * (size_t)i + j] = EE[j];
+}
+
+// ------------------------------------------------------------------------------- host-side state
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  template <class T>
+  T* as() {
+    return (T*)p;
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 8); }
+};
+
+struct BaState {
+  BaDims D;
+  int G = 1, lm_per_wg = 1, nb_obs = 1, nb_upd = 1;
+  bool small = true;
+  std::vector<int> perm;  // sorted position -> caller observation index
+  DevBuf poses, cand_poses, points, cand_points, intr, cam_intr, cam_free, free_cams, obs_cam, obs_lm, obs_uv, lm_start,
+      cam_start, cam_obs, r, F, E, scale_c, scale_l, n2l, grad_l, H, g_c, diag_c, diag_l, gabs, S, rhs, S_part, rhs_part,
+      Pinv, bl, dc, dl, partials, scalars, flag;
+};
+
+#define BA_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return vsl_fail(ctx, VSL_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int ba_validate(vsl_ctx* ctx, const vsl_ba_problem* p) {
+  if (!ctx) return VSL_ERR_INVALID;
+  if (!p || p->n_cams <= 0 || p->n_lms <= 0 || p->n_obs <= 0 || !p->poses || !p->cam_fixed || !p->cam_intr || !p->intr ||
+      !p->points || !p->obs_cam || !p->obs_lm || !p->obs_uv)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "bundle adjustment: null pointer or empty problem");
+  for (int k = 0; k < 2; k++)
+    if (p->cam_model[k] < 0 || p->cam_model[k] > 3) return vsl_fail(ctx, VSL_ERR_INVALID, "unknown camera model %d", p->cam_model[k]);
+  for (int i = 0; i < p->n_obs; i++)
+    if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->n_cams || p->obs_lm[i] < 0 || p->obs_lm[i] >= p->n_lms)
+      return vsl_fail(ctx, VSL_ERR_INVALID, "observation %d references camera %d / landmark %d out of range", i, p->obs_cam[i], p->obs_lm[i]);
+  for (int c = 0; c < p->n_cams; c++)
+    if (p->cam_intr[c] < 0 || p->cam_intr[c] > 1) return vsl_fail(ctx, VSL_ERR_INVALID, "cam_intr[%d] = %d not in {0,1}", c, p->cam_intr[c]);
+  return VSL_OK;
+}
+
+template <class T>
+int upload(vsl_ctx* ctx, DevBuf& b, const T* src, size_t n) {
+  BA_HIP(b.alloc(sizeof(T) * n));
+  if (n) BA_HIP(hipMemcpyAsync(b.p, src, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+  return VSL_OK;
+}
+
+int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaState& st) {
+  BaDims& D = st.D;
+  D.C = p->n_cams;
+  D.L = p->n_lms;
+  D.O = p->n_obs;
+  D.model0 = p->cam_model[0];
+  D.model1 = p->cam_model[1];
+  D.use_huber = o ? o->use_huber : 1;
+  D.huber = o ? o->huber_parameter : 1.0;
+  std::vector<int> cam_free(D.C, -1), free_cams;
+  for (int c = 0; c < D.C; c++)
+    if (!p->cam_fixed[c]) {
+      cam_free[c] = (int)free_cams.size();
+      free_cams.push_back(c);
+    }
+  D.nfree = (int)free_cams.size();
+  D.n = 6 * D.nfree;
+  // sort observations by landmark (stable: keeps the caller's order inside a landmark)
+  std::vector<int> lm_start(D.L + 1, 0);
+  for (int i = 0; i < D.O; i++) lm_start[p->obs_lm[i] + 1]++;
+  for (int l = 0; l < D.L; l++) lm_start[l + 1] += lm_start[l];
+  st.perm.resize(D.O);
+  {
+    std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
+    for (int i = 0; i < D.O; i++) st.perm[fill[p->obs_lm[i]]++] = i;
+  }
+  std::vector<int> s_cam(D.O), s_lm(D.O);
+  std::vector<double> s_uv(2 * (size_t)D.O);
+  int kmax_free = 0;
+  for (int q = 0; q < D.O; q++) {
+    const int i = st.perm[q];
+    s_cam[q] = p->obs_cam[i];
+    s_lm[q] = p->obs_lm[i];
+    s_uv[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
+    s_uv[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
+  }
+  for (int l = 0; l < D.L; l++) {
+    int k = 0;
+    for (int q = lm_start[l]; q < lm_start[l + 1]; q++) k += cam_free[s_cam[q]] >= 0;
+    kmax_free = std::max(kmax_free, k);
+  }
+  // camera CSR over the sorted observation positions
+  std::vector<int> cam_start(D.C + 1, 0), cam_obs(D.O);
+  for (int q = 0; q < D.O; q++) cam_start[s_cam[q] + 1]++;
+  for (int c = 0; c < D.C; c++) cam_start[c + 1] += cam_start[c];
+  {
+    std::vector<int> fill(cam_start.begin(), cam_start.end() - 1);
+    for (int q = 0; q < D.O; q++) cam_obs[fill[s_cam[q]]++] = q;
+  }
+  st.small = D.n <= 128 && D.nfree <= SCH_CMAX && kmax_free <= SCH_KMAX;
+  st.nb_obs = (D.O + 255) / 256;
+  st.nb_upd = (std::max(D.C, D.L) + 255) / 256;
+  st.G = std::min(256, (D.L + SCH_LB - 1) / SCH_LB);
+  st.lm_per_wg = ((D.L + st.G - 1) / st.G + SCH_LB - 1) / SCH_LB * SCH_LB;
+  st.G = (D.L + st.lm_per_wg - 1) / st.lm_per_wg;
+
+  int rc;
+  if ((rc = upload(ctx, st.poses, p->poses, 7 * (size_t)D.C))) return rc;
+  if ((rc = upload(ctx, st.points, p->points, 3 * (size_t)D.L))) return rc;
+  if ((rc = upload(ctx, st.intr, p->intr, 16))) return rc;
+  if ((rc = upload(ctx, st.cam_intr, p->cam_intr, (size_t)D.C))) return rc;
+  if ((rc = upload(ctx, st.cam_free, cam_free.data(), (size_t)D.C))) return rc;
+  if ((rc = upload(ctx, st.free_cams, free_cams.data(), free_cams.size()))) return rc;
+  if ((rc = upload(ctx, st.obs_cam, s_cam.data(), (size_t)D.O))) return rc;
+  if ((rc = upload(ctx, st.obs_lm, s_lm.data(), (size_t)D.O))) return rc;
+  if ((rc = upload(ctx, st.obs_uv, s_uv.data(), 2 * (size_t)D.O))) return rc;
+  if ((rc = upload(ctx, st.lm_start, lm_start.data(), lm_start.size()))) return rc;
+  if ((rc = upload(ctx, st.cam_start, cam_start.data(), cam_start.size()))) return rc;
+  if ((rc = upload(ctx, st.cam_obs, cam_obs.data(), cam_obs.size()))) return rc;
+  const size_t n = (size_t)D.n, L = (size_t)D.L, O = (size_t)D.O;
+  BA_HIP(st.cand_poses.alloc(8 * 7 * (size_t)D.C));
+  BA_HIP(st.cand_points.alloc(8 * 3 * L));
+  BA_HIP(st.r.alloc(8 * 2 * O));
+  BA_HIP(st.F.alloc(8 * 12 * O));
+  BA_HIP(st.E.alloc(8 * 6 * O));
+  BA_HIP(st.scale_c.alloc(8 * n));
+  BA_HIP(st.scale_l.alloc(8 * 3 * L));
+  BA_HIP(st.n2l.alloc(8 * 3 * L));
+  BA_HIP(st.grad_l.alloc(8 * 3 * L));
+  BA_HIP(st.H.alloc(8 * 36 * (size_t)D.nfree));
+  BA_HIP(st.g_c.alloc(8 * n));
+  BA_HIP(st.diag_c.alloc(8 * n));
+  BA_HIP(st.diag_l.alloc(8 * 3 * L));
+  BA_HIP(st.gabs.alloc(8 * (n + 3 * L)));
+  BA_HIP(st.S.alloc(8 * n * n));
+  BA_HIP(st.rhs.alloc(8 * n));
+  if (st.small) {
+    BA_HIP(st.S_part.alloc(8 * n * n * st.G));
+    BA_HIP(st.rhs_part.alloc(8 * n * st.G));
+  }
+  BA_HIP(st.Pinv.alloc(8 * 9 * L));
+  BA_HIP(st.bl.alloc(8 * 3 * L));
+  BA_HIP(st.dc.alloc(8 * n));
+  BA_HIP(st.dl.alloc(8 * 3 * L));
+  BA_HIP(st.partials.alloc(8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)));
+  BA_HIP(st.scalars.alloc(8 * 16));
+  BA_HIP(st.flag.alloc(sizeof(int) * 4));
+  BA_HIP(hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors that die here
+  return VSL_OK;
+}
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// linearize at (poses, points): r, F, E (scaled when `scaled`), cost -> scalars[0]; per-landmark and
+// per-camera column statistics.
+int ba_linearize(vsl_ctx* ctx, BaState& st, bool scaled) {
+  const BaDims& D = st.D;
+  {
+    VslStage s(ctx, VSL_STAGE_BA_LIN);
+    hipLaunchKernelGGL(ba_linearize_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.poses.as<double>(),
+                       st.points.as<double>(), st.intr.as<double>(), st.cam_intr.as<int>(), st.cam_free.as<int>(),
+                       st.obs_cam.as<int>(), st.obs_lm.as<int>(), st.obs_uv.as<double>(),
+                       scaled ? st.scale_c.as<double>() : nullptr, scaled ? st.scale_l.as<double>() : nullptr,
+                       st.r.as<double>(), st.F.as<double>(), st.E.as<double>(), st.partials.as<double>(), 1);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs,
+                       st.scalars.as<double>(), 0, 0);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  return VSL_OK;
+}
+
+int ba_columns(vsl_ctx* ctx, BaState& st) {
+  const BaDims& D = st.D;
+  VslStage s(ctx, VSL_STAGE_BA_LIN);
+  hipLaunchKernelGGL(ba_lm_cols_kernel, dim3((D.L + 255) / 256), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
+                     st.r.as<double>(), st.E.as<double>(), st.n2l.as<double>(), st.grad_l.as<double>());
+  if (D.nfree > 0)
+    hipLaunchKernelGGL(ba_cam_block_kernel, dim3(D.nfree), dim3(256), 0, ctx->stream, st.free_cams.as<int>(),
+                       st.cam_start.as<int>(), st.cam_obs.as<int>(), st.r.as<double>(), st.F.as<double>(),
+                       st.H.as<double>(), st.g_c.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// Schur complement of the landmark blocks over landmarks [l0, l0+lc); damping when diag != null.
+int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc, bool keep_backsub) {
+  const BaDims& D = st.D;
+  const int n = D.n;
+  if (n == 0) return VSL_OK;
+  VslStage s(ctx, VSL_STAGE_BA_SCHUR);
+  const double inv_radius = damp ? 1.0 / radius : 0.0;
+  const double* dgl = damp ? st.diag_l.as<double>() : nullptr;
+  const double* dgc = damp ? st.diag_c.as<double>() : nullptr;
+  double* Pinv = keep_backsub ? st.Pinv.as<double>() : nullptr;
+  double* bl = keep_backsub ? st.bl.as<double>() : nullptr;
+  if (st.small) {
+    const int lpw = ((lc + st.G - 1) / st.G + SCH_LB - 1) / SCH_LB * SCH_LB;
+    const int G = lpw > 0 ? (lc + lpw - 1) / lpw : 0;
+    if (G > 0)
+      hipLaunchKernelGGL(ba_schur_small_kernel, dim3(G), dim3(SCH_THREADS), 0, ctx->stream, D, st.lm_start.as<int>(),
+                         st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
+                         st.E.as<double>(), dgl, inv_radius, l0, lc, lpw, st.S_part.as<double>(),
+                         st.rhs_part.as<double>(), Pinv, bl);
+    hipLaunchKernelGGL(ba_schur_finish_kernel, dim3((n * n + 255) / 256), dim3(256), 0, ctx->stream, n, G,
+                       st.S_part.as<double>(), st.rhs_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), dgc,
+                       inv_radius, st.S.as<double>(), st.rhs.as<double>());
+  } else {
+    VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * (size_t)n * n, ctx->stream));
+    VSL_HIP(ctx, hipMemsetAsync(st.rhs.p, 0, sizeof(double) * n, ctx->stream));
+    if (lc > 0)
+      hipLaunchKernelGGL(ba_schur_atomic_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
+                         st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
+                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S.as<double>(), st.rhs.as<double>(), Pinv, bl);
+    hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
+                       st.H.as<double>(), st.g_c.as<double>(), dgc, inv_radius, st.S.as<double>(), st.rhs.as<double>());
+  }
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// dc = -(S^-1 rhs).  ok = false if S is not positive definite.
+int ba_solve(vsl_ctx* ctx, BaState& st, bool& ok) {
+  const int n = st.D.n;
+  ok = true;
+  if (n == 0) return VSL_OK;
+  VslStage s(ctx, VSL_STAGE_BA_SOLVE);
+  int flag = 1;
+  if (n <= 128) {
+    hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, ctx->stream, n,
+                       st.S.as<double>(), st.rhs.as<double>(), st.dc.as<double>(), st.flag.as<int>());
+    VSL_CHECK_LAUNCH(ctx);
+    VSL_HIP(ctx, hipMemcpyAsync(&flag, st.flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    // blocked right-looking Cholesky + substitutions (chol.hip); rhs <- S^-1 rhs
+    int rc = vsl_chol_solve_dev(ctx, st.S.as<double>(), st.rhs.as<double>(), n, st.flag.as<int>());
+    if (rc) return rc;
+    hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
+    VSL_CHECK_LAUNCH(ctx);
+    VSL_HIP(ctx, hipMemcpyAsync(&flag, st.flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ok = flag != 0;
+  return VSL_OK;
+}
+
+int read_scalars(vsl_ctx* ctx, BaState& st, double* out, int n) {
+  VSL_HIP(ctx, hipMemcpyAsync(out, st.scalars.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VSL_OK;
+}
+
+}  // namespace
+
+extern "C" int vsl_ba_residuals_jacobians(vsl_ctx* ctx, const vsl_ba_problem* prob, double* r, double* J_pose,
+                                          double* J_point) {
+  int rc = ba_validate(ctx, prob);
+  if (rc) return rc;
+  if (!r || !J_pose || !J_point) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_residuals_jacobians: null output");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  BaState st;
+  if ((rc = ba_setup(ctx, prob, nullptr, st))) return rc;
+  const BaDims& D = st.D;
+  hipLaunchKernelGGL(ba_raw_blocks_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.poses.as<double>(),
+                     st.points.as<double>(), st.intr.as<double>(), st.cam_intr.as<int>(), st.obs_cam.as<int>(),
+                     st.obs_lm.as<int>(), st.obs_uv.as<double>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
+  std::vector<double> hr(2 * (size_t)D.O), hF(12 * (size_t)D.O), hE(6 * (size_t)D.O);
+  VSL_HIP(ctx, hipMemcpyAsync(hr.data(), st.r.p, 8 * hr.size(), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(hF.data(), st.F.p, 8 * hF.size(), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(hE.data(), st.E.p, 8 * hE.size(), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int q = 0; q < D.O; q++) {  // back to the caller's observation order
+    const size_t i = (size_t)st.perm[q];
+    memcpy(r + 2 * i, &hr[2 * (size_t)q], 16);
+    memcpy(J_pose + 12 * i, &hF[12 * (size_t)q], 96);
+    memcpy(J_point + 6 * i, &hE[6 * (size_t)q], 48);
+  }
+  return VSL_OK;
+}
+
+extern "C" int vsl_ba_linearize(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, int lm_first,
+                                int lm_count, double* S, double* g, double* cost, int* n_free) {
+  int rc = ba_validate(ctx, prob);
+  if (rc) return rc;
+  if (!opt || !S || !g || !cost || !n_free) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_linearize: null argument");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  BaState st;
+  if ((rc = ba_setup(ctx, prob, opt, st))) return rc;
+  const BaDims& D = st.D;
+  int l0 = 0, lc = D.L;
+  if (lm_count >= 0) {
+    if (lm_first < 0 || lm_first > D.L) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_linearize: lm_first out of range");
+    l0 = lm_first;
+    lc = std::min(lm_count, D.L - lm_first);
+  }
+  if ((rc = ba_linearize(ctx, st, false))) return rc;
+  if (lm_count >= 0) {
+    // restrict to the observations of the landmark range: zero the others' blocks so that the camera
+    // sums and the cost only see the range (observations are sorted by landmark => one contiguous run)
+    std::vector<int> lm_start(D.L + 1);
+    VSL_HIP(ctx, hipMemcpyAsync(lm_start.data(), st.lm_start.p, sizeof(int) * lm_start.size(), hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t o0 = (size_t)lm_start[l0], o1 = (size_t)lm_start[l0 + lc];
+    if (o0 > 0) {
+      VSL_HIP(ctx, hipMemsetAsync(st.r.p, 0, 16 * o0, ctx->stream));
+      VSL_HIP(ctx, hipMemsetAsync(st.F.p, 0, 96 * o0, ctx->stream));
+      VSL_HIP(ctx, hipMemsetAsync(st.E.p, 0, 48 * o0, ctx->stream));
+    }
+    if (o1 < (size_t)D.O) {
+      VSL_HIP(ctx, hipMemsetAsync(st.r.as<double>() + 2 * o1, 0, 16 * ((size_t)D.O - o1), ctx->stream));
+      VSL_HIP(ctx, hipMemsetAsync(st.F.as<double>() + 12 * o1, 0, 96 * ((size_t)D.O - o1), ctx->stream));
+      VSL_HIP(ctx, hipMemsetAsync(st.E.as<double>() + 6 * o1, 0, 48 * ((size_t)D.O - o1), ctx->stream));
+    }
+    const int oc = (int)(o1 - o0);
+    const int nb = (oc + 255) / 256;
+    if (nb > 0)
+      hipLaunchKernelGGL(ba_cost_kernel, dim3(nb), dim3(256), 0, ctx->stream, D, st.poses.as<double>(), st.points.as<double>(),
+                         st.intr.as<double>(), st.cam_intr.as<int>(), st.obs_cam.as<int>(), st.obs_lm.as<int>(),
+                         st.obs_uv.as<double>(), (int)o0, oc, st.partials.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), nb, st.scalars.as<double>(), 0, 0);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  if ((rc = ba_columns(ctx, st))) return rc;
+  if ((rc = ba_schur(ctx, st, false, 1.0, l0, lc, false))) return rc;
+  double sc[1];
+  if ((rc = read_scalars(ctx, st, sc, 1))) return rc;
+  *cost = sc[0];
+  *n_free = D.nfree;
+  if (D.n > 0) {
+    VSL_HIP(ctx, hipMemcpy(S, st.S.p, sizeof(double) * (size_t)D.n * D.n, hipMemcpyDeviceToHost));
+    VSL_HIP(ctx, hipMemcpy(g, st.rhs.p, sizeof(double) * D.n, hipMemcpyDeviceToHost));
+  }
+  return VSL_OK;
+}
+
+// [upstream] ceres::Solve, TRUST_REGION / LEVENBERG_MARQUARDT / Schur, defaults (see oracle/orc_ba.cpp
+// for the option values this loop restates).
+extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
+                                 vsl_ba_summary* summary) {
+  int rc = ba_validate(ctx, prob);
+  if (rc) return rc;
+  if (!opt) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_bundle_adjust: options are null");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  const double t_start = now_ms();
+  BaState st;
+  if ((rc = ba_setup(ctx, prob, opt, st))) return rc;
+  const BaDims& D = st.D;
+  const int nc = D.n, nl = 3 * D.L;
+  vsl_ba_summary sum;
+  memset(&sum, 0, sizeof(sum));
+  const bool prof_was = ctx->profiling;
+  vsl_ctx_set_profiling(ctx, 1);
+  double base_ms[3];
+  for (int k = 0; k < 3; k++) base_ms[k] = ctx->stage_ms[VSL_STAGE_BA_LIN + k];
+
+  double sc[8];
+  // iteration 0: evaluate, Jacobi scaling from the unscaled Jacobian, then scale it
+  if ((rc = ba_linearize(ctx, st, false))) return rc;
+  if ((rc = ba_columns(ctx, st))) return rc;
+  const int nmax = std::max(nc, nl);
+  hipLaunchKernelGGL(ba_make_scale_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, D.L,
+                     st.H.as<double>(), st.n2l.as<double>(), st.scale_c.as<double>(), st.scale_l.as<double>());
+  hipLaunchKernelGGL(ba_apply_scale_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D.O, st.cam_free.as<int>(),
+                     st.obs_cam.as<int>(), st.obs_lm.as<int>(), st.scale_c.as<double>(), st.scale_l.as<double>(),
+                     st.F.as<double>(), st.E.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
+  if ((rc = ba_columns(ctx, st))) return rc;
+
+  auto diag_and_gmax = [&]() -> int {
+    hipLaunchKernelGGL(ba_diag_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, D.L, st.H.as<double>(),
+                       st.n2l.as<double>(), st.g_c.as<double>(), st.grad_l.as<double>(), st.scale_c.as<double>(),
+                       st.scale_l.as<double>(), st.diag_c.as<double>(), st.diag_l.as<double>(), st.gabs.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), nc + nl,
+                       st.scalars.as<double>(), 1, 1);
+    VSL_CHECK_LAUNCH(ctx);
+    return VSL_OK;
+  };
+  if ((rc = diag_and_gmax())) return rc;
+  if ((rc = read_scalars(ctx, st, sc, 2))) return rc;
+  double cost = sc[0], gmax = sc[1];
+  sum.initial_cost = cost;
+
+  double radius = 1e4, decrease_factor = 2.0;
+  int iteration = 0, invalid = 0;
+  sum.termination = 0;
+  if (opt->verbosity >= 2)
+    fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, cost);
+  while (true) {
+    if (iteration >= opt->max_num_iterations) { sum.termination = 0; break; }
+    if (gmax <= 1e-10) { sum.termination = 2; break; }
+    if (radius <= 1e-32) { sum.termination = 4; break; }
+    iteration++;
+    if ((rc = ba_schur(ctx, st, true, radius, 0, D.L, true))) return rc;
+    bool ok = true;
+    if ((rc = ba_solve(ctx, st, ok))) return rc;
+    double model_change = 0, step_norm = 0, x_norm = 0;
+    if (ok) {
+      VslStage s(ctx, VSL_STAGE_BA_SOLVE);
+      int one = 1;
+      VSL_HIP(ctx, hipMemcpyAsync(st.flag.p, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3((D.L + 255) / 256), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
+                         st.obs_cam.as<int>(), st.cam_free.as<int>(), st.F.as<double>(), st.E.as<double>(),
+                         st.Pinv.as<double>(), st.bl.as<double>(), st.dc.as<double>(), st.dl.as<double>());
+      if (nc > 0) hipLaunchKernelGGL(ba_all_finite_kernel, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, nc, st.dc.as<double>(), st.flag.as<int>());
+      hipLaunchKernelGGL(ba_all_finite_kernel, dim3((nl + 255) / 256), dim3(256), 0, ctx->stream, nl, st.dl.as<double>(), st.flag.as<int>());
+      hipLaunchKernelGGL(ba_model_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.obs_cam.as<int>(),
+                         st.obs_lm.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(),
+                         st.dc.as<double>(), st.dl.as<double>(), st.partials.as<double>());
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs,
+                         st.scalars.as<double>(), 2, 0);
+      hipLaunchKernelGGL(ba_update_kernel, dim3(st.nb_upd), dim3(256), 0, ctx->stream, D, st.cam_free.as<int>(),
+                         st.poses.as<double>(), st.points.as<double>(), st.dc.as<double>(), st.dl.as<double>(),
+                         st.scale_c.as<double>(), st.scale_l.as<double>(), st.cand_poses.as<double>(),
+                         st.cand_points.as<double>(), st.partials.as<double>(), st.nb_upd);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_upd,
+                         st.scalars.as<double>(), 3, 0);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>() + st.nb_upd, st.nb_upd,
+                         st.scalars.as<double>(), 4, 0);
+      VSL_CHECK_LAUNCH(ctx);
+    }
+    if (ok) {
+      VslStage s(ctx, VSL_STAGE_BA_LIN);
+      hipLaunchKernelGGL(ba_cost_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.cand_poses.as<double>(),
+                         st.cand_points.as<double>(), st.intr.as<double>(), st.cam_intr.as<int>(), st.obs_cam.as<int>(),
+                         st.obs_lm.as<int>(), st.obs_uv.as<double>(), 0, D.O, st.partials.as<double>());
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs,
+                         st.scalars.as<double>(), 5, 0);
+      VSL_CHECK_LAUNCH(ctx);
+    }
+    double cand_cost = 0;
+    if (ok) {
+      int flag = 1;
+      VSL_HIP(ctx, hipMemcpyAsync(&flag, st.flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      if ((rc = read_scalars(ctx, st, sc, 6))) return rc;
+      model_change = sc[2];
+      step_norm = sqrt(sc[3]);
+      x_norm = sqrt(sc[4]);
+      cand_cost = sc[5];
+      ok = flag != 0 && model_change > 0.0;
+    }
+    if (!ok) {
+      if (++invalid >= 5) { sum.termination = 4; break; }
+      radius *= 0.5;
+      if (opt->verbosity >= 2) fprintf(stderr, "%4d  invalid step, radius %.3e\n", iteration, radius);
+      continue;  // the LM diagonal is reused (the Jacobian is unchanged)
+    }
+    invalid = 0;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 3; break; }
+    const double cost_change = cost - cand_cost;
+    if (fabs(cost_change) <= 1e-6 * cost) { sum.termination = 1; break; }
+    const double rel = cost_change / model_change;
+    if (opt->verbosity >= 2)
+      fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", iteration, cand_cost, cost_change, gmax, step_norm, rel, radius);
+    if (rel > 1e-3) {
+      std::swap(st.poses.p, st.cand_poses.p);
+      std::swap(st.points.p, st.cand_points.p);
+      if ((rc = ba_linearize(ctx, st, true))) return rc;
+      if ((rc = ba_columns(ctx, st))) return rc;
+      if ((rc = diag_and_gmax())) return rc;
+      if ((rc = read_scalars(ctx, st, sc, 2))) return rc;
+      cost = sc[0];
+      gmax = sc[1];
+      sum.successful_steps++;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+      radius = std::min(1e16, radius);
+      decrease_factor = 2.0;
+    } else {
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+    }
+  }
+  sum.iterations = iteration;
+  sum.final_cost = cost;
+  VSL_HIP(ctx, hipMemcpyAsync(prob->poses, st.poses.p, sizeof(double) * 7 * (size_t)D.C, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(prob->points, st.points.p, sizeof(double) * 3 * (size_t)D.L, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double ms;
+  int64_t cnt;
+  vsl_ctx_stage_ms(ctx, VSL_STAGE_BA_LIN, &ms, &cnt);
+  sum.linearize_ms = ctx->stage_ms[VSL_STAGE_BA_LIN] - base_ms[0];
+  sum.schur_ms = ctx->stage_ms[VSL_STAGE_BA_SCHUR] - base_ms[1];
+  sum.solve_ms = ctx->stage_ms[VSL_STAGE_BA_SOLVE] - base_ms[2];
+  vsl_ctx_set_profiling(ctx, prof_was ? 1 : 0);
+  sum.total_ms = now_ms() - t_start;
+  if (opt->verbosity >= 1)
+    fprintf(stderr, "vsl BA: iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n", sum.iterations,
+            sum.initial_cost, sum.final_cost, sum.termination, sum.total_ms);
+  if (summary) *summary = sum;
+  return VSL_OK;
+}

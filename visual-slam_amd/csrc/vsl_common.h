@@ -114,6 +114,9 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
 int vsl_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
 int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_pairs);
 
+// dense fp64 Cholesky solve on the device (chol.hip): S x = b in place, *ok_dev = 0 if not SPD
+int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev);
+
 // scratch store of the host-buffer API
 int vsl_ctx_scratch_frames(vsl_ctx* ctx, int w, int h, int feat, vsl_frames** out);
 

@@ -118,7 +118,8 @@ def ds_project(intr, p):
 
 
 def ba_problem(seed, n_kf=7, n_lms=20000, pix_noise=0.5, outlier_frac=0.05, pose_noise=(0.02, 0.0087),
-               point_noise=0.05, n_fixed_kf=1, max_range=15.0, w=W, h=H, loop_radius=None):
+               point_noise=0.05, n_fixed_kf=1, max_range=15.0, w=W, h=H, loop_radius=None,
+               integer_pixels=True):
     """Stereo keyframes on a smooth trajectory looking at a random point cloud.
 
     Returns a dict of numpy arrays in the flattened layout of include/vslam_hip.h (cameras 2*k and
@@ -181,7 +182,9 @@ def ba_problem(seed, n_kf=7, n_lms=20000, pix_noise=0.5, outlier_frac=0.05, pose
     noise = rng.normal(0, pix_noise, obs_uv.shape)
     out = rng.random(len(obs_uv)) < outlier_frac
     noise[out] = rng.normal(0, 20.0, (out.sum(), 2))
-    obs_uv = np.rint(obs_uv + noise)
+    obs_uv = obs_uv + noise
+    if integer_pixels:
+        obs_uv = np.rint(obs_uv)
     gt_poses, gt_pts = poses.copy(), pts.copy()
     cam_fixed = np.zeros(n_cams, np.uint8)
     cam_fixed[:2 * n_fixed_kf] = 1
