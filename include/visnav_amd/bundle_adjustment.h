@@ -1,0 +1,136 @@
+// visnav_amd/bundle_adjustment.h -- drop-in for visnav::bundle_adjustment
+// (include/visnav/map_utils.h:319-421) and visnav::global_bundle_adjustment
+// (include/visnav/loop_closure_utils.h:651-748).  The wrappers flatten the reference's node-based
+// containers (Cameras = std::map, Landmarks = unordered_map, Corners = concurrent map) into the SoA
+// arrays of vsl_ba_problem, call the MI355X solver, and write poses / landmark positions back in
+// place -- the contract of the Ceres version (parameter blocks are the containers' own storage).
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "keypoints.h"  // context holder + types
+
+namespace visnav {
+
+// include/visnav/map_utils.h:319-334
+struct BundleAdjustmentOptions {
+  int verbosity_level = 1;
+  bool optimize_intrinsics = false;
+  bool use_huber = true;
+  double huber_parameter = 1.0;
+  int max_num_iterations = 20;
+};
+// include/visnav/loop_closure_utils.h:651-663
+struct GlobalBundleAdjustmentOptions {
+  int verbosity_level = 1;
+  bool use_huber = true;
+  double huber_parameter = 1.0;
+  int max_num_iterations = 20;
+};
+
+namespace amd {
+inline int camera_model_id(const std::string& name) {
+  if (name == "ds") return VSL_CAM_DS;
+  if (name == "pinhole") return VSL_CAM_PINHOLE;
+  if (name == "eucm") return VSL_CAM_EUCM;
+  if (name == "kb4") return VSL_CAM_KB4;
+  std::fprintf(stderr, "Camera model %s is not implemented.\n", name.c_str());  // camera_models.h:493-495
+  std::abort();
+}
+
+template <bool kAllObs>
+inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_parameter, int max_num_iterations,
+                   int verbosity_level, const std::set<FrameCamId>& fixed_cameras, Calibration& calib_cam,
+                   Cameras& cameras, Landmarks& landmarks) {
+  if (cameras.empty() || landmarks.empty()) return;
+  std::vector<double> poses, points, uv, intr(16, 0.0);
+  std::vector<uint8_t> fixed;
+  std::vector<int32_t> cam_intr, obs_cam, obs_lm;
+  std::vector<Camera*> cam_ptr;
+  std::vector<Landmark*> lm_ptr;
+  std::map<FrameCamId, int> cam_index;
+  for (auto& kv : cameras) {  // std::map order == the order Ceres receives the blocks (map_utils.h:359)
+    cam_index[kv.first] = (int)cam_ptr.size();
+    cam_ptr.push_back(&kv.second);
+    const double* d = kv.second.T_w_c.data();
+    poses.insert(poses.end(), d, d + 7);
+    fixed.push_back(fixed_cameras.count(kv.first) ? 1 : 0);
+    cam_intr.push_back((int32_t)kv.first.cam_id);
+  }
+  for (auto& kv : landmarks) {
+    Landmark& lm = kv.second;
+    const auto& track = kAllObs ? lm.all_obs : lm.obs;  // loop_closure_utils.h:706 vs map_utils.h:373
+    const int li = (int)lm_ptr.size();
+    lm_ptr.push_back(&lm);
+    points.insert(points.end(), lm.p.data(), lm.p.data() + 3);
+    for (const auto& ob : track) {
+      const auto& p_2d = feature_corners.at(ob.first).corners[ob.second];  // .at(): std::out_of_range like the reference
+      obs_cam.push_back(cam_index.at(ob.first));
+      obs_lm.push_back(li);
+      uv.push_back(p_2d[0]);
+      uv.push_back(p_2d[1]);
+    }
+  }
+  if (obs_cam.empty()) return;
+  vsl_ba_problem prob;
+  prob.n_cams = (int32_t)cam_ptr.size();
+  prob.n_lms = (int32_t)lm_ptr.size();
+  prob.n_obs = (int32_t)obs_cam.size();
+  for (int k = 0; k < 2; k++) {
+    prob.cam_model[k] = camera_model_id(calib_cam.intrinsics[k]->name());
+    const double* p = calib_cam.intrinsics[k]->data();
+    for (int j = 0; j < 8; j++) intr[8 * k + j] = p[j];
+  }
+  prob.poses = poses.data();
+  prob.cam_fixed = fixed.data();
+  prob.cam_intr = cam_intr.data();
+  prob.intr = intr.data();
+  prob.points = points.data();
+  prob.obs_cam = obs_cam.data();
+  prob.obs_lm = obs_lm.data();
+  prob.obs_uv = uv.data();
+  vsl_ba_options opt;
+  opt.use_huber = use_huber ? 1 : 0;
+  opt.huber_parameter = huber_parameter;
+  opt.max_num_iterations = max_num_iterations;
+  opt.verbosity = 0;
+  vsl_ba_summary sum;
+  check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
+  for (size_t c = 0; c < cam_ptr.size(); c++) {
+    double* d = cam_ptr[c]->T_w_c.data();
+    for (int j = 0; j < 7; j++) d[j] = poses[7 * c + j];
+  }
+  for (size_t l = 0; l < lm_ptr.size(); l++)
+    for (int j = 0; j < 3; j++) lm_ptr[l]->p.data()[j] = points[3 * l + j];
+  if (verbosity_level >= 1)  // stands in for summary.BriefReport() (map_utils.h:414-415)
+    std::printf("vslam_hip BA: iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n",
+                sum.iterations, sum.initial_cost, sum.final_cost, sum.termination, sum.total_ms);
+}
+}  // namespace amd
+
+// include/visnav/map_utils.h:337-421.  options.optimize_intrinsics == true is not supported (the
+// reference never sets it: src/slam.cpp uses the default false) and aborts loudly.
+inline void bundle_adjustment(const Corners& feature_corners, const BundleAdjustmentOptions& options,
+                              const std::set<FrameCamId>& fixed_cameras, Calibration& calib_cam, Cameras& cameras,
+                              Landmarks& landmarks) {
+  if (options.optimize_intrinsics) {
+    std::fprintf(stderr, "visnav_amd: bundle_adjustment with optimize_intrinsics is not implemented\n");
+    std::abort();
+  }
+  amd::run_ba<false>(feature_corners, options.use_huber, options.huber_parameter, options.max_num_iterations,
+                     options.verbosity_level, fixed_cameras, calib_cam, cameras, landmarks);
+}
+
+// include/visnav/loop_closure_utils.h:672-748
+inline void global_bundle_adjustment(const Corners& feature_corners, const GlobalBundleAdjustmentOptions& options,
+                                     const std::set<FrameCamId>& fixed_cameras, Calibration& calib_cam, Cameras& cameras,
+                                     Landmarks& landmarks) {
+  amd::run_ba<true>(feature_corners, options.use_huber, options.huber_parameter, options.max_num_iterations,
+                    options.verbosity_level, fixed_cameras, calib_cam, cameras, landmarks);
+}
+
+}  // namespace visnav

@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vslam_hip.h declares (no compute
+calls -- there is no GPU here), the oracle library exports what its header declares, and the product
+never references the oracle."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+DECL = re.compile(r"^\s*(?:const\s+)?[A-Za-z_][A-Za-z0-9_\s\*]*?\b((?:vsl|orc)_[a-z0-9_]+)\s*\(", re.M)
+
+
+def _declared(header):
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / header).read_text(), flags=re.S)
+    return sorted(set(DECL.findall(text)))
+
+
+def test_hip_library_exports_every_declared_symbol(vsl):
+    names = _declared("include/vslam_hip.h")
+    assert len(names) >= 30
+    lib = vsl.load()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_and_error_strings(vsl):
+    lib = vsl.load()
+    assert b"gfx950" in lib.vsl_version()
+    assert lib.vsl_last_error(None) is not None
+
+
+def test_no_device_means_loud_failure(vsl):
+    # In this container (no GPU) context creation must fail with VSL_ERR_NO_DEVICE: no CPU fallback.
+    lib = vsl.load()
+    if lib.vsl_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    h = ctypes.c_void_p()
+    assert lib.vsl_ctx_create(0, ctypes.byref(h)) == -5
+    assert b"no CPU fallback" in lib.vsl_last_error(None)
+    with pytest.raises(vsl.VslError):
+        vsl.Context(0)
+
+
+def test_oracle_exports(orc):
+    names = _declared("oracle/vslam_oracle.h")
+    lib = orc.lib()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_product_never_touches_the_oracle():
+    pkg = ROOT / "visual-slam_amd"
+    offenders = []
+    for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + list(pkg.rglob("Makefile")) + \
+            list((ROOT / "include").rglob("*.h")):
+        t = p.read_text()
+        if re.search(r"pyoracle|vslam_oracle|orc_[a-z]+\s*\(|liboracle|/oracle/", t):
+            offenders.append(str(p.relative_to(ROOT)))
+    assert not offenders, offenders
+
+
+def test_host_byte_order_helpers_match_reference_rule(vsl):
+    # pure host helpers: callable without a GPU.  converter.h:27: bit i -> byte i/8, bit 7 - i%8
+    import numpy as np
+    lib = vsl.load()
+    d = np.zeros((1, 4), np.uint64)
+    d[0, 0] = (1 << 0) | (1 << 9)
+    d[0, 3] = 1 << 63
+    b = np.zeros((1, 32), np.uint8)
+    lib.vsl_desc_bitset_to_bytes(d.ctypes.data_as(vsl.u64p), 1, b.ctypes.data_as(vsl.u8p))
+    assert b[0, 0] == 0x80 and b[0, 1] == 0x40 and b[0, 31] == 0x01 and b.sum() == 0x80 + 0x40 + 1
+    back = np.zeros_like(d)
+    lib.vsl_desc_bytes_to_bitset(b.ctypes.data_as(vsl.u8p), 1, back.ctypes.data_as(vsl.u64p))
+    assert np.array_equal(back, d)

@@ -1,0 +1,93 @@
+"""The C++ drop-in layer (include/visnav_amd/*.h): compiles against nothing but this repo's headers
+(CPU test), and -- on the GPU box -- reproduces the oracle when driven the way src/slam.cpp drives the
+reference (detectKeypointsAndDescriptors, the three separate calls, matchDescriptors(70, 1.2),
+bundle_adjustment, vocabulary transform + score)."""
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _compile(out):
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", str(ROOT / "include"),
+           str(ROOT / "tests/cpp/dropin_test.cpp"), "-o", str(out), "-L", str(ROOT / "visual-slam_amd"),
+           "-lvslam_hip", "-Wl,-rpath," + str(ROOT / "visual-slam_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def test_dropin_headers_compile(tmp_path, vsl):
+    assert vsl.library_path().exists()
+    _compile(tmp_path / "dropin_test")
+
+
+@pytest.mark.gpu
+def test_dropin_matches_oracle(tmp_path, orc, synth):
+    exe = _compile(tmp_path / "dropin_test")
+    left, right = synth.stereo_pair(31)
+    left.tofile(tmp_path / "l.raw")
+    right.tofile(tmp_path / "r.raw")
+    d = synth.ba_problem(9, n_kf=4, n_lms=500)
+    with open(tmp_path / "ba.bin", "wb") as f:
+        f.write(struct.pack("iii", len(d["poses"]), len(d["points"]), len(d["obs_cam"])))
+        for a, t in ((d["poses"], np.float64), (d["cam_fixed"], np.uint8), (d["intr"], np.float64),
+                     (d["points"], np.float64), (d["obs_cam"], np.int32), (d["obs_lm"], np.int32),
+                     (d["obs_uv"], np.float64)):
+            f.write(np.ascontiguousarray(a, t).tobytes())
+    (tmp_path / "voc.txt").write_text(synth.vocabulary_text(8, k=10, L=3))
+    r = subprocess.run([str(exe), str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), "752", "480",
+                        str(tmp_path / "ba.bin"), str(tmp_path / "voc.txt"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    buf = (tmp_path / "out.bin").read_bytes()
+    off = 0
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(buf, dtype, n, off)
+        off += a.nbytes
+        return a
+
+    descs = []
+    for img in (left, right):
+        n = int(take(np.int32, 1)[0])
+        xy, ang, desc = take(np.float64, 2 * n).reshape(n, 2), take(np.float64, n), take(np.uint64, 4 * n).reshape(n, 4)
+        oxy, oang, odesc = orc.detect_describe(img, 1500, True)
+        assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+        assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
+        descs.append(desc)
+    n = int(take(np.int32, 1)[0])
+    m = take(np.int32, 2 * n).reshape(n, 2)
+    assert np.array_equal(m, orc.match_descriptors(descs[0], descs[1], 70, 1.2))
+    # BA: the wrapper walks an unordered_map, so the landmark order (hence the summation order and
+    # possibly the iteration at which a convergence test fires) differs from the oracle's: same
+    # optimum -- cost within 1e-5 relative, poses within 1e-5, landmarks within 1e-6 except ill-conditioned depths
+    arr = orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"], d["obs_cam"], d["obs_lm"],
+                       d["obs_uv"], d["cam_model"])
+    orc.bundle_adjust(arr, max_iters=20)
+    poses = take(np.float64, 7 * len(d["poses"])).reshape(-1, 7)
+    points = take(np.float64, 3 * len(d["points"])).reshape(-1, 3)
+    dp = np.abs(points - arr.points).max(1)
+    assert np.allclose(poses, arr.poses, rtol=0, atol=1e-5), np.abs(poses - arr.poses).max()
+    # landmarks seen only by one stereo pair have an ill-conditioned 3x3 block (depth along the ray):
+    # rounding differences are amplified there, so: nearly all within 1e-6, every one within 5 cm
+    assert (dp < 1e-6).mean() > 0.97 and dp.max() < 0.05, (dp.max(), int((dp > 1e-6).sum()))
+    got = orc.BaArrays(poses, d["cam_fixed"], d["cam_intr"], d["intr"], points, d["obs_cam"], d["obs_lm"], d["obs_uv"],
+                       d["cam_model"])
+    assert orc.ba_linearize(got)[2] == pytest.approx(orc.ba_linearize(arr)[2], rel=1e-5)
+    assert not np.allclose(points, d["points"], atol=1e-4)  # it did move
+    # BoW of the left descriptors + scores
+    nb = int(take(np.int32, 1)[0])
+    rec = np.frombuffer(buf, np.dtype([("id", np.uint32), ("v", np.float64)]), nb, off)
+    off += rec.nbytes
+    s_lr, s_ll = take(np.float64, 2)
+    voc = orc.Vocabulary(tmp_path / "voc.txt")
+    oi, ov, _, _ = voc.transform(orc.bitset_to_bytes(descs[0]), 4)
+    ri, rv, _, _ = voc.transform(orc.bitset_to_bytes(descs[1]), 4)
+    assert np.array_equal(rec["id"], oi) and np.array_equal(rec["v"].view(np.uint64), ov.view(np.uint64))
+    assert s_lr == orc.bow_score_l1(oi, ov, ri, rv) and s_ll == orc.bow_score_l1(oi, ov, oi, ov)
