@@ -61,32 +61,28 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs per rank")
     ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--no-ba", dest="ba", action="store_false", help="skip the local-BA ms/iter measurement")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    vsl = entry.load_package()
+    synth = importlib.import_module("visual_slam_amd.synth")
+    vdist = importlib.import_module("visual_slam_amd.dist")
+    rank, world, local_rank = vdist.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    vsl = entry.load_package()
-    synth = importlib.import_module("visual_slam_amd.synth")
+    vdist.init("nccl")  # RCCL; a no-op at world size 1
     B = args.batch
     n_img = 2 * B
 
     stream = torch.cuda.Stream()
     ctx = vsl.Context(local_rank, stream=stream.cuda_stream)
     frames = vsl.Frames(ctx, n_img, W, H, NUM_FEATURES, max_pairs=B)
-    pairs_img = [synth.stereo_pair(1000 * rank + 10 + i) for i in range(args.distinct)]
+    pairs_img = [synth.stereo_pair(seed) for seed in vdist.stream_seeds(rank, args.distinct)]
     batch = np.stack([pairs_img[(k // 2) % args.distinct][k % 2] for k in range(n_img)])
     frames.upload(0, batch)  # inputs resident in HBM before the timed region
     slot_pairs = np.array([[2 * k, 2 * k + 1] for k in range(B)], np.int32)
@@ -97,8 +93,7 @@ def main():
         frames.match(slot_pairs, 70, 1.2)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        vdist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -108,11 +103,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
 
     nk, nm = frames.counts(n_img, B)
     if not (nk.min() > 0 and nm.min() > 0):
@@ -174,12 +165,40 @@ def main():
                                              "detect+describe x2 + match, single thread (the reference's "
                                              "keypoints.h path has no parallel loops)" % n_done}
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        # ---- second metric of BASELINE.json: ms per LM iteration of local bundle adjustment
+        # (configs[2]: 7 keyframes = 14 cameras, ~20k landmarks), GPU next to the oracle on all host cores
+        if args.ba:
+            d = synth.ba_problem(4, n_kf=7, n_lms=20000)
+            orc = entry.load_oracle()
+            mk = lambda: orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"],  # noqa: E731
+                                      d["obs_cam"], d["obs_lm"], d["obs_uv"], d["cam_model"])
+            ctx.bundle_adjust(mk(), max_iters=2)  # warm-up (allocations, code objects)
+            ctx.synchronize()
+            a = mk()
+            t0 = time.perf_counter()
+            sg = ctx.bundle_adjust(a, max_iters=20)
+            gpu_ms = 1e3 * (time.perf_counter() - t0)
+            ncpu = os.cpu_count() or 1
+            b = mk()
+            t0 = time.perf_counter()
+            sc = orc.bundle_adjust(b, max_iters=20, threads=ncpu)
+            cpu_ms = 1e3 * (time.perf_counter() - t0)
+            out["local_ba"] = {"workload": "7 keyframes (14 cameras, 2 fixed), %d landmarks, %d observations, "
+                                           "Huber 1.0, <= 20 LM iterations" % (len(d["points"]), len(d["obs_cam"])),
+                               "iterations": sg.iterations, "ms_per_iter": round(gpu_ms / max(sg.iterations, 1), 4),
+                               "ms_total_incl_upload": round(gpu_ms, 3),
+                               "device_ms": {"linearize": round(sg.linearize_ms, 3), "schur": round(sg.schur_ms, 3),
+                                             "solve": round(sg.solve_ms, 3)},
+                               "final_cost_rel_diff_vs_oracle": abs(sg.final_cost - sc.final_cost) / sc.final_cost,
+                               "cpu_oracle_ms_per_iter": round(cpu_ms / max(sc.iterations, 1), 3),
+                               "cpu_threads": ncpu}
         print(json.dumps(out), flush=True)
 
     frames.close()
     ctx.close()
+    vdist.barrier()
     if world > 1:
-        dist.barrier()
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 
