@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="stereo frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="stereo frames per step per GPU (256 images: one selection workgroup per CU)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs per rank")
     ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
