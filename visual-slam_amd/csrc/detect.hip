@@ -16,7 +16,8 @@
 #include "vsl_common.h"
 
 #define K1_ROWS 16
-#define K1_COLS 62  // output columns per wave: 64 lanes minus one halo lane on each side
+#define K1_LIST 1024  // LDS candidate slots per workgroup; overflow goes straight to global memory
+#define K1_COLS 60  // owned columns per wave: 64 lanes minus two halo lanes on each side
 
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
@@ -26,7 +27,7 @@ struct RowF {
 
 __device__ __forceinline__ RowF rowfilt(const uint8_t* __restrict__ img, int w, int yr, int xm, int xe, int xp,
                                         float s, float s2) {
-  const uint8_t* row = img + (size_t)yr * w;
+  const uint8_t* row = img + yr * w;
   const float l = (float)row[xm], m = (float)row[xe], r = (float)row[xp];
   RowF o;
   o.rx = r - l;
@@ -37,6 +38,15 @@ __device__ __forceinline__ RowF rowfilt(const uint8_t* __restrict__ img, int w, 
   return o;
 }
 
+// value of the lane below / above (wave-wide shift by one lane, a full-rate DPP move; lane 0 / 63
+// receive 0 and are halo lanes whose results are never used)
+__device__ __forceinline__ float from_lane_below(float v) {  // lane i <- lane i-1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_lane_above(float v) {  // lane i <- lane i+1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
 __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
@@ -45,58 +55,78 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
   }
 }
 
-// K1.  grid = (ceil(w/62), ceil(h/64), n_images), block = 256: wave v of a block owns the 16-row
-// strip (blockIdx.y*4 + v) of the 62-column strip blockIdx.x.  One image column per lane; rows are
-// walked top to bottom with the row-filter results and the fp64 row sums held in registers, so an
-// image byte is loaded ~1.3 times and nothing is staged through LDS; the +-1 column neighbours of
-// the cov values come from cross-lane shuffles.
+// K1 + K2a fused.  grid = (ceil(w/60), ceil(h/64), n_images), block = 256: wave v of a block owns the
+// 16-row strip (blockIdx.y*4 + v) of the 60-column strip blockIdx.x.  One image column per lane; rows
+// are walked top to bottom with the row-filter results, the fp64 row sums and three response rows held
+// in registers; column neighbours come from DPP lane shifts.  Nothing but the image is read and -- in
+// the normal pipeline -- nothing but the candidate list is written: the response image (4 bytes per
+// pixel) never goes to memory.
+//
+// Candidates.  goodFeaturesToTrack keeps a pixel iff its thresholded response is non-zero and equals the
+// 3x3 maximum of the thresholded response, with threshold = 0.01 * (global maximum) -- unknown until the
+// whole image has been processed.  For a positive threshold that is equivalent to
+//      response > threshold   and   no 3x3 neighbour has a larger raw response,
+// so this kernel emits every pixel with response > 0 and no larger neighbour ("provisional
+// candidates", a superset), and the selection kernel drops those at or below the threshold once the
+// maximum is known.  (A response image whose maximum is <= 0 yields no corners here; OpenCV could only
+// differ on an image whose responses are all negative.)
+// Key = (order-preserving fp32 bits << 32) | pixel index: a descending sort on the key is the
+// reference's order (value descending, equal values by address descending).
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
-                                                               float* __restrict__ response,
-                                                               int32_t* __restrict__ meta, int w, int h,
-                                                               int first) {
+                                                               float* __restrict__ response, int32_t* __restrict__ meta,
+                                                               uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
+                                                               int first, int store_response) {
+  __shared__ uint64_t list[K1_LIST];
+  __shared__ int n_list, g_base;
   const int slot = first + blockIdx.z;
   const uint8_t* __restrict__ img = images + (size_t)slot * w * h;
   float* __restrict__ resp = response + (size_t)slot * w * h;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * K1_COLS;
+  const int xs = blockIdx.x * K1_COLS;
   const int y0 = (blockIdx.y * 4 + wave) * K1_ROWS;
-  if (y0 >= h) return;
-  const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
-  const float s2 = 2.0f * s;
-  const int x = x0 - 1 + lane;
-  int xe = reflect101(min(x, w), w);  // lanes right of the halo are parked on a valid column
-  const int xm = reflect101(xe - 1, w), xp = reflect101(xe + 1, w);
+  if (threadIdx.x == 0) n_list = 0;
+  __syncthreads();
+  if (y0 < h) {
+    const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
+    const float s2 = 2.0f * s;
+    const int x = xs - 2 + lane;
+    const int xe = reflect101(min(max(x, -1), w), w);  // out-of-range lanes are parked on a valid column
+    const int xm = reflect101(xe - 1, w), xp = reflect101(xe + 1, w);
+    const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
 
-  double Rxx[3], Rxy[3], Ryy[3];  // row sums of rows q-2, q-1, q
-  RowF f0, f1, f2;                // row filters of rows ye-1, ye, ye+1
-  int prev_ye = -100;
-  float vmax = -INFINITY;
-  const int y_end = min(h, y0 + K1_ROWS);
-  for (int q = y0 - 1; q <= y_end; q++) {
-    const int ye = reflect101(q, h);
-    if (ye == prev_ye + 1 && ye + 1 < h) {
-      f0 = f1;
-      f1 = f2;
-      f2 = rowfilt(img, w, ye + 1, xm, xe, xp, s, s2);
-    } else {
-      f0 = rowfilt(img, w, reflect101(ye - 1, h), xm, xe, xp, s, s2);
-      f1 = rowfilt(img, w, ye, xm, xe, xp, s, s2);
-      f2 = rowfilt(img, w, reflect101(ye + 1, h), xm, xe, xp, s, s2);
-    }
-    prev_ye = ye;
-    const float dx = (f0.rx + f2.rx) * s + f1.rx * s2;
-    const float dy = f2.ry - f0.ry;
-    const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
-    const float lxx = __shfl_up(cxx, 1), lxy = __shfl_up(cxy, 1), lyy = __shfl_up(cyy, 1);
-    const float rxx = __shfl_down(cxx, 1), rxy = __shfl_down(cxy, 1), ryy = __shfl_down(cyy, 1);
-    Rxx[0] = Rxx[1]; Rxx[1] = Rxx[2];
-    Rxy[0] = Rxy[1]; Rxy[1] = Rxy[2];
-    Ryy[0] = Ryy[1]; Ryy[1] = Ryy[2];
-    Rxx[2] = ((double)lxx + (double)cxx) + (double)rxx;
-    Rxy[2] = ((double)lxy + (double)cxy) + (double)rxy;
-    Ryy[2] = ((double)lyy + (double)cyy) + (double)ryy;
-    if (q >= y0 + 1) {
+    double Rxx[3] = {0, 0, 0}, Rxy[3] = {0, 0, 0}, Ryy[3] = {0, 0, 0};  // row sums of rows q-2, q-1, q
+    float v_up = 0.f, v_mid = 0.f;                                       // response rows q-3, q-2
+    float l_up = 0.f, r_up = 0.f, l_mid = 0.f, r_mid = 0.f;              // their column neighbours
+    RowF f0, f1, f2;                                                      // row filters of rows ye-1, ye, ye+1
+    int prev_ye = -100;
+    float vmax = -INFINITY;
+    const int y_end = min(h, y0 + K1_ROWS);
+    // q = row whose row sums are produced; response row q-1 is complete after it; candidate row q-2
+    for (int q = y0 - 2; q <= y_end + 1; q++) {
+      const int ye = reflect101(min(max(q, -1), h), h);
+      if (ye == prev_ye + 1 && ye + 1 < h) {
+        f0 = f1;
+        f1 = f2;
+        f2 = rowfilt(img, w, ye + 1, xm, xe, xp, s, s2);
+      } else {
+        f0 = rowfilt(img, w, reflect101(ye - 1, h), xm, xe, xp, s, s2);
+        f1 = rowfilt(img, w, ye, xm, xe, xp, s, s2);
+        f2 = rowfilt(img, w, reflect101(ye + 1, h), xm, xe, xp, s, s2);
+      }
+      prev_ye = ye;
+      const float dx = (f0.rx + f2.rx) * s + f1.rx * s2;
+      const float dy = f2.ry - f0.ry;
+      const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
+      const float lxx = from_lane_below(cxx), lxy = from_lane_below(cxy), lyy = from_lane_below(cyy);
+      const float rxx = from_lane_above(cxx), rxy = from_lane_above(cxy), ryy = from_lane_above(cyy);
+      Rxx[0] = Rxx[1]; Rxx[1] = Rxx[2];
+      Rxy[0] = Rxy[1]; Rxy[1] = Rxy[2];
+      Ryy[0] = Ryy[1]; Ryy[1] = Ryy[2];
+      Rxx[2] = ((double)lxx + (double)cxx) + (double)rxx;
+      Rxy[2] = ((double)lxy + (double)cxy) + (double)rxy;
+      Ryy[2] = ((double)lyy + (double)cyy) + (double)ryy;
+      // response of row y = q - 1 (valid once three row sums exist)
       const int y = q - 1;
       const double Axx = (Rxx[0] + Rxx[1]) + Rxx[2];
       const double Axy = (Rxy[0] + Rxy[1]) + Rxy[2];
@@ -107,84 +137,37 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const float bb = b * b;
       t = t + bb;
       // sqrtf is correctly rounded under hipcc's default flags; __fsqrt_rn is the approximate native sqrt
-      const float val = (a + c) - sqrtf(t);
-      if (lane >= 1 && lane <= K1_COLS && x < w) {
-        resp[(size_t)y * w + x] = val;
-        vmax = fmaxf(vmax, val);
+      const float v_dn = (a + c) - sqrtf(t);
+      const float l_dn = from_lane_below(v_dn), r_dn = from_lane_above(v_dn);
+      if (own_col && y >= y0 && y < y_end) {
+        if (store_response) resp[y * w + x] = v_dn;
+        vmax = fmaxf(vmax, v_dn);
       }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-  if (lane == 0) atomicMax(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_MAX], vsl_float_to_ordered(vmax));
-}
-
-// K2a.  Candidates = strict interior pixels whose thresholded response is non-zero and equals the
-// 3x3 maximum of the thresholded response (goodFeaturesToTrack: threshold(TOZERO) + dilate + compare).
-// Key = (order-preserving fp32 bits << 32) | pixel index: a descending sort on the key is the
-// reference's order (value descending, equal values by address descending).
-// A workgroup owns a 64 x 32 tile (a lane walks 8 rows with a sliding 3x3 window: 3 loads per
-// pixel), gathers its candidates in LDS and reserves its output range with ONE global atomic; the
-// per-image counters sit on separate 128-byte lines (VSL_META_STRIDE), because thousands of
-// returning atomics on neighbouring words serialise in one L2 channel (measured: 3.1 ms per 128
-// images with one atomic per wave on adjacent counters).
-#define K2A_ROWS 8
-__global__ __launch_bounds__(256) void candidates_kernel(const float* __restrict__ response,
-                                                         int32_t* __restrict__ meta, uint64_t* __restrict__ cand,
-                                                         int w, int h, size_t cand_cap, int first, double quality) {
-  const int slot = first + blockIdx.z;
-  const float* __restrict__ resp = response + (size_t)slot * w * h;
-  const float maxv = vsl_ordered_to_float(meta[(size_t)slot * VSL_META_STRIDE + VSL_META_MAX]);
-  const float thr = (float)((double)maxv * quality);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 64 + lane;
-  const int y0 = blockIdx.y * (4 * K2A_ROWS) + wave * K2A_ROWS;
-  __shared__ uint64_t list[64 * 4 * K2A_ROWS];
-  __shared__ int n_list, g_base;
-  if (threadIdx.x == 0) n_list = 0;
-  __syncthreads();
-  const bool col_ok = x >= 1 && x < w - 1;
-  if (col_ok && y0 < h - 1) {
-    // thresholded 3-wide rows of the window: t[r][c]
-    float t[3][3];
-    auto load_row = [&](int yy, float* o) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const float v = resp[(size_t)yy * w + (x - 1 + c)];
-        o[c] = v;
-      }
-    };
-    const int ys = max(y0, 1);
-    load_row(ys - 1, t[0]);
-    load_row(ys, t[1]);
-    const int ye = min(h - 1, y0 + K2A_ROWS);
-    for (int y = ys; y < ye; y++) {
-      load_row(y + 1, t[2]);
-      const float val = t[1][1];
-      if (val > thr && val != 0.f) {
-        bool is_c = true;
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const float nv = t[r][c] > thr ? t[r][c] : 0.f;
-            is_c = is_c && !(nv > val);
-          }
-        if (is_c) {
-          const uint32_t ob = (uint32_t)vsl_float_to_ordered(val) ^ 0x80000000u;
+      // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn)
+      const int yc = q - 2;
+      if (own_col && yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1 && x >= 1 && x < w - 1 && v_mid > 0.f) {
+        const float m8 = fmaxf(fmaxf(fmaxf(l_up, v_up), fmaxf(r_up, l_mid)), fmaxf(fmaxf(r_mid, l_dn), fmaxf(v_dn, r_dn)));
+        if (!(m8 > v_mid)) {
+          const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
+          const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
           const int p = atomicAdd(&n_list, 1);
-          list[p] = ((uint64_t)ob << 32) | (uint32_t)(y * w + x);
+          if (p < K1_LIST) {
+            list[p] = key;
+          } else {  // more than K1_LIST candidates in one 60 x 64 tile (plateaus): rare direct append
+            const int g = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], 1);
+            if ((size_t)g < cand_cap) cand[(size_t)slot * cand_cap + g] = key;
+          }
         }
       }
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        t[0][c] = t[1][c];
-        t[1][c] = t[2][c];
-      }
+      v_up = v_mid; l_up = l_mid; r_up = r_mid;
+      v_mid = v_dn; l_mid = l_dn; r_mid = r_dn;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) atomicMax(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_MAX], vsl_float_to_ordered(vmax));
   }
   __syncthreads();
-  const int n = n_list;
+  const int n = min(n_list, K1_LIST);
   if (n == 0) return;
   if (threadIdx.x == 0) g_base = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], n);
   __syncthreads();
@@ -244,7 +227,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
                                                              const int32_t* __restrict__ meta,
                                                              int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_count,
                                                              int w, int h, size_t cand_cap, int F, int first,
-                                                             int num_features, int border) {
+                                                             int num_features, int border, double quality) {
   __shared__ __align__(16) unsigned char smem[SEL_LDS_BYTES];
   const int slot = first + blockIdx.x;
   const uint64_t* __restrict__ cand = cand_all + (size_t)slot * cand_cap;
@@ -266,8 +249,24 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
 
   int n_acc = 0, n_out = 0;
   unsigned long long hi = ~0ull;  // keys >= hi have been consumed
-  int remaining = n_cand;
   int32_t* out = kp_xy + (size_t)slot * F * 2;
+  // quality threshold (goodFeaturesToTrack: eig > maxVal * qualityLevel survives THRESH_TOZERO): the
+  // provisional candidates at or below it do not exist as far as the rest of the kernel is concerned
+  const float maxv = vsl_ordered_to_float(meta[(size_t)slot * VSL_META_STRIDE + VSL_META_MAX]);
+  const float thr = (float)((double)maxv * quality);
+  const unsigned long long floor_key =
+      (((unsigned long long)((uint32_t)vsl_float_to_ordered(thr) ^ 0x80000000u)) << 32) | 0xFFFFFFFFull;
+  int remaining = 0;
+  if (maxv > 0.f) {
+    int mine = 0;
+    for (int i = tid; i < n_cand; i += SEL_THREADS) mine += cand[i] > floor_key;
+    if (tid == 0) sh->n_chunk = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&sh->n_chunk, mine);
+    __syncthreads();
+    remaining = sh->n_chunk;
+    __syncthreads();
+  }
 
   while (remaining > 0 && n_acc < num_features) {
     // ---- choose the chunk [lo, hi): all remaining keys, or the SEL_CHUNK largest of them
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
         const unsigned long long pmask = shift == 56 ? 0ull : (~0ull << (shift + 8));
         for (int i = tid; i < n_cand; i += SEL_THREADS) {
           const unsigned long long key = cand[i];
-          if (key < hi && (key & pmask) == prefix) atomicAdd(&sh->hist[(int)((key >> shift) & 255)], 1);
+          if (key < hi && key > floor_key && (key & pmask) == prefix) atomicAdd(&sh->hist[(int)((key >> shift) & 255)], 1);
         }
         __syncthreads();
         if (tid == 0) {
@@ -305,7 +304,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
     __syncthreads();
     for (int i = tid; i < n_cand; i += SEL_THREADS) {
       const unsigned long long key = cand[i];
-      if (key >= lo && key < hi) {
+      if (key >= lo && key < hi && key > floor_key) {
         const int p = atomicAdd(&sh->n_chunk, 1);
         if (p < SEL_CHUNK) keys[p] = key;
       }
@@ -425,15 +424,14 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     VslStage st(ctx, VSL_STAGE_RESPONSE);
     hipLaunchKernelGGL(detect_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f->meta, first, n);
     hipLaunchKernelGGL(min_eig_response_kernel, dim3((w + K1_COLS - 1) / K1_COLS, (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS), n),
-                       dim3(256), 0, ctx->stream, f->images, f->response, f->meta, w, h, first);
-    hipLaunchKernelGGL(candidates_kernel, dim3((w + 63) / 64, (h + 4 * K2A_ROWS - 1) / (4 * K2A_ROWS), n), dim3(256), 0,
-                       ctx->stream, f->response, f->meta, f->cand, w, h, f->cand_cap, first, 0.01);
+                       dim3(256), 0, ctx->stream, f->images, f->response, f->meta, f->cand, f->cand_cap, w, h, first,
+                       f->store_response ? 1 : 0);
     VSL_CHECK_LAUNCH(ctx);
   }
   {
     VslStage st(ctx, VSL_STAGE_SELECT);
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), 0, ctx->stream, f->cand, f->meta, f->kp_xy,
-                       f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19);
+                       f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01);
     VSL_CHECK_LAUNCH(ctx);
   }
   return VSL_OK;

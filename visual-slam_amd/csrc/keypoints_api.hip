@@ -122,7 +122,10 @@ extern "C" int vsl_min_eig_response(vsl_ctx* ctx, const uint8_t* img, int w, int
   rc = vsl_ctx_scratch_frames(ctx, w, h, ctx->scratch_feat > 0 ? ctx->scratch_feat : 2048, &f);
   if (rc) return rc;
   if ((rc = upload_image(ctx, f, img, pitch))) return rc;
-  if ((rc = vsl_launch_detect(ctx, f, 0, 1, 1))) return rc;
+  f->store_response = true;
+  rc = vsl_launch_detect(ctx, f, 0, 1, 1);
+  f->store_response = false;
+  if (rc) return rc;
   VSL_HIP(ctx, hipMemcpyAsync(response, f->response, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VSL_OK;

@@ -161,6 +161,8 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
   constexpr int WAVES = 8;
   {
     VslStage st(ctx, VSL_STAGE_MATCH);
+    // (a row-split variant -- waves share the column stream, no merge -- was measured slower: 0.288 vs
+    // 0.255 ms per 128 pairs; the column split keeps more, shorter waves in flight)
     dim3 grid((f->F + 63) / 64, 2, n_pairs);
     hipLaunchKernelGGL(hamming_best2_kernel<WAVES>, grid, dim3(64 * WAVES), 0, ctx->stream, f->kp_desc,
                        f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);

@@ -102,6 +102,7 @@ struct vsl_frames {
   int32_t* tie_rec = nullptr;      // [tie_cap][4]  (slot, keypoint, bit, unused)
   int tie_cap = 0;
   bool ties_pending = false, ties_from_angles = false;
+  bool store_response = false;  // K1 writes the fp32 response image only for the parity hook
   std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
 };
 
