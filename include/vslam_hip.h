@@ -256,6 +256,32 @@ int vsl_ba_linearize(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_opti
 int vsl_ba_residuals_jacobians(vsl_ctx* ctx, const vsl_ba_problem* prob, double* r, double* J_pose,
                                double* J_point);
 
+/* ---- step-wise session: multi-GPU global bundle adjustment ----
+ * One process per GPU.  Every rank holds all camera poses and owns the landmark range
+ * [lm_first, lm_first + lm_count) with its observations; per LM iteration the ranks SUM-all-reduce
+ * the packed partial reduced camera system and five scalars (RCCL over xGMI via torch.distributed;
+ * the loop is visual-slam_amd/ba_dist.py).  `_dev` arguments are DEVICE pointers; those calls are
+ * asynchronous on the context's stream.  Replaces, for ~500-keyframe maps, the single Ceres solve of
+ * global_bundle_adjustment (include/visnav/loop_closure_utils.h:672-748). */
+typedef struct vsl_ba_session vsl_ba_session;
+int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
+                          int lm_first, int lm_count, vsl_ba_session** out);
+int vsl_ba_session_destroy(vsl_ba_session* s);
+/* n = 6 * free cameras; owned landmarks / observations; cameras. */
+int vsl_ba_session_dims(const vsl_ba_session* s, int* n, int* n_lms_own, int* n_obs_own, int* n_cams);
+int vsl_ba_session_linearize(vsl_ba_session* s, int use_scale);
+/* out_dev[n + 1] = [diag(H_part) | cost_part] */
+int vsl_ba_session_hdiag_cost_dev(vsl_ba_session* s, double* out_dev);
+int vsl_ba_session_set_scale_dev(vsl_ba_session* s, const double* hdiag_full_dev);
+/* packB_dev[n*n + 3n + 2] = [S_part | rhs_part | diag(H_part) | g_c part | cost_part | 0];
+ * gmax_l_dev[1] (nullable) = max |gradient| over the owned landmark columns */
+int vsl_ba_session_reduce_dev(vsl_ba_session* s, double radius, double* packB_dev, double* gmax_l_dev);
+/* packC_dev[8] = [bad, model_part, step2, x2, cand_cost_part, step2_cams, x2_cams, 0] */
+int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_full_dev, double radius,
+                            int refresh_diag, double* packC_dev);
+int vsl_ba_session_accept(vsl_ba_session* s);
+int vsl_ba_session_download(vsl_ba_session* s, double* poses, double* points_own);
+
 /* --------------------------------------------------------------- DBoW2 path */
 /*
  * Replaces, for loop-closure candidate scoring:

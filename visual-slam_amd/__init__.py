@@ -273,6 +273,61 @@ class Context:
         return scores[:m].copy()
 
 
+class BaSession:
+    """vsl_ba_session: the step-wise (multi-GPU) bundle-adjustment API; see ba_dist.py for the loop."""
+
+    def __init__(self, ctx, arr, use_huber=True, huber=1.0, lm_first=0, lm_count=None):
+        self.ctx = ctx
+        st = ctx._ba_struct(arr)
+        o = ctx._ba_opts(use_huber, huber, 0, 0)
+        if lm_count is None:
+            lm_count = len(arr.points) - lm_first
+        h = C.c_void_p()
+        ctx._ck(ctx.L.vsl_ba_session_create(ctx.h, C.byref(st), C.byref(o), int(lm_first), int(lm_count), C.byref(h)))
+        self.h = h
+        v = [C.c_int32() for _ in range(4)]
+        ctx._ck(ctx.L.vsl_ba_session_dims(self.h, *[C.byref(x) for x in v]))
+        self.n, self.n_lms, self.n_obs, self.n_cams = (x.value for x in v)
+        self.lm_first, self.lm_count = int(lm_first), int(lm_count)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.vsl_ba_session_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def linearize(self, use_scale):
+        self.ctx._ck(self.ctx.L.vsl_ba_session_linearize(self.h, int(use_scale)))
+
+    def hdiag_cost(self, out_ptr):
+        self.ctx._ck(self.ctx.L.vsl_ba_session_hdiag_cost_dev(self.h, C.c_void_p(out_ptr)))
+
+    def set_scale(self, hdiag_ptr):
+        self.ctx._ck(self.ctx.L.vsl_ba_session_set_scale_dev(self.h, C.c_void_p(hdiag_ptr)))
+
+    def reduce(self, radius, packb_ptr, gmax_ptr):
+        self.ctx._ck(self.ctx.L.vsl_ba_session_reduce_dev(self.h, C.c_double(radius), C.c_void_p(packb_ptr),
+                                                          C.c_void_p(gmax_ptr)))
+
+    def step(self, packb_ptr, radius, refresh, packc_ptr):
+        self.ctx._ck(self.ctx.L.vsl_ba_session_step_dev(self.h, C.c_void_p(packb_ptr), C.c_double(radius),
+                                                        int(refresh), C.c_void_p(packc_ptr)))
+
+    def accept(self):
+        self.ctx._ck(self.ctx.L.vsl_ba_session_accept(self.h))
+
+    def download(self):
+        poses = np.zeros((self.n_cams, 7))
+        pts = np.zeros((self.n_lms, 3))
+        self.ctx._ck(self.ctx.L.vsl_ba_session_download(self.h, poses.ctypes.data_as(f64p), pts.ctypes.data_as(f64p)))
+        return poses, pts
+
+
 class Vocabulary:
     def __init__(self, ctx, path):
         self.ctx = ctx

@@ -1353,3 +1353,322 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   if (summary) *summary = sum;
   return VSL_OK;
 }
+
+// =================================================================================================
+// Step-wise session: the multi-GPU global-BA path.
+//
+// One process per GPU.  Every rank holds all camera poses and OWNS a contiguous landmark range with
+// its observations (the session is built on that sub-problem).  Per LM iteration the ranks exchange
+//   packB = [ S_part (n*n) | rhs_part (n) | diag(H_part) (n) | g_c part (n) | cost_part | 0 ]  SUM all-reduce
+//   packC = [ bad, model_part, step2_lm, x2_lm, cand_cost_part ]                  SUM all-reduce
+// (plus one MAX all-reduce of the landmark gradient norm after an accepted step, and one SUM of
+// [diag(H_part) | cost_part] for the Jacobi scaling at iteration 0).  Every rank then factorises the
+// same reduced camera system redundantly -- RCCL all-reduce leaves bit-identical buffers on all ranks,
+// so the accept / reject decisions agree without a broadcast.  Landmark damping and back-substitution
+// are local.  The host-side loop lives in visual-slam_amd/ba_dist.py (torch.distributed = RCCL).
+struct vsl_ba_session {
+  vsl_ctx* ctx = nullptr;
+  BaState st;
+  vsl_ba_options opt;
+  int lm_first = 0, lm_count = 0;
+  DevBuf diagc_keep;  // clamp(diag H_full): reused across rejected steps
+};
+
+namespace {
+__global__ void sess_pack_hdiag_kernel(int nfree, const double* __restrict__ H, const double* __restrict__ scalars,
+                                       double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = 6 * nfree;
+  if (i < n) out[i] = H[36 * (size_t)(i / 6) + 7 * (i % 6)];
+  if (i == 0) out[n] = scalars[0];
+}
+
+__global__ void sess_scale_kernel(int nfree, int L, const double* __restrict__ hdiag_full, const double* __restrict__ n2l,
+                                  double* __restrict__ scale_c, double* __restrict__ scale_l) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * nfree) scale_c[i] = 1.0 / (1.0 + sqrt(hdiag_full[i]));
+  if (i < 3 * L) scale_l[i] = 1.0 / (1.0 + sqrt(n2l[i]));
+}
+
+// landmark LM diagonal (own landmarks) and |gradient| of the unscaled problem for the landmark columns
+__global__ void sess_diag_l_kernel(int L, const double* __restrict__ n2l, const double* __restrict__ grad_l,
+                                   const double* __restrict__ scale_l, double* __restrict__ diag_l, double* __restrict__ gabs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 * L) {
+    diag_l[i] = fmin(fmax(n2l[i], 1e-6), 1e32);
+    gabs[i] = fabs(grad_l[i] / scale_l[i]);
+  }
+}
+
+// packB tail after the n*n block: [rhs_part | diag(H_part) | g_c part (raw sum F^T r) | cost_part | 0]
+__global__ void sess_pack_b_kernel(int nfree, const double* __restrict__ rhs, const double* __restrict__ H,
+                                   const double* __restrict__ g_c, const double* __restrict__ scalars,
+                                   double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = 6 * nfree;
+  if (i < n) {
+    out[i] = rhs[i];
+    out[n + i] = H[36 * (size_t)(i / 6) + 7 * (i % 6)];
+    out[2 * n + i] = g_c[i];
+  }
+  if (i == 0) {
+    out[3 * n] = scalars[0];
+    out[3 * n + 1] = 0.0;
+  }
+}
+
+// S = S_full + diag(diag_c / radius); diag_c = clamp(diag H_full) when refresh, else kept; gabs_c
+__global__ void sess_damp_kernel(int n, const double* __restrict__ packB, double inv_radius, int refresh,
+                                 double* __restrict__ diag_keep, double* __restrict__ S, double* __restrict__ rhs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n * n) {
+    double v = packB[idx];
+    const int i = idx / n, j = idx - i * n;
+    if (i == j) {
+      double d = diag_keep[i];
+      if (refresh) {
+        d = fmin(fmax(packB[(size_t)n * n + n + i], 1e-6), 1e32);
+        diag_keep[i] = d;
+      }
+      v += d * inv_radius;
+    }
+    S[idx] = v;
+  }
+  if (idx < n) rhs[idx] = packB[(size_t)n * n + idx];
+}
+
+__global__ void sess_pack_c_kernel(const double* __restrict__ scalars, const int* __restrict__ flag, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = flag[0] ? 0.0 : 1.0;  // number of ranks whose step is unusable
+    out[1] = scalars[2];           // model cost change, own observations
+    out[2] = scalars[3];           // squared step norm (own landmarks + cameras, see ba_dist.py)
+    out[3] = scalars[4];           // squared x norm   (own landmarks + cameras)
+    out[4] = scalars[5];           // candidate cost, own observations
+    out[5] = scalars[6];           // squared step norm of the cameras alone (replicated on every rank)
+    out[6] = scalars[7];           // squared x norm of the cameras alone
+    out[7] = 0.0;
+  }
+}
+
+// camera-only parts of the step / x norms (identical on every rank)
+__global__ __launch_bounds__(256) void sess_cam_norms_kernel(BaDims D, const int* __restrict__ cam_free,
+                                                             const double* __restrict__ poses, const double* __restrict__ dc,
+                                                             const double* __restrict__ scale_c, double* __restrict__ scalars) {
+  __shared__ double sh[256];
+  double step2 = 0, x2 = 0;
+  for (int c = threadIdx.x; c < D.C; c += 256) {
+    const int fc = cam_free[c];
+    if (fc < 0) continue;
+    for (int j = 0; j < 6; j++) {
+      const double d = dc[6 * fc + j] * scale_c[6 * fc + j];
+      step2 += d * d;
+    }
+    for (int j = 0; j < 7; j++) x2 += poses[7 * (size_t)c + j] * poses[7 * (size_t)c + j];
+  }
+  const double a = block_sum_256(step2, sh);
+  __syncthreads();
+  const double b = block_sum_256(x2, sh);
+  if (threadIdx.x == 0) {
+    scalars[6] = a;
+    scalars[7] = b;
+  }
+}
+}  // namespace
+
+extern "C" int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, int lm_first,
+                                     int lm_count, vsl_ba_session** out) {
+  int rc = ba_validate(ctx, prob);
+  if (rc) return rc;
+  if (!opt || !out) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_session_create: null argument");
+  *out = nullptr;
+  if (lm_first < 0 || lm_count < 1 || lm_first + lm_count > prob->n_lms)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_session_create: landmark range [%d, %d) must be non-empty and inside [0, %d)", lm_first, lm_first + lm_count, prob->n_lms);
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  // sub-problem of the owned landmarks (all cameras)
+  std::vector<int32_t> ocam, olm;
+  std::vector<double> ouv;
+  for (int i = 0; i < prob->n_obs; i++) {
+    const int l = prob->obs_lm[i];
+    if (l >= lm_first && l < lm_first + lm_count) {
+      ocam.push_back(prob->obs_cam[i]);
+      olm.push_back(l - lm_first);
+      ouv.push_back(prob->obs_uv[2 * (size_t)i]);
+      ouv.push_back(prob->obs_uv[2 * (size_t)i + 1]);
+    }
+  }
+  if (ocam.empty()) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_session_create: landmark range has no observations");
+  vsl_ba_problem sub = *prob;
+  sub.n_lms = lm_count;
+  sub.n_obs = (int32_t)ocam.size();
+  sub.points = prob->points + 3 * (size_t)lm_first;
+  sub.obs_cam = ocam.data();
+  sub.obs_lm = olm.data();
+  sub.obs_uv = ouv.data();
+  vsl_ba_session* s = new (std::nothrow) vsl_ba_session;
+  if (!s) return vsl_fail(ctx, VSL_ERR_NOMEM, "out of host memory");
+  s->ctx = ctx;
+  s->opt = *opt;
+  s->lm_first = lm_first;
+  s->lm_count = lm_count;
+  if ((rc = ba_setup(ctx, &sub, opt, s->st))) {
+    delete s;
+    return rc;
+  }
+  if (s->diagc_keep.alloc(8 * (size_t)(s->st.D.n > 0 ? s->st.D.n : 1)) != hipSuccess) {
+    delete s;
+    return vsl_fail(ctx, VSL_ERR_NOMEM, "device allocation failed");
+  }
+  *out = s;
+  return VSL_OK;
+}
+
+extern "C" int vsl_ba_session_destroy(vsl_ba_session* s) {
+  if (!s) return VSL_OK;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  delete s;
+  return VSL_OK;
+}
+
+extern "C" int vsl_ba_session_dims(const vsl_ba_session* s, int* n, int* n_lms_own, int* n_obs_own, int* n_cams) {
+  if (!s) return VSL_ERR_INVALID;
+  if (n) *n = s->st.D.n;
+  if (n_lms_own) *n_lms_own = s->st.D.L;
+  if (n_obs_own) *n_obs_own = s->st.D.O;
+  if (n_cams) *n_cams = s->st.D.C;
+  return VSL_OK;
+}
+
+// Linearise the owned observations at the current parameters (Jacobi-scaled when use_scale) and
+// compute the per-landmark / per-camera column statistics.
+extern "C" int vsl_ba_session_linearize(vsl_ba_session* s, int use_scale) {
+  if (!s) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ba_linearize(ctx, s->st, use_scale != 0);
+  if (rc) return rc;
+  return ba_columns(ctx, s->st);
+}
+
+// out_dev[n + 1] = [diag(H_part) | cost_part]   (device pointer; asynchronous on the context's stream)
+extern "C" int vsl_ba_session_hdiag_cost_dev(vsl_ba_session* s, double* out_dev) {
+  if (!s || !out_dev) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  const BaDims& D = s->st.D;
+  hipLaunchKernelGGL(sess_pack_hdiag_kernel, dim3((D.n + 256) / 256), dim3(256), 0, ctx->stream, D.nfree, s->st.H.as<double>(),
+                     s->st.scalars.as<double>(), out_dev);
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// Jacobi scaling from the all-reduced diag(H) (cameras) and the owned landmark column norms; scales the
+// stored Jacobian blocks and refreshes the column statistics.
+extern "C" int vsl_ba_session_set_scale_dev(vsl_ba_session* s, const double* hdiag_full_dev) {
+  if (!s || !hdiag_full_dev) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  BaState& st = s->st;
+  const BaDims& D = st.D;
+  const int nmax = std::max(D.n, 3 * D.L);
+  hipLaunchKernelGGL(sess_scale_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, D.L, hdiag_full_dev,
+                     st.n2l.as<double>(), st.scale_c.as<double>(), st.scale_l.as<double>());
+  hipLaunchKernelGGL(ba_apply_scale_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D.O, st.cam_free.as<int>(),
+                     st.obs_cam.as<int>(), st.obs_lm.as<int>(), st.scale_c.as<double>(), st.scale_l.as<double>(),
+                     st.F.as<double>(), st.E.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
+  return ba_columns(ctx, st);
+}
+
+// packB_dev[n*n + 3n + 2] = [S_part | rhs_part | diag(H_part) | g_c part | cost_part | 0]: Schur complement of the
+// owned landmarks with THEIR damping (diag_l / radius) plus this rank's camera blocks, no camera damping.
+// gmax_l_dev[1] = max |gradient| over the owned landmark columns (unscaled problem).
+extern "C" int vsl_ba_session_reduce_dev(vsl_ba_session* s, double radius, double* packB_dev, double* gmax_l_dev) {
+  if (!s || !packB_dev || !(radius > 0)) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  BaState& st = s->st;
+  const BaDims& D = st.D;
+  const int n = D.n;
+  hipLaunchKernelGGL(sess_diag_l_kernel, dim3((3 * D.L + 255) / 256), dim3(256), 0, ctx->stream, D.L, st.n2l.as<double>(),
+                     st.grad_l.as<double>(), st.scale_l.as<double>(), st.diag_l.as<double>(), st.gabs.as<double>());
+  if (gmax_l_dev) {
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), 3 * D.L, gmax_l_dev, 0, 1);
+  }
+  VSL_CHECK_LAUNCH(ctx);
+  // Schur with landmark damping only: reuse ba_schur with damping, but with a zero camera diagonal
+  VSL_HIP(ctx, hipMemsetAsync(st.diag_c.p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), ctx->stream));
+  int rc = ba_schur(ctx, st, true, radius, 0, D.L, true);
+  if (rc) return rc;
+  if (n > 0) {
+    VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(sess_pack_b_kernel, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, D.nfree, st.rhs.as<double>(),
+                       st.H.as<double>(), st.g_c.as<double>(), st.scalars.as<double>(), packB_dev + (size_t)n * n);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  return VSL_OK;
+}
+
+// From the all-reduced packB: damp the cameras, solve, back-substitute the owned landmarks, build the
+// candidate, and report packC_dev[8] (see sess_pack_c_kernel).  refresh_diag = 1 after an accepted step
+// (or at the first iteration), 0 when the Jacobian is unchanged (LM reuses its diagonal).
+extern "C" int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_full_dev, double radius, int refresh_diag,
+                                       double* packC_dev) {
+  if (!s || !packB_full_dev || !packC_dev || !(radius > 0)) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  BaState& st = s->st;
+  const BaDims& D = st.D;
+  const int n = D.n, nl = 3 * D.L;
+  if (n > 0) {
+    hipLaunchKernelGGL(sess_damp_kernel, dim3((n * n + 255) / 256), dim3(256), 0, ctx->stream, n, packB_full_dev, 1.0 / radius,
+                       refresh_diag, s->diagc_keep.as<double>(), st.S.as<double>(), st.rhs.as<double>());
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  bool ok = true;
+  int rc = ba_solve(ctx, st, ok);
+  if (rc) return rc;
+  const int okflag = ok ? 1 : 0;
+  VSL_HIP(ctx, hipMemcpyAsync(st.flag.p, &okflag, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ok) {
+    hipLaunchKernelGGL(ba_backsub_kernel, dim3((D.L + 255) / 256), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
+                       st.obs_cam.as<int>(), st.cam_free.as<int>(), st.F.as<double>(), st.E.as<double>(), st.Pinv.as<double>(),
+                       st.bl.as<double>(), st.dc.as<double>(), st.dl.as<double>());
+    if (n > 0) hipLaunchKernelGGL(ba_all_finite_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.dc.as<double>(), st.flag.as<int>());
+    hipLaunchKernelGGL(ba_all_finite_kernel, dim3((nl + 255) / 256), dim3(256), 0, ctx->stream, nl, st.dl.as<double>(), st.flag.as<int>());
+    hipLaunchKernelGGL(ba_model_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.obs_cam.as<int>(), st.obs_lm.as<int>(),
+                       st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(), st.dc.as<double>(),
+                       st.dl.as<double>(), st.partials.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs, st.scalars.as<double>(), 2, 0);
+    hipLaunchKernelGGL(ba_update_kernel, dim3(st.nb_upd), dim3(256), 0, ctx->stream, D, st.cam_free.as<int>(), st.poses.as<double>(),
+                       st.points.as<double>(), st.dc.as<double>(), st.dl.as<double>(), st.scale_c.as<double>(), st.scale_l.as<double>(),
+                       st.cand_poses.as<double>(), st.cand_points.as<double>(), st.partials.as<double>(), st.nb_upd);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_upd, st.scalars.as<double>(), 3, 0);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>() + st.nb_upd, st.nb_upd, st.scalars.as<double>(), 4, 0);
+    hipLaunchKernelGGL(sess_cam_norms_kernel, dim3(1), dim3(256), 0, ctx->stream, D, st.cam_free.as<int>(), st.poses.as<double>(),
+                       st.dc.as<double>(), st.scale_c.as<double>(), st.scalars.as<double>());
+    hipLaunchKernelGGL(ba_cost_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.cand_poses.as<double>(), st.cand_points.as<double>(),
+                       st.intr.as<double>(), st.cam_intr.as<int>(), st.obs_cam.as<int>(), st.obs_lm.as<int>(), st.obs_uv.as<double>(), 0,
+                       D.O, st.partials.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs, st.scalars.as<double>(), 5, 0);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  hipLaunchKernelGGL(sess_pack_c_kernel, dim3(1), dim3(64), 0, ctx->stream, st.scalars.as<double>(), st.flag.as<int>(), packC_dev);
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// The candidate becomes the current estimate.
+extern "C" int vsl_ba_session_accept(vsl_ba_session* s) {
+  if (!s) return VSL_ERR_INVALID;
+  std::swap(s->st.poses.p, s->st.cand_poses.p);
+  std::swap(s->st.points.p, s->st.cand_points.p);
+  return VSL_OK;
+}
+
+// poses[7 * n_cams] (all cameras) and points_own[3 * lm_count] (the owned range), host pointers.
+extern "C" int vsl_ba_session_download(vsl_ba_session* s, double* poses, double* points_own) {
+  if (!s) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  if (poses) VSL_HIP(ctx, hipMemcpyAsync(poses, s->st.poses.p, sizeof(double) * 7 * (size_t)s->st.D.C, hipMemcpyDeviceToHost, ctx->stream));
+  if (points_own) VSL_HIP(ctx, hipMemcpyAsync(points_own, s->st.points.p, sizeof(double) * 3 * (size_t)s->st.D.L, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VSL_OK;
+}
