@@ -20,6 +20,9 @@
 // Algorithmic bytes per pair: (n_a + n_b) * 32 B read + 8 B per match written.
 #include "vsl_common.h"
 
+#ifndef VSL_MATCH_WAVES
+#define VSL_MATCH_WAVES 8
+#endif
 #define KEY_SHIFT 23
 #define KEY_INIT ((256u << KEY_SHIFT) | 0u)
 
@@ -100,6 +103,148 @@ __global__ __launch_bounds__(64 * WAVES) void hamming_best2_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core variant.  popcount(a ^ b) = |a| + |b| - 2 <a, b> for bit vectors, and the inner products
+// of 32 "database" descriptors with 32 "query" descriptors are one 32x32 tile of an int8 GEMM with K =
+// 256 (bits expanded to 0/1 bytes): 8 x v_mfma_i32_32x32x32_i8, exact integer arithmetic.  v_bcnt_u32_b32
+// issues at a quarter of the VALU rate on gfx950 (the VALU kernel above measures 43 issue slots per
+// pair instead of 19), so the MFMA form is ~5x faster per distance -- this is not a GEMM dressed up for
+// the matrix cores' sake, the VALU popcount is simply the slow instruction here.
+//   * queries sit on the N side: a lane keeps the 32 x K fragment of ITS query in 32 VGPRs for the whole
+//     kernel and receives, per tile, the 16 distances of that query to 16 database rows in its
+//     accumulator registers -- so best / second-best are lane-local min / med3 updates on packed keys
+//     (no cross-lane reduction; the two lane halves of a column are merged once at the end);
+//   * database tiles (32 descriptors) are read packed (1 KiB), expanded to bytes by the workgroup
+//     (nibble * 0x00204081 & 0x01010101) into a double-buffered LDS tile shared by the 4 waves;
+//   * both directions of a pair are two independent grid slices (query / database roles swapped).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+#define MM_ROW 272  // LDS bytes per expanded descriptor: 256 + 16 pad (conflict-free ds_read_b128)
+
+__device__ __forceinline__ v4i_t expand16(uint32_t bits16) {
+  v4i_t o;
+  o.x = (int)((((bits16 >> 0) & 15u) * 0x00204081u) & 0x01010101u);
+  o.y = (int)((((bits16 >> 4) & 15u) * 0x00204081u) & 0x01010101u);
+  o.z = (int)((((bits16 >> 8) & 15u) * 0x00204081u) & 0x01010101u);
+  o.w = (int)((((bits16 >> 12) & 15u) * 0x00204081u) & 0x01010101u);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __restrict__ desc,
+                                                           const int32_t* __restrict__ kp_count,
+                                                           const int32_t* __restrict__ pair_slots,
+                                                           uint32_t* __restrict__ best_key,
+                                                           uint32_t* __restrict__ second_key, int F) {
+  // a "super tile" = 64 database descriptors = two MFMA tiles per workgroup barrier
+  __shared__ __align__(16) unsigned char tile[2][64 * MM_ROW];
+  __shared__ __align__(16) uint32_t rowkey[2][64];  // (|d_m| << KEY_SHIFT) | m, or KEY_INIT past the end
+  const int pair = blockIdx.z, dir = blockIdx.y;
+  const int slot_q = pair_slots[2 * pair + dir];      // queries (rows of the result)
+  const int slot_d = pair_slots[2 * pair + 1 - dir];  // database (columns of the reference's loop)
+  const int n_q = kp_count[slot_q], n_d = kp_count[slot_d];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= n_q) return;  // workgroup-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int qc = q0 + wave * 32 + c;
+  const uint32_t* __restrict__ qd = (const uint32_t*)(desc + ((size_t)slot_q * F + (qc < n_q ? qc : 0)) * 4);
+  const uint32_t* __restrict__ dbase = (const uint32_t*)(desc + (size_t)slot_d * F * 4);
+
+  // query fragment: bits expanded to bytes 0 / -2, so that the accumulator is -2 <a, b> directly
+  v4i_t bq[8];
+  int pq = 0;
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const uint32_t wq = qd[s];
+    pq += __builtin_popcount(wq);
+    const v4i_t e = expand16((wq >> (16 * h)) & 0xFFFFu);
+    // each byte 1 -> 0xFE (-2): bytes are 0/1, so the per-dword multiply has no carries between bytes
+    bq[s].x = (int)((uint32_t)e.x * 0xFEu);
+    bq[s].y = (int)((uint32_t)e.y * 0xFEu);
+    bq[s].z = (int)((uint32_t)e.z * 0xFEu);
+    bq[s].w = (int)((uint32_t)e.w * 0xFEu);
+  }
+  const uint32_t pq_key = (uint32_t)pq << KEY_SHIFT;
+
+  // tile fill: thread t expands words (t & 7) of database rows (t >> 3) and (t >> 3) + 32 of the super tile
+  const int frow = tid >> 3, fword = tid & 7;
+  auto load_words = [&](int st, uint32_t& w0, uint32_t& w1) {
+    const int r0 = st * 64 + frow, r1 = r0 + 32;
+    w0 = r0 < n_d ? dbase[(size_t)r0 * 8 + fword] : 0u;
+    w1 = r1 < n_d ? dbase[(size_t)r1 * 8 + fword] : 0u;
+  };
+  auto store_rows = [&](int buf, int st, uint32_t w0, uint32_t w1) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t wd = k ? w1 : w0;
+      const int lr = frow + 32 * k;
+      unsigned char* dst = &tile[buf][lr * MM_ROW + fword * 32];
+      *(v4i_t*)dst = expand16(wd & 0xFFFFu);
+      *(v4i_t*)(dst + 16) = expand16(wd >> 16);
+      int pc = __builtin_popcount(wd);
+      pc += __shfl_xor(pc, 1);
+      pc += __shfl_xor(pc, 2);
+      pc += __shfl_xor(pc, 4);
+      const int m = st * 64 + lr;
+      if (fword == 0) rowkey[buf][lr] = m < n_d ? (((uint32_t)pc << KEY_SHIFT) | (uint32_t)m) : KEY_INIT;
+    }
+  };
+  const int n_st = (n_d + 63) / 64;
+  uint32_t b = KEY_INIT, sk = KEY_INIT;
+  {
+    uint32_t w0, w1;
+    load_words(0, w0, w1);
+    store_rows(0, 0, w0, w1);
+    __syncthreads();
+  }
+  for (int st = 0; st < n_st; st++) {
+    const int buf = st & 1;
+    uint32_t n0 = 0, n1 = 0;
+    if (st + 1 < n_st) load_words(st + 1, n0, n1);
+    v16i_t acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v16i_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      const v4i_t a0 = *(const v4i_t*)&tile[buf][c * MM_ROW + s * 32 + h * 16];
+      const v4i_t a1 = *(const v4i_t*)&tile[buf][(c + 32) * MM_ROW + s * 32 + h * 16];
+      acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[s], acc1, 0, 0, 0);
+    }
+    // accumulator register g*4+j of lane (c, h) = -2 <database row 8g + 4h + j of the tile, query c>;
+    // key = ((|q| + |d_m| - 2<q, d_m>) << KEY_SHIFT) | m.  A padded row has rowkey = KEY_INIT and a zero
+    // accumulator; adding |q| << KEY_SHIFT to it can only make the key larger than every real key's
+    // distance field allows only if |q| = 0 -- so padded rows are clamped back to KEY_INIT.
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint4 rk = *(const uint4*)&rowkey[buf][32 * half + 8 * g + 4 * h];
+        const uint32_t rks[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int av = half ? acc1[4 * g + j] : acc0[4 * g + j];
+          uint32_t key = rks[j] + pq_key + ((uint32_t)av << KEY_SHIFT);
+          key = rks[j] == KEY_INIT ? KEY_INIT : key;
+          sk = umed3(b, key, sk);
+          b = min(b, key);
+        }
+      }
+    }
+    if (st + 1 < n_st) store_rows(buf ^ 1, st + 1, n0, n1);
+    __syncthreads();
+  }
+  // merge the two lane halves of a query column (disjoint database rows)
+  const uint32_t b2 = (uint32_t)__shfl_xor((int)b, 32), s2 = (uint32_t)__shfl_xor((int)sk, 32);
+  sk = min(umed3(b, b2, sk), s2);
+  b = min(b, b2);
+  if (h == 0 && qc < n_q) {
+    const size_t o = ((size_t)pair * 2 + dir) * F + qc;
+    best_key[o] = b;
+    second_key[o] = sk;
+  }
+}
+
 // Ratio test + cross-check + ordered emit.  One workgroup per pair.
 __global__ __launch_bounds__(1024) void match_finalize_kernel(
     const int32_t* __restrict__ kp_count, const int32_t* __restrict__ pair_slots,
@@ -158,14 +303,20 @@ __global__ __launch_bounds__(1024) void match_finalize_kernel(
 
 int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best) {
   if (n_pairs <= 0) return VSL_OK;
-  constexpr int WAVES = 8;
+  constexpr int WAVES = VSL_MATCH_WAVES;
   {
     VslStage st(ctx, VSL_STAGE_MATCH);
     // (a row-split variant -- waves share the column stream, no merge -- was measured slower: 0.288 vs
     // 0.255 ms per 128 pairs; the column split keeps more, shorter waves in flight)
-    dim3 grid((f->F + 63) / 64, 2, n_pairs);
-    hipLaunchKernelGGL(hamming_best2_kernel<WAVES>, grid, dim3(64 * WAVES), 0, ctx->stream, f->kp_desc,
-                       f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
+    if (ctx->match_use_valu) {
+      dim3 grid((f->F + 63) / 64, 2, n_pairs);
+      hipLaunchKernelGGL(hamming_best2_kernel<WAVES>, grid, dim3(64 * WAVES), 0, ctx->stream, f->kp_desc,
+                         f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
+    } else {
+      dim3 grid((f->F + 127) / 128, 2, n_pairs);
+      hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(256), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
+                         f->best_key, f->second_key, f->F);
+    }
     VSL_CHECK_LAUNCH(ctx);
   }
   {

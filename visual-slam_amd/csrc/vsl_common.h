@@ -42,6 +42,7 @@ struct vsl_ctx {
   size_t hpinned_cap = 0;
   bool select_attr_set = false;
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
+  bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
 };
 
