@@ -27,8 +27,8 @@ struct RowF {
 
 __device__ __forceinline__ RowF rowfilt(const uint8_t* __restrict__ img, int w, int yr, int xm, int xe, int xp,
                                         float s, float s2) {
-  const uint8_t* row = img + yr * w;
-  const float l = (float)row[xm], m = (float)row[xe], r = (float)row[xp];
+  const int off = yr * w;  // 32-bit offsets from the (wave-uniform) image base: saddr + voffset loads
+  const float l = (float)img[off + xm], m = (float)img[off + xe], r = (float)img[off + xp];
   RowF o;
   o.rx = r - l;
   float t = s * l;
@@ -45,6 +45,14 @@ __device__ __forceinline__ float from_lane_below(float v) {  // lane i <- lane i
 }
 __device__ __forceinline__ float from_lane_above(float v) {  // lane i <- lane i+1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// one-instruction maximum of three finite floats (fmaxf chains compile to v_max_f32 pairs with
+// canonicalisation; the responses here are never NaN)
+__device__ __forceinline__ float fmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
@@ -95,15 +103,21 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const int xm = reflect101(xe - 1, w), xp = reflect101(xe + 1, w);
     const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
 
-    double Rxx[3] = {0, 0, 0}, Rxy[3] = {0, 0, 0}, Ryy[3] = {0, 0, 0};  // row sums of rows q-2, q-1, q
-    float v_up = 0.f, v_mid = 0.f;                                       // response rows q-3, q-2
-    float l_up = 0.f, r_up = 0.f, l_mid = 0.f, r_mid = 0.f;              // their column neighbours
-    RowF f0, f1, f2;                                                      // row filters of rows ye-1, ye, ye+1
+    // Three generations of row sums / response rows live in registers; the row loop is unrolled by
+    // three with the roles rotated by NAME (no register-to-register moves).
+    struct Gen {
+      double xx, xy, yy;  // fp64 row sums R(x, q)
+      float v, l, r;      // response row and its left / right neighbours
+    };
+    Gen g0 = {0, 0, 0, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
+    RowF f0, f1, f2;  // row filters of rows ye-1, ye, ye+1
     int prev_ye = -100;
-    float vmax = -INFINITY;
+    float vmax = -3.0e38f;
     const int y_end = min(h, y0 + K1_ROWS);
-    // q = row whose row sums are produced; response row q-1 is complete after it; candidate row q-2
-    for (int q = y0 - 2; q <= y_end + 1; q++) {
+    // one step: q = row whose row sums are produced into `cur`; `pm1`/`pm2` hold rows q-1 / q-2.
+    // Afterwards cur.v is the response of row q-1, and the candidate row is q-2 (rows q-3, q-2, q-1 =
+    // pm2.v (old), pm1.v (old), cur.v) -- the response slots lag the row-sum slots by one row.
+    auto step = [&](int q, Gen& pm2, Gen& pm1, Gen& cur) {
       const int ye = reflect101(min(max(q, -1), h), h);
       if (ye == prev_ye + 1 && ye + 1 < h) {
         f0 = f1;
@@ -120,17 +134,17 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
       const float lxx = from_lane_below(cxx), lxy = from_lane_below(cxy), lyy = from_lane_below(cyy);
       const float rxx = from_lane_above(cxx), rxy = from_lane_above(cxy), ryy = from_lane_above(cyy);
-      Rxx[0] = Rxx[1]; Rxx[1] = Rxx[2];
-      Rxy[0] = Rxy[1]; Rxy[1] = Rxy[2];
-      Ryy[0] = Ryy[1]; Ryy[1] = Ryy[2];
-      Rxx[2] = ((double)lxx + (double)cxx) + (double)rxx;
-      Rxy[2] = ((double)lxy + (double)cxy) + (double)rxy;
-      Ryy[2] = ((double)lyy + (double)cyy) + (double)ryy;
-      // response of row y = q - 1 (valid once three row sums exist)
+      // response rows of the two previous steps, read before `cur` (= the slot of row q-3) is overwritten
+      const float v_up = pm2.v, l_up = pm2.l, r_up = pm2.r;    // response row q-3
+      const float v_mid = pm1.v, l_mid = pm1.l, r_mid = pm1.r;  // response row q-2
+      cur.xx = ((double)lxx + (double)cxx) + (double)rxx;
+      cur.xy = ((double)lxy + (double)cxy) + (double)rxy;
+      cur.yy = ((double)lyy + (double)cyy) + (double)ryy;
+      // response of row y = q - 1 from the row sums of rows q-2, q-1, q
       const int y = q - 1;
-      const double Axx = (Rxx[0] + Rxx[1]) + Rxx[2];
-      const double Axy = (Rxy[0] + Rxy[1]) + Rxy[2];
-      const double Ayy = (Ryy[0] + Ryy[1]) + Ryy[2];
+      const double Axx = (pm2.xx + pm1.xx) + cur.xx;
+      const double Axy = (pm2.xy + pm1.xy) + cur.xy;
+      const double Ayy = (pm2.yy + pm1.yy) + cur.yy;
       const float a = (float)Axx * 0.5f, b = (float)Axy, c = (float)Ayy * 0.5f;
       const float d = a - c;
       float t = d * d;
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn)
       const int yc = q - 2;
       if (own_col && yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1 && x >= 1 && x < w - 1 && v_mid > 0.f) {
-        const float m8 = fmaxf(fmaxf(fmaxf(l_up, v_up), fmaxf(r_up, l_mid)), fmaxf(fmaxf(r_mid, l_dn), fmaxf(v_dn, r_dn)));
+        const float m8 = fmax3(fmax3(l_up, v_up, r_up), fmax3(l_mid, r_mid, l_dn), fmaxf(v_dn, r_dn));
         if (!(m8 > v_mid)) {
           const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
           const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
@@ -159,8 +173,20 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
           }
         }
       }
-      v_up = v_mid; l_up = l_mid; r_up = r_mid;
-      v_mid = v_dn; l_mid = l_dn; r_mid = r_dn;
+      // the response of row q-1 is stored in the slot of the row sums of row q-1 (pm1) for the next steps
+      // -- but pm1.v currently holds response row q-2, still needed as "v_up" next step; so the response
+      // rows are kept in the slot that is overwritten last: cur (row sums of q) receives response q-1.
+      cur.v = v_dn;
+      cur.l = l_dn;
+      cur.r = r_dn;
+    };
+    // response slots: after a step, cur.v = resp(q-1); at the next step (q+1) that slot is "pm1" and is
+    // read as v_mid = resp(q-1) = resp((q+1)-2) -- consistent with the reads above.
+    const int q_first = y0 - 2, q_last = y_end + 1;
+    for (int q = q_first; q <= q_last; q += 3) {
+      step(q, g0, g1, g2);
+      step(q + 1, g1, g2, g0);
+      step(q + 2, g2, g0, g1);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
