@@ -39,14 +39,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achiev
 def stage_algorithmic_bytes(stage, n_img, n_pairs, kp_total, cand_total, match_total):
     """Compulsory bytes of one launch of a stage over the whole batch (DESIGN.md 'Kernels')."""
     px = W * H
-    if stage == "response":      # K1 + K2a: image in, fp32 response out and back in, candidate keys out
-        return n_img * (px + 4 * px + 4 * px) + 8 * cand_total
+    if stage == "response":      # K1+K2a fused: image in, provisional candidate keys out (no response image)
+        return n_img * px + 8 * cand_total
     if stage == "select":        # K2b: candidate keys in, selected corners out
         return 8 * cand_total + 8 * kp_total
     if stage == "describe":      # K3+K4: 709-px disc + position in, moments/angle/descriptor out
         return kp_total * (709 + 8 + 8 + 8 + 32)
-    if stage == "match":         # K5: both descriptor sets in, best/second keys out (both directions)
-        return kp_total * 32 + kp_total * 8
+    if stage == "match":         # K5: both descriptor sets in (per direction), best/second keys out
+        return 2 * kp_total * 32 + kp_total * 8
     if stage == "match_finalize":
         return kp_total * 8 + match_total * 8
     return 0
@@ -141,8 +141,17 @@ def main():
         out["config"]["mean_candidates_per_image"] = round(cand_total / n_img, 1)
         ab = stage_algorithmic_bytes(dom, n_img, B, kp_total, cand_total, match_total)
         achieved = ab / (stages[dom] * 1e-3) / 1e9
+        # HBM traffic of that stage per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+        # uncorrected -- see profiles/r01_pmc_traffic.json); only valid for the batch size it was taken at
+        traffic = None
+        try:
+            pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            if pm.get("batch_stereo_frames") == B and dom in pm["kernels"]:
+                traffic = pm["kernels"][dom]["bytes_per_launch_uncorrected"]
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(ab),
                            "avg_launch_ms": round(stages[dom], 5)}
         out["stage_ms_per_step"] = {k: round(v, 5) for k, v in stages.items()}
