@@ -104,9 +104,18 @@ using Landmarks = std::unordered_map<TrackId, Landmark>;
 struct AbstractCameraD {
   std::string model;  // "ds" | "pinhole" | "eucm" | "kb4"
   double param[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int width_ = 0, height_ = 0;
   std::string name() const { return model; }
   double* data() { return param; }
   const double* data() const { return param; }
+  int width() const { return width_; }
+  int height() const { return height_; }
+};
+// include/visnav/common_types.h:150-160
+struct LandmarkMatchData {
+  Sophus::SE3d T_w_c;
+  std::vector<std::pair<FeatureId, TrackId>> matches;
+  std::vector<std::pair<FeatureId, TrackId>> inliers;
 };
 struct Calibration {
   std::vector<Sophus::SE3d> T_i_c;

@@ -132,6 +132,25 @@ int vsl_min_eig_response(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t 
 int vsl_match_descriptors(vsl_ctx* ctx, const uint64_t* d1, int n1, const uint64_t* d2, int n2,
                           int threshold, double dist_2_best, int32_t* pairs, int* n_out);
 
+/* --------------------------- per-frame landmark projection / guided matching */
+/* (the "next" callers of the matcher, run on every frame)
+ * Replaces visnav::project_landmarks (include/visnav/vo_utils.h:48-81): p_c = T_w_c^-1 * p; kept iff
+ * p_c.z >= cam_z_threshold and the projection lies in [0, width] x [0, height].  Landmarks are visited
+ * in the given order; proj_idx[i] = index into `points` of the i-th kept landmark (capacity n). */
+int vsl_project_landmarks(vsl_ctx* ctx, const double* pose7, int cam_model, const double* intr8,
+                          int width, int height, const double* points, int n,
+                          double cam_z_threshold, double* proj_uv, int32_t* proj_idx, int* n_out);
+/* Replaces visnav::find_matches_landmarks (include/visnav/vo_utils.h:83-167): for every keypoint, the
+ * projected landmarks within match_max_dist_2d; landmark distance = min Hamming distance to the
+ * landmark's observation descriptors obs_desc[lm_obs_start[l] .. lm_obs_start[l+1]); best / second by
+ * std::partial_sort semantics; threshold and ratio tests.  pairs: (keypoint, landmark index) in keypoint
+ * order, capacity 2*n_kp. */
+int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, const uint64_t* kp_desc, int n_kp,
+                               const double* proj_uv, const int32_t* proj_lm, int n_proj,
+                               const int32_t* lm_obs_start, int n_lms, const uint64_t* obs_desc,
+                               double match_max_dist_2d, int feature_match_threshold,
+                               double feature_match_dist_2_best, int32_t* pairs, int* n_out);
+
 /* ------------------------------------- device-resident batched frame store */
 /*
  * The throughput path: B images live in HBM; detect/describe runs over a range

@@ -24,7 +24,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force=False):
     so = _DIR / "libvslam_oracle.so"
-    srcs = [_DIR / n for n in ("orc_keypoints.cpp", "orc_bow.cpp", "orc_ba.cpp", "vslam_oracle.h",
+    srcs = [_DIR / n for n in ("orc_keypoints.cpp", "orc_bow.cpp", "orc_ba.cpp", "orc_vo.cpp", "vslam_oracle.h",
                                "rbrief_pattern.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_DIR)], check=True, capture_output=True)
@@ -162,6 +162,36 @@ def bytes_to_bitset(b):
     for i in range(len(b)):
         lib().orc_bytes_to_bitset(b[i].ctypes.data_as(u8p), out[i].ctypes.data_as(u64p))
     return out
+
+
+def project_landmarks(pose7, model, intr8, width, height, points, cam_z_threshold=0.1):
+    pose7 = np.ascontiguousarray(pose7, np.float64)
+    intr8 = np.ascontiguousarray(intr8, np.float64)
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    n = len(points)
+    uv = np.zeros((max(n, 1), 2), np.float64)
+    idx = np.zeros(max(n, 1), np.int32)
+    m = lib().orc_project_landmarks(pose7.ctypes.data_as(f64p), int(model), intr8.ctypes.data_as(f64p), int(width),
+                                    int(height), points.ctypes.data_as(f64p), n, C.c_double(cam_z_threshold),
+                                    uv.ctypes.data_as(f64p), idx.ctypes.data_as(i32p))
+    return uv[:m].copy(), idx[:m].copy()
+
+
+def find_matches_landmarks(kp_xy, kp_desc, proj_uv, proj_lm, lm_obs_start, obs_desc, max_dist_2d=20.0, threshold=70,
+                           dist_2_best=1.2):
+    kp_xy = np.ascontiguousarray(kp_xy, np.float64).reshape(-1, 2)
+    kp_desc = np.ascontiguousarray(kp_desc, np.uint64).reshape(-1, 4)
+    proj_uv = np.ascontiguousarray(proj_uv, np.float64).reshape(-1, 2)
+    proj_lm = np.ascontiguousarray(proj_lm, np.int32)
+    lm_obs_start = np.ascontiguousarray(lm_obs_start, np.int32)
+    obs_desc = np.ascontiguousarray(obs_desc, np.uint64).reshape(-1, 4)
+    pairs = np.zeros((max(len(kp_xy), 1), 2), np.int32)
+    n = lib().orc_find_matches_landmarks(kp_xy.ctypes.data_as(f64p), kp_desc.ctypes.data_as(u64p), len(kp_xy),
+                                         proj_uv.ctypes.data_as(f64p), proj_lm.ctypes.data_as(i32p), len(proj_uv),
+                                         lm_obs_start.ctypes.data_as(i32p), obs_desc.ctypes.data_as(u64p),
+                                         C.c_double(max_dist_2d), int(threshold), C.c_double(dist_2_best),
+                                         pairs.ctypes.data_as(i32p))
+    return pairs[:n].copy()
 
 
 class Vocabulary:

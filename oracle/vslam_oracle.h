@@ -61,6 +61,16 @@ int orc_match_descriptors(const uint64_t* d1, int n1, const uint64_t* d2, int n2
 void orc_bitset_to_bytes(const uint64_t* desc, uint8_t* out32);
 void orc_bytes_to_bitset(const uint8_t* in32, uint64_t* desc);
 
+/* ---- vo_utils.h (per-frame landmark projection / guided matching) ------------ */
+/* vo_utils.h:48-81; landmarks visited in the given order; returns #projected */
+int orc_project_landmarks(const double* pose7, int model, const double* intr8, int width, int height,
+                          const double* points, int n, double cam_z_threshold, double* proj_uv, int32_t* proj_idx);
+/* vo_utils.h:83-167 (std::partial_sort kept literally); pairs capacity 2*n_kp; returns #matches */
+int orc_find_matches_landmarks(const double* kp_xy, const uint64_t* kp_desc, int n_kp, const double* proj_uv,
+                               const int32_t* proj_lm, int n_proj, const int32_t* lm_obs_start, const uint64_t* obs_desc,
+                               double match_max_dist_2d, int feature_match_threshold, double feature_match_dist_2_best,
+                               int32_t* pairs);
+
 /* ---- DBoW2 ---------------------------------------------------------------- */
 typedef struct orc_voc orc_voc;
 orc_voc* orc_voc_load_text(const char* path); /* TemplatedVocabulary.h:1338-1424 */

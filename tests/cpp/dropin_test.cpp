@@ -11,6 +11,7 @@
 #include "visnav_amd/bow.h"
 #include "visnav_amd/bundle_adjustment.h"
 #include "visnav_amd/keypoints.h"
+#include "visnav_amd/vo_utils.h"
 
 using namespace visnav;
 
@@ -86,6 +87,23 @@ int main(int argc, char** argv) {
   voc.transform(kdr.corner_descriptors, br, fr, 4);
   const double s_lr = voc.score(bl, br), s_ll = voc.score(bl, bl);
 
+  // ---- per-frame guided matching (src/slam.cpp:1099-1114, :1159): landmarks = the BA map, every
+  // observation carries the left image's descriptor of the same feature index modulo the count
+  for (auto& kv : landmarks) kv.second.all_obs = kv.second.obs;
+  for (auto& kv : corners) {
+    auto& kd = kv.second;
+    kd.corner_descriptors.resize(kd.corners.size());
+    for (size_t i = 0; i < kd.corners.size(); i++) kd.corner_descriptors[i] = kdl.corner_descriptors[i % kdl.corner_descriptors.size()];
+  }
+  auto cam = std::make_shared<AbstractCameraD>(*calib.intrinsics[0]);
+  cam->width_ = w;
+  cam->height_ = h;
+  std::vector<Eigen::Vector2d, Eigen::aligned_allocator<Eigen::Vector2d>> projected_points;
+  std::vector<TrackId> projected_track_ids;
+  project_landmarks(cameras.begin()->second.T_w_c, cam, landmarks, 0.1, projected_points, projected_track_ids);
+  LandmarkMatchData md;
+  find_matches_landmarks(kdl, landmarks, corners, projected_points, projected_track_ids, 20.0, 70, 1.2, md);
+
   std::ofstream out(argv[7], std::ios::binary);
   int32_t n;
   n = (int32_t)kdl.corners.size(); put(out, &n, 1);
@@ -103,5 +121,9 @@ int main(int argc, char** argv) {
   n = (int32_t)bl.size(); put(out, &n, 1);
   for (auto& kv : bl) { uint32_t id = kv.first; put(out, &id, 1); put(out, &kv.second, 1); }
   put(out, &s_lr, 1); put(out, &s_ll, 1);
+  n = (int32_t)projected_track_ids.size(); put(out, &n, 1);
+  for (int i = 0; i < n; i++) { int64_t id = projected_track_ids[i]; put(out, &id, 1); put(out, projected_points[i].data(), 2); }
+  n = (int32_t)md.matches.size(); put(out, &n, 1);
+  for (auto& mm : md.matches) { int64_t p[2] = {mm.first, mm.second}; put(out, p, 2); }
   return 0;
 }

@@ -61,6 +61,8 @@ def test_dropin_matches_oracle(tmp_path, orc, synth):
         assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
         assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
         descs.append(desc)
+        if len(descs) == 1:
+            oxy_left = oxy
     n = int(take(np.int32, 1)[0])
     m = take(np.int32, 2 * n).reshape(n, 2)
     assert np.array_equal(m, orc.match_descriptors(descs[0], descs[1], 70, 1.2))
@@ -91,3 +93,33 @@ def test_dropin_matches_oracle(tmp_path, orc, synth):
     ri, rv, _, _ = voc.transform(orc.bitset_to_bytes(descs[1]), 4)
     assert np.array_equal(rec["id"], oi) and np.array_equal(rec["v"].view(np.uint64), ov.view(np.uint64))
     assert s_lr == orc.bow_score_l1(oi, ov, ri, rv) and s_ll == orc.bow_score_l1(oi, ov, oi, ov)
+    # project_landmarks + find_matches_landmarks on the optimised map (unordered_map order = the order the
+    # wrapper passed; recover it from the returned track ids)
+    n = int(take(np.int32, 1)[0])
+    rec = np.frombuffer(buf, np.dtype([("id", np.int64), ("uv", np.float64, 2)]), n, off)
+    off += rec.nbytes
+    pose0 = poses[0]
+    euv, eidx = orc.project_landmarks(pose0, 0, d["intr"][0], 752, 480, points, 0.1)
+    assert sorted(rec["id"].tolist()) == sorted(eidx.tolist()) and n > 50
+    by_id = {int(i): u for i, u in zip(eidx, euv)}
+    assert all(np.array_equal(rec["uv"][k], by_id[int(rec["id"][k])]) for k in range(n))
+    nm = int(take(np.int32, 1)[0])
+    mm = take(np.int64, 2 * nm).reshape(nm, 2)
+    # oracle on the same projected order: landmark l's observations carry descriptors desc_left[f % n_left]
+    obs_lm, obs_cam = d["obs_lm"], d["obs_cam"]
+    fid = np.zeros(len(obs_lm), np.int64)
+    counter = {}
+    for i, c in enumerate(obs_cam):
+        fid[i] = counter.get(int(c), 0)
+        counter[int(c)] = fid[i] + 1
+    nl = len(descs[0])
+    order = [int(t) for t in rec["id"]]
+    start, obs = [0], []
+    for t in order:
+        sel = np.nonzero(obs_lm == t)[0]
+        sel = sel[np.argsort(obs_cam[sel], kind="stable")]  # FeatureTrack is a std::map ordered by FrameCamId
+        obs.extend(descs[0][fid[i] % nl] for i in sel)
+        start.append(len(obs))
+    exp = orc.find_matches_landmarks(oxy_left, descs[0], rec["uv"], np.arange(n, dtype=np.int32), np.array(start, np.int32),
+                                     np.array(obs, np.uint64).reshape(-1, 4), 20.0, 70, 1.2)
+    assert [[int(a), order[int(b)]] for a, b in exp] == mm.tolist()

@@ -1,0 +1,98 @@
+"""GPU parity: project_landmarks / find_matches_landmarks (visual-slam_amd/csrc/vo.hip) vs the oracle.
+fp64 projection in the oracle's operation order: bit-exact for ds / pinhole / eucm (kb4 goes through
+atan2: device and glibc differ in the last bits -> same kept set, 1e-12 px); matches: identical pairs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INTR = {0: [351.0, 350.0, 365.9, 249.3, -0.2385, 0.5679, 0, 0], 1: [351.0, 350.0, 365.9, 249.3, 0, 0, 0, 0],
+        2: [351.0, 350.0, 365.9, 249.3, 0.6, 1.1, 0, 0], 3: [351.0, 350.0, 365.9, 249.3, 0.01, -0.004, 0.002, -0.0005]}
+
+
+def _scene(synth, seed, n_lms=3000):
+    rng = np.random.default_rng(seed)
+    pose = np.concatenate([synth.axis_angle_q(rng.normal(size=3), 0.3), rng.normal(0, 0.5, 3)])
+    R = synth.quat_R(pose[:4])
+    pc = np.stack([rng.uniform(-8, 8, n_lms), rng.uniform(-5, 5, n_lms), rng.uniform(-2, 12, n_lms)], -1)
+    pw = pc @ R.T + pose[4:]
+    return pose, pw
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+def test_project_landmarks(ctx, orc, synth, model):
+    pose, pw = _scene(synth, model)
+    uv, idx = ctx.project_landmarks(pose, model, INTR[model], 752, 480, pw, 0.1)
+    euv, eidx = orc.project_landmarks(pose, model, INTR[model], 752, 480, pw, 0.1)
+    assert np.array_equal(idx, eidx) and 200 < len(idx) < len(pw)
+    if model == 3:
+        assert np.allclose(uv, euv, rtol=0, atol=1e-12)
+    else:
+        assert np.array_equal(uv.view(np.uint64), euv.view(np.uint64))
+
+
+def test_project_landmarks_edges(ctx, orc):
+    ident = [0, 0, 0, 1, 0, 0, 0]
+    pin = [100.0, 100.0, 50.0, 40.0, 0, 0, 0, 0]
+    pts = np.array([[0, 0, 1.0], [0, 0, 0.05], [0.5, 0, 1.0], [0.51, 0, 1.0], [-0.51, 0, 1.0], [0, 0.4, 1.0], [0, 0, -1.0]])
+    uv, idx = ctx.project_landmarks(ident, 1, pin, 100, 80, pts, 0.1)
+    assert idx.tolist() == [0, 2, 5] and uv.tolist() == [[50.0, 40.0], [100.0, 40.0], [50.0, 80.0]]
+    uv, idx = ctx.project_landmarks(ident, 1, pin, 100, 80, np.zeros((0, 3)), 0.1)
+    assert len(idx) == 0
+
+
+def _match_case(synth, seed, n_kp, n_lms, max_obs, planted=0.6):
+    rng = np.random.default_rng(seed)
+    kp_xy = np.stack([rng.integers(19, 733, n_kp), rng.integers(19, 461, n_kp)], -1).astype(np.float64)
+    kp_desc = synth.random_descriptors(rng, n_kp)
+    n_obs = rng.integers(0, max_obs + 1, n_lms)
+    start = np.concatenate([[0], np.cumsum(n_obs)]).astype(np.int32)
+    obs = synth.random_descriptors(rng, int(start[-1]))
+    proj_uv = np.stack([rng.uniform(0, 752, n_lms), rng.uniform(0, 480, n_lms)], -1)
+    # plant: landmark l projects near keypoint k and one of its observations is a noisy copy of k's descriptor
+    for l in range(n_lms):
+        if n_obs[l] and rng.random() < planted:
+            k = int(rng.integers(n_kp))
+            proj_uv[l] = kp_xy[k] + rng.uniform(-12, 12, 2)
+            o = int(start[l] + rng.integers(n_obs[l]))
+            obs[o] = synth.flip_bits(rng, kp_desc[k:k + 1], int(rng.choice([0, 0, 3, 20, 50, 69, 70, 75])))[0]
+    proj_lm = rng.permutation(n_lms).astype(np.int32)  # projected order != landmark order
+    return kp_xy, kp_desc, proj_uv[proj_lm], proj_lm, start, obs
+
+
+@pytest.mark.parametrize("seed,n_kp,n_lms,max_obs", [(1, 1, 1, 3), (2, 1300, 2500, 20), (3, 257, 4000, 70), (4, 1500, 63, 5),
+                                                      (5, 64, 300, 200)])
+def test_find_matches_landmarks(ctx, orc, synth, seed, n_kp, n_lms, max_obs):
+    c = _match_case(synth, seed, n_kp, n_lms, max_obs)
+    got = ctx.find_matches_landmarks(*c, 20.0, 70, 1.2)
+    exp = orc.find_matches_landmarks(*c, 20.0, 70, 1.2)
+    assert np.array_equal(got, exp)
+    if n_kp > 100 and n_lms > 1000:
+        assert len(got) > 50
+    for r, t, q in ((5.0, 70, 1.2), (40.0, 100, 1.0), (20.0, 1, 3.0)):
+        assert np.array_equal(ctx.find_matches_landmarks(*c, r, t, q), orc.find_matches_landmarks(*c, r, t, q))
+
+
+def test_find_matches_tie_semantics(ctx, orc):
+    # the partial_sort tie cases of tests/test_oracle_vo.py, through the kernel's state machine
+    z = np.zeros(4, np.uint64)
+
+    def d(n):
+        o = np.zeros(4, np.uint64)
+        for b in range(n):
+            o[b // 64] |= np.uint64(1) << np.uint64(b % 64)
+        return o
+
+    for dists in ([0, 0], [0, 7, 0], [7, 0, 0], [0, 0, 0], [5, 0, 9, 0, 3], [3, 3], [4, 2, 2, 9, 2], [9, 8, 7, 6, 5, 5, 6, 5]):
+        proj = [[100.0 + 0.1 * i, 100.0] for i in range(len(dists))]
+        start = np.arange(len(dists) + 1, dtype=np.int32)
+        obs = np.stack([d(v) for v in dists])
+        args = ([[100.0, 100.0]], [z], proj, np.arange(len(dists), dtype=np.int32), start, obs, 20.0, 70, 1.0)
+        assert np.array_equal(ctx.find_matches_landmarks(*args), orc.find_matches_landmarks(*args)), dists
+
+
+def test_find_matches_empty(ctx):
+    z = np.zeros((0, 4), np.uint64)
+    assert len(ctx.find_matches_landmarks(np.zeros((0, 2)), z, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(1, np.int32), z)) == 0
+    assert len(ctx.find_matches_landmarks([[50.0, 50.0]], np.zeros((1, 4), np.uint64), np.zeros((0, 2)), np.zeros(0, np.int32),
+                                          np.zeros(1, np.int32), z)) == 0

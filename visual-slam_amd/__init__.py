@@ -199,6 +199,40 @@ class Context:
                                               C.byref(n)))
         return pairs[:n.value].copy()
 
+    # ---- vo_utils.h drop-ins
+    def project_landmarks(self, pose7, model, intr8, width, height, points, cam_z_threshold=0.1):
+        pose7 = np.ascontiguousarray(pose7, np.float64)
+        intr8 = np.ascontiguousarray(intr8, np.float64)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        n = len(points)
+        uv = np.zeros((max(n, 1), 2), np.float64)
+        idx = np.zeros(max(n, 1), np.int32)
+        m = C.c_int32()
+        self._ck(self.L.vsl_project_landmarks(self.h, pose7.ctypes.data_as(f64p), int(model), intr8.ctypes.data_as(f64p),
+                                              int(width), int(height), points.ctypes.data_as(f64p), n,
+                                              C.c_double(cam_z_threshold), uv.ctypes.data_as(f64p),
+                                              idx.ctypes.data_as(i32p), C.byref(m)))
+        return uv[:m.value].copy(), idx[:m.value].copy()
+
+    def find_matches_landmarks(self, kp_xy, kp_desc, proj_uv, proj_lm, lm_obs_start, obs_desc, max_dist_2d=20.0,
+                               threshold=70, dist_2_best=1.2):
+        kp_xy = np.ascontiguousarray(kp_xy, np.float64).reshape(-1, 2)
+        kp_desc = np.ascontiguousarray(kp_desc, np.uint64).reshape(-1, 4)
+        proj_uv = np.ascontiguousarray(proj_uv, np.float64).reshape(-1, 2)
+        proj_lm = np.ascontiguousarray(proj_lm, np.int32)
+        lm_obs_start = np.ascontiguousarray(lm_obs_start, np.int32)
+        obs_desc = np.ascontiguousarray(obs_desc, np.uint64).reshape(-1, 4)
+        pairs = np.zeros((max(len(kp_xy), 1), 2), np.int32)
+        m = C.c_int32()
+        self._ck(self.L.vsl_find_matches_landmarks(self.h, kp_xy.ctypes.data_as(f64p), kp_desc.ctypes.data_as(u64p),
+                                                   len(kp_xy), proj_uv.ctypes.data_as(f64p),
+                                                   proj_lm.ctypes.data_as(i32p), len(proj_uv),
+                                                   lm_obs_start.ctypes.data_as(i32p), len(lm_obs_start) - 1,
+                                                   obs_desc.ctypes.data_as(u64p), C.c_double(max_dist_2d),
+                                                   int(threshold), C.c_double(dist_2_best),
+                                                   pairs.ctypes.data_as(i32p), C.byref(m)))
+        return pairs[:m.value].copy()
+
     # ---- bundle adjustment
     def _ba_struct(self, arr):
         st = BaProblem()

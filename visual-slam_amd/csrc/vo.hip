@@ -1,0 +1,322 @@
+// vo.hip -- per-frame landmark projection and guided descriptor matching.
+//
+// Replaces visnav::project_landmarks (include/visnav/vo_utils.h:48-81) and
+// visnav::find_matches_landmarks (include/visnav/vo_utils.h:83-167), which src/slam.cpp runs on EVERY
+// frame (:1099-1114, :1159, :1339).
+//
+//  * projection: one thread per landmark, fp64 in the oracle's operation order (no FMA), then an
+//    order-preserving compaction -- the output order is the caller's landmark order (the reference
+//    iterates its unordered_map);
+//  * matching: one wavefront per keypoint.  Lanes test 64 projected points at a time against the 2-D
+//    radius (double, sqrt(dx*dx + dy*dy) < r like Eigen's norm()); for every hit, in order, the lanes
+//    stride the landmark's observation descriptors and a wave-wide minimum gives the landmark
+//    distance.  The reference then calls std::partial_sort(first, first + 2, last) on the (landmark,
+//    distance) list; which of two EQUALLY distant landmarks comes first is libstdc++'s heap-select
+//    behaviour, reproduced here as the equivalent streaming state machine over the list:
+//        first two:   top = (d1 < d0) ? e0 : e1,  other = the other one
+//        each later e with d(e) < d(top):   (top, other) = d(other) < d(e) ? (e, other) : (other, e)
+//        result[0] = other, result[1] = top
+//    so ties are broken exactly like the reference (pinned against the oracle, which calls the real
+//    std::partial_sort).
+#include <cmath>
+
+#include "vsl_common.h"
+
+namespace {
+
+__device__ __forceinline__ void quat_rotate_d(const double* q, const double* p, double* out) {
+  double uv[3] = {q[1] * p[2] - q[2] * p[1], q[2] * p[0] - q[0] * p[2], q[0] * p[1] - q[1] * p[0]};
+  for (int i = 0; i < 3; i++) uv[i] = uv[i] + uv[i];
+  const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int i = 0; i < 3; i++) out[i] = p[i] + q[3] * uv[i] + c[i];
+}
+
+// camera_models.h project(), expression for expression (include/visnav/camera_models.h:75-94, :158-178,
+// :246-270, :341-374)
+__device__ __forceinline__ void project_exact(int model, const double* ip, double x, double y, double z, double& u,
+                                              double& v) {
+  const double fx = ip[0], fy = ip[1], cx = ip[2], cy = ip[3];
+  if (model == VSL_CAM_PINHOLE) {
+    u = fx * x / z + cx;
+    v = fy * y / z + cy;
+  } else if (model == VSL_CAM_EUCM) {
+    const double alpha = ip[4], beta = ip[5];
+    const double d = sqrt(beta * (x * x + y * y) + z * z);
+    u = fx * x / (alpha * d + (1.0 - alpha) * z) + cx;
+    v = fy * y / (alpha * d + (1.0 - alpha) * z) + cy;
+  } else if (model == VSL_CAM_KB4) {
+    const double k1 = ip[4], k2 = ip[5], k3 = ip[6], k4 = ip[7];
+    const double r = sqrt(x * x + y * y);
+    const double theta = atan2(r, z);
+    const double d = theta + k1 * theta * theta * theta + k2 * theta * theta * theta * theta * theta +
+                     k3 * theta * theta * theta * theta * theta * theta * theta +
+                     k4 * theta * theta * theta * theta * theta * theta * theta * theta * theta;
+    if (r == 0.0) {
+      u = cx;
+      v = cy;
+    } else {
+      u = fx * d * x / r + cx;
+      v = fy * d * y / r + cy;
+    }
+  } else {
+    const double xi = ip[4], alpha = ip[5];
+    const double d1 = sqrt(x * x + y * y + z * z);
+    const double d2 = sqrt(x * x + y * y + (xi * d1 + z) * (xi * d1 + z));
+    u = fx * x / (alpha * d2 + (1.0 - alpha) * (xi * d1 + z)) + cx;
+    v = fy * y / (alpha * d2 + (1.0 - alpha) * (xi * d1 + z)) + cy;
+  }
+}
+
+__global__ __launch_bounds__(256) void project_landmarks_kernel(const double* __restrict__ pose, int model,
+                                                                const double* __restrict__ intr, int width, int height,
+                                                                const double* __restrict__ points, int n, double z_thr,
+                                                                double* __restrict__ uv, uint8_t* __restrict__ keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double qi[4] = {-pose[0], -pose[1], -pose[2], pose[3]};
+  const double nt[3] = {pose[4] * -1.0, pose[5] * -1.0, pose[6] * -1.0};
+  double ti[3], rp[3];
+  quat_rotate_d(qi, nt, ti);
+  const double p[3] = {points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]};
+  quat_rotate_d(qi, p, rp);
+  const double pc[3] = {rp[0] + ti[0], rp[1] + ti[1], rp[2] + ti[2]};
+  bool ok = !(pc[2] < z_thr);
+  double u = 0, v = 0;
+  if (ok) {
+    project_exact(model, intr, pc[0], pc[1], pc[2], u, v);
+    ok = !(u > (double)width || v > (double)height || u < 0 || v < 0);
+  }
+  uv[2 * (size_t)i] = u;
+  uv[2 * (size_t)i + 1] = v;
+  keep[i] = ok ? 1 : 0;
+}
+
+// order-preserving compaction of (uv, index) by keep[]; one workgroup
+__global__ __launch_bounds__(1024) void compact_projection_kernel(const double* __restrict__ uv, const uint8_t* __restrict__ keep,
+                                                                  int n, double* __restrict__ out_uv, int32_t* __restrict__ out_idx,
+                                                                  int32_t* __restrict__ n_out) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const bool ok = i < n && keep[i];
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    if (ok) {
+      const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+      out_uv[2 * (size_t)p] = uv[2 * (size_t)i];
+      out_uv[2 * (size_t)p + 1] = uv[2 * (size_t)i + 1];
+      out_idx[p] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += wave_tot[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = base_s;
+}
+
+// one wavefront per keypoint; result[k] = matched landmark index or -1
+__global__ __launch_bounds__(256) void find_matches_kernel(const double* __restrict__ kp_xy, const uint64_t* __restrict__ kp_desc,
+                                                           int n_kp, const double* __restrict__ proj_uv,
+                                                           const int32_t* __restrict__ proj_lm, int n_proj,
+                                                           const int32_t* __restrict__ lm_obs_start,
+                                                           const uint64_t* __restrict__ obs_desc, double max_dist_2d,
+                                                           int threshold, double dist_2_best, int32_t* __restrict__ result) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= n_kp) return;  // wave-uniform
+  const double kx = kp_xy[2 * (size_t)k], ky = kp_xy[2 * (size_t)k + 1];
+  uint32_t d[8];
+  {
+    const uint32_t* p = (const uint32_t*)(kp_desc + 4 * (size_t)k);
+#pragma unroll
+    for (int q = 0; q < 8; q++) d[q] = p[q];
+  }
+  int count = 0, top_d = 0, other_d = 0, other_id = 0;
+  for (int base = 0; base < n_proj; base += 64) {
+    const int j = base + lane;
+    bool hit = false;
+    if (j < n_proj) {
+      const double dx = kx - proj_uv[2 * (size_t)j], dy = ky - proj_uv[2 * (size_t)j + 1];
+      hit = sqrt(dx * dx + dy * dy) < max_dist_2d;
+    }
+    unsigned long long mask = __ballot(hit);
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int l = proj_lm[base + b];
+      const int o0 = lm_obs_start[l], o1 = lm_obs_start[l + 1];
+      int best = 256;  // minimal_dist, vo_utils.h:116
+      for (int o = o0 + lane; o < o1; o += 64) {
+        const uint32_t* od = (const uint32_t*)(obs_desc + 4 * (size_t)o);
+        int dist = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) dist += __builtin_popcount(d[q] ^ od[q]);
+        best = min(best, dist);
+      }
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) best = min(best, __shfl_xor(best, s));
+      // libstdc++ partial_sort(first, first + 2, last) as a streaming state machine (see the file header)
+      if (count == 0) {
+        other_d = best;
+        other_id = l;
+      } else if (count == 1) {
+        // e0 = (other_id, other_d) so far, e1 = (l, best)
+        if (best < other_d) {  // d1 < d0: top = e0, other = e1
+          top_d = other_d;
+          other_d = best;
+          other_id = l;
+        } else {  // top = e1, other = e0
+          top_d = best;
+        }
+      } else if (best < top_d) {
+        if (other_d < best) {
+          top_d = best;
+        } else {
+          top_d = other_d;
+          other_d = best;
+          other_id = l;
+        }
+      }
+      count++;
+    }
+  }
+  if (lane == 0) {
+    int res = -1;
+    if (count > 0 && !(other_d >= threshold)) {
+      const double second = count < 2 ? 256.0 : (double)top_d;  // vo_utils.h:146-160
+      if (!(second < (double)other_d * dist_2_best)) res = other_id;
+    }
+    result[k] = res;
+  }
+}
+
+__global__ __launch_bounds__(1024) void compact_matches_kernel(const int32_t* __restrict__ result, int n, int32_t* __restrict__ pairs,
+                                                               int32_t* __restrict__ n_out) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const int r = i < n ? result[i] : -1;
+    const bool ok = r >= 0;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    if (ok) {
+      const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+      pairs[2 * (size_t)p] = i;
+      pairs[2 * (size_t)p + 1] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; w++) t += wave_tot[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = base_s;
+}
+
+}  // namespace
+
+extern "C" int vsl_project_landmarks(vsl_ctx* ctx, const double* pose7, int cam_model, const double* intr8, int width,
+                                     int height, const double* points, int n, double cam_z_threshold, double* proj_uv,
+                                     int32_t* proj_idx, int* n_out) {
+  if (!ctx || !pose7 || !intr8 || !n_out || n < 0 || (n > 0 && (!points || !proj_uv || !proj_idx)) || cam_model < 0 ||
+      cam_model > 3)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_project_landmarks: bad arguments");
+  *n_out = 0;
+  if (n == 0) return VSL_OK;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)n;
+  void* d = nullptr;
+  // pose (8) | intr (8) | points (3N) | uv (2N) | out_uv (2N) | out_idx (N i32) | n_out | keep (N u8)
+  int rc = vsl_ctx_dscratch(ctx, 8 * (16 + 7 * N) + 4 * (N + 4) + N + 64, &d);
+  if (rc) return rc;
+  double* dpose = (double*)d;
+  double* dintr = dpose + 8;
+  double* dpts = dintr + 8;
+  double* duv = dpts + 3 * N;
+  double* douv = duv + 2 * N;
+  int32_t* didx = (int32_t*)(douv + 2 * N);
+  int32_t* dn = didx + N;
+  uint8_t* dkeep = (uint8_t*)(dn + 4);
+  VSL_HIP(ctx, hipMemcpyAsync(dpose, pose7, 56, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(dintr, intr8, 64, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(dpts, points, 24 * N, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(project_landmarks_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dpose, cam_model, dintr, width,
+                     height, dpts, n, cam_z_threshold, duv, dkeep);
+  hipLaunchKernelGGL(compact_projection_kernel, dim3(1), dim3(1024), 0, ctx->stream, duv, dkeep, n, douv, didx, dn);
+  VSL_CHECK_LAUNCH(ctx);
+  int32_t m = 0;
+  VSL_HIP(ctx, hipMemcpyAsync(&m, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_out = m;
+  if (m > 0) {
+    VSL_HIP(ctx, hipMemcpy(proj_uv, douv, 16 * (size_t)m, hipMemcpyDeviceToHost));
+    VSL_HIP(ctx, hipMemcpy(proj_idx, didx, 4 * (size_t)m, hipMemcpyDeviceToHost));
+  }
+  return VSL_OK;
+}
+
+extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, const uint64_t* kp_desc, int n_kp,
+                                          const double* proj_uv, const int32_t* proj_lm, int n_proj,
+                                          const int32_t* lm_obs_start, int n_lms, const uint64_t* obs_desc,
+                                          double match_max_dist_2d, int feature_match_threshold,
+                                          double feature_match_dist_2_best, int32_t* pairs, int* n_out) {
+  if (!ctx || !n_out || n_kp < 0 || n_proj < 0 || n_lms < 0 || (n_kp > 0 && (!kp_xy || !kp_desc || !pairs)) ||
+      (n_proj > 0 && (!proj_uv || !proj_lm || !lm_obs_start)))
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_find_matches_landmarks: bad arguments");
+  *n_out = 0;
+  if (n_kp == 0 || n_proj == 0) return VSL_OK;
+  for (int j = 0; j < n_proj; j++)
+    if (proj_lm[j] < 0 || proj_lm[j] >= n_lms) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_find_matches_landmarks: landmark index %d out of range", proj_lm[j]);
+  const int total = lm_obs_start[n_lms];
+  if (total < 0 || (total > 0 && !obs_desc)) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_find_matches_landmarks: bad observation arrays");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t K = (size_t)n_kp, P = (size_t)n_proj, L = (size_t)n_lms, T = (size_t)total;
+  void* d = nullptr;
+  int rc = vsl_ctx_dscratch(ctx, 8 * (2 * K + 4 * K + 2 * P + 4 * T) + 4 * (P + L + 1 + K + 2 * K + 4) + 64, &d);
+  if (rc) return rc;
+  double* dkxy = (double*)d;
+  uint64_t* dkd = (uint64_t*)(dkxy + 2 * K);
+  double* dpuv = (double*)(dkd + 4 * K);
+  uint64_t* dod = (uint64_t*)(dpuv + 2 * P);
+  int32_t* dplm = (int32_t*)(dod + 4 * T);
+  int32_t* dstart = dplm + P;
+  int32_t* dres = dstart + L + 1;
+  int32_t* dpairs = dres + K;
+  int32_t* dn = dpairs + 2 * K;
+  VSL_HIP(ctx, hipMemcpyAsync(dkxy, kp_xy, 16 * K, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(dkd, kp_desc, 32 * K, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(dpuv, proj_uv, 16 * P, hipMemcpyHostToDevice, ctx->stream));
+  if (T) VSL_HIP(ctx, hipMemcpyAsync(dod, obs_desc, 32 * T, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(dplm, proj_lm, 4 * P, hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(dstart, lm_obs_start, 4 * (L + 1), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(find_matches_kernel, dim3((n_kp + 3) / 4), dim3(256), 0, ctx->stream, dkxy, dkd, n_kp, dpuv, dplm, n_proj,
+                     dstart, dod, match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, dres);
+  hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, dres, n_kp, dpairs, dn);
+  VSL_CHECK_LAUNCH(ctx);
+  int32_t m = 0;
+  VSL_HIP(ctx, hipMemcpyAsync(&m, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_out = m;
+  if (m > 0) VSL_HIP(ctx, hipMemcpy(pairs, dpairs, 8 * (size_t)m, hipMemcpyDeviceToHost));
+  return VSL_OK;
+}
