@@ -74,8 +74,11 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # one rank per GPU; `% device_count` only matters when several ranks rehearse on a one-GPU box
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    vdist.init("nccl")  # RCCL; a no-op at world size 1
+    backend = os.environ.get("VSL_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; "gloo" for rehearsals
+    vdist.init(backend)  # a no-op at world size 1
     B = args.batch
     n_img = 2 * B
 
@@ -103,7 +106,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
 
     nk, nm = frames.counts(n_img, B)
     if not (nk.min() > 0 and nm.min() > 0):

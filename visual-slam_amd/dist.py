@@ -29,7 +29,7 @@ def init(backend):
         kw = {}
         if backend == "nccl":
             import torch
-            kw["device_id"] = torch.device("cuda", local_rank)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
