@@ -69,6 +69,12 @@ def load():
         if not _SO.exists():
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback)" % _SO)
+        try:
+            # PyTorch-ROCm ships its own HIP runtime; when both live in one process the runtime that is
+            # loaded FIRST must be torch's, otherwise torch later reports "No HIP GPUs are available".
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(str(_SO))
         L.vsl_version.restype = C.c_char_p
         L.vsl_last_error.restype = C.c_char_p

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
   __shared__ double b_s[SCH_LB][3];
   __shared__ int slot[SCH_LB][SCH_CMAX];
   __shared__ int kcnt[SCH_LB];
+  __shared__ int obs_of[SCH_LB][SCH_KMAX];  // observation index of the k-th free-camera observation
   __shared__ int ok_s[SCH_LB];
   const int n = D.n, tid = threadIdx.x;
   const int wl0 = l_first + blockIdx.x * lm_per_wg;
@@ -421,40 +422,79 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
   double racc = 0;  // thread tid < n owns rhs[tid]
   for (int s0 = wl0; s0 < wl1; s0 += SCH_LB) {
     const int nl = min(SCH_LB, wl1 - s0);
-    // phase A: per landmark P, b, P^-1 and the slot table (one thread per landmark)
-    if (tid < nl) {
-      const int l = s0 + tid;
-      double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
-      if (diag_l) {
-        P[0] = diag_l[3 * (size_t)l] * inv_radius;
-        P[4] = diag_l[3 * (size_t)l + 1] * inv_radius;
-        P[8] = diag_l[3 * (size_t)l + 2] * inv_radius;
-      }
-      for (int c = 0; c < SCH_CMAX; c++) slot[tid][c] = -1;
-      int k = 0;
-      for (int i = lm_start[l]; i < lm_start[l + 1]; i++) {
-        const double* e = E + 6 * (size_t)i;
-        const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
-        for (int x = 0; x < 3; x++) {
-          for (int y = 0; y < 3; y++) P[3 * x + y] += e[x] * e[y] + e[3 + x] * e[3 + y];
-          bb[x] += e[x] * r0 + e[3 + x] * r1;
+    // phase A: per landmark P, b, P^-1 and the slot table -- one WAVE per staged landmark: lanes take
+    // the observations (a landmark of the small-system path has at most 64), xor-shuffle tree sums
+    // (fixed order), the free-camera rank of an observation from a ballot prefix
+    {
+      const int wv = tid >> 6, ln = tid & 63;
+      if (wv < nl) {
+        const int l = s0 + wv;
+        const int o0 = lm_start[l], o1 = lm_start[l + 1];
+        const int i = o0 + ln;
+        const bool have = i < o1;
+        double P6[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};  // P upper: 00 01 02 11 12 22
+        int fc = -1;
+        if (have) {
+          const double* e = E + 6 * (size_t)i;
+          const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+          P6[0] = e[0] * e[0] + e[3] * e[3];
+          P6[1] = e[0] * e[1] + e[3] * e[4];
+          P6[2] = e[0] * e[2] + e[3] * e[5];
+          P6[3] = e[1] * e[1] + e[4] * e[4];
+          P6[4] = e[1] * e[2] + e[4] * e[5];
+          P6[5] = e[2] * e[2] + e[5] * e[5];
+          for (int x = 0; x < 3; x++) bb[x] = e[x] * r0 + e[3 + x] * r1;
+          fc = cam_free[obs_cam[i]];
         }
-        const int fc = cam_free[obs_cam[i]];
-        if (fc >= 0 && k < SCH_KMAX) {
-          slot[tid][fc] = k;
-          k++;
+        // landmarks with more than 64 observations cannot occur here (one observation per camera,
+        // at most SCH_CMAX free + the fixed cameras); extra observations are folded in serially anyway
+        for (int j = o0 + 64 + ln; j < o1; j += 64) {
+          const double* e = E + 6 * (size_t)j;
+          const double r0 = r[2 * (size_t)j], r1 = r[2 * (size_t)j + 1];
+          P6[0] += e[0] * e[0] + e[3] * e[3];
+          P6[1] += e[0] * e[1] + e[3] * e[4];
+          P6[2] += e[0] * e[2] + e[3] * e[5];
+          P6[3] += e[1] * e[1] + e[4] * e[4];
+          P6[4] += e[1] * e[2] + e[4] * e[5];
+          P6[5] += e[2] * e[2] + e[5] * e[5];
+          for (int x = 0; x < 3; x++) bb[x] += e[x] * r0 + e[3 + x] * r1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+          for (int q = 0; q < 6; q++) P6[q] += __shfl_xor(P6[q], o);
+#pragma unroll
+          for (int q = 0; q < 3; q++) bb[q] += __shfl_xor(bb[q], o);
+        }
+        double P[9] = {P6[0], P6[1], P6[2], P6[1], P6[3], P6[4], P6[2], P6[4], P6[5]};
+        if (diag_l) {
+          P[0] += diag_l[3 * (size_t)l] * inv_radius;
+          P[4] += diag_l[3 * (size_t)l + 1] * inv_radius;
+          P[8] += diag_l[3 * (size_t)l + 2] * inv_radius;
+        }
+        if (ln < SCH_CMAX) slot[wv][ln] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long fm = __ballot(have && fc >= 0);
+        const int rank = __popcll(fm & ((1ull << ln) - 1ull));
+        if (have && fc >= 0 && rank < SCH_KMAX) {
+          slot[wv][fc] = rank;
+          obs_of[wv][rank] = i;
+        }
+        const int k = min(__popcll(fm), SCH_KMAX);
+        double Pi[9];
+        const bool ok = o1 > o0 && inv3(P, Pi);
+        if (ln == 0) {
+          ok_s[wv] = ok;
+          kcnt[wv] = ok ? k : 0;
+          for (int q = 0; q < 9; q++) Pi_s[wv][q] = ok ? Pi[q] : 0.0;
+          for (int q = 0; q < 3; q++) b_s[wv][q] = ok ? bb[q] : 0.0;
+          if (Pinv_out)
+            for (int q = 0; q < 9; q++) Pinv_out[9 * (size_t)l + q] = ok ? Pi[q] : 0.0;
+          if (bl_out)
+            for (int q = 0; q < 3; q++) bl_out[3 * (size_t)l + q] = ok ? bb[q] : 0.0;
         }
       }
-      double Pi[9];
-      const bool ok = lm_start[l + 1] > lm_start[l] && inv3(P, Pi);
-      ok_s[tid] = ok;
-      kcnt[tid] = ok ? k : 0;
-      for (int q = 0; q < 9; q++) Pi_s[tid][q] = ok ? Pi[q] : 0.0;
-      for (int q = 0; q < 3; q++) b_s[tid][q] = ok ? bb[q] : 0.0;
-      if (Pinv_out)
-        for (int q = 0; q < 9; q++) Pinv_out[9 * (size_t)l + q] = ok ? Pi[q] : 0.0;
-      if (bl_out)
-        for (int q = 0; q < 3; q++) bl_out[3 * (size_t)l + q] = ok ? bb[q] : 0.0;
     }
     __syncthreads();
     // phase B: W = F^T E (6x3) and Y = W P^-1 for every free-camera observation of the staged landmarks
@@ -462,13 +502,7 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
       const int li = item / (SCH_KMAX * 6), rem = item - li * (SCH_KMAX * 6);
       const int q = rem / 6, x = rem - q * 6;
       if (q >= kcnt[li]) continue;
-      // find the q-th free-camera observation of landmark s0+li
-      const int l = s0 + li;
-      int i = lm_start[l], seen = -1;
-      for (; i < lm_start[l + 1]; i++) {
-        if (cam_free[obs_cam[i]] >= 0) seen++;
-        if (seen == q) break;
-      }
+      const int i = obs_of[li][q];
       const double* f = F + 12 * (size_t)i;
       const double* e = E + 6 * (size_t)i;
       double w[3];
@@ -675,19 +709,21 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
     __syncthreads();
   }
   if (ok) {
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < n; i++) {
-        double s = bvec[i];
-        for (int k = 0; k < i; k++) s -= A[i * n + k] * bvec[k];
-        bvec[i] = s / A[i * n + i];
-      }
-      for (int i = n - 1; i >= 0; i--) {
-        double s = bvec[i];
-        for (int k = i + 1; k < n; k++) s -= A[k * n + i] * bvec[k];
-        bvec[i] = s / A[i * n + i];
-      }
+    // column-oriented substitutions: once x_j is final every later row subtracts its multiple in parallel
+    for (int j = 0; j < n; j++) {  // forward: L y = b
+      if (threadIdx.x == 0) bvec[j] /= A[j * n + j];
+      __syncthreads();
+      const double yj = bvec[j];
+      for (int i = j + 1 + threadIdx.x; i < n; i += 256) bvec[i] -= A[i * n + j] * yj;
+      __syncthreads();
     }
-    __syncthreads();
+    for (int j = n - 1; j >= 0; j--) {  // backward: L^T x = y
+      if (threadIdx.x == 0) bvec[j] /= A[j * n + j];
+      __syncthreads();
+      const double xj = bvec[j];
+      for (int i = threadIdx.x; i < j; i += 256) bvec[i] -= A[j * n + i] * xj;
+      __syncthreads();
+    }
     for (int i = threadIdx.x; i < n; i += 256) dc[i] = -bvec[i];
   }
   if (threadIdx.x == 0) *ok_flag = ok;
