@@ -47,6 +47,20 @@ def test_detect_describe_bit_exact(ctx, orc, images, name, nf):
         assert len(xy) > 1000
 
 
+def test_large_image_uses_global_grid(ctx, orc, synth):
+    # 1280 x 720 = 14400 8x8 cells > 6144: the selection kernel keeps its per-cell arrays in global memory
+    left, _ = synth.stereo_pair(41, w=1280, h=720, n_rects=7000)
+    xy, ang, desc = ctx.detect_describe(left, 2000, True)
+    oxy, oang, odesc = orc.detect_describe(left, 2000, True)
+    assert np.array_equal(xy, oxy) and len(xy) > 1500
+    assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64)) and np.array_equal(desc, odesc)
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (720, 1280), dtype=np.uint8)  # > 8192 candidates on top of it
+    xy, _, desc = ctx.detect_describe(noise, 1500, True)
+    oxy, _, odesc = orc.detect_describe(noise, 1500, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+
+
 def test_detect_without_rotation(ctx, orc, images):
     xy, ang, desc = ctx.detect_describe(images["left"], 800, False)
     oxy, oang, odesc = orc.detect_describe(images["left"], 800, False)

@@ -244,7 +244,7 @@ extern "C" int vsl_frames_destroy(vsl_frames* f) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {f->images, f->response, f->meta, f->cand, f->kp_xy, f->kp_count,
                   f->kp_moments, f->kp_angle, f->kp_desc, f->pair_slots, f->best_key, f->second_key,
-                  f->matches, f->match_count, f->tie_count, f->tie_rec};
+                  f->matches, f->match_count, f->tie_count, f->tie_rec, f->sel_grid};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;

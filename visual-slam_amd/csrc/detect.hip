@@ -249,12 +249,17 @@ __device__ __forceinline__ int block_scan(bool p, int* wave_tot, int& total) {
 #define SEL_LDS_BYTES (SEL_CHUNK * 8 + SEL_MAX_CELLS * 2 * 4 + SEL_THREADS * 4 * 3 + SEL_MAX_CELLS * 4 + 2048)
 static_assert(SEL_LDS_BYTES <= 160 * 1024, "selection kernel LDS budget");
 
+// GRID_GLOBAL = false: the accepted-corner grid and the batch list heads live in LDS (images of up to
+// SEL_MAX_CELLS cells, e.g. 752 x 480).  GRID_GLOBAL = true: larger images keep the two per-cell arrays
+// in a global scratch (grid_scratch, 3 words per cell per image, L2-resident) -- same algorithm, slower.
+template <bool GRID_GLOBAL>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __restrict__ cand_all,
                                                              const int32_t* __restrict__ meta,
                                                              int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_count,
                                                              int w, int h, size_t cand_cap, int F, int first,
-                                                             int num_features, int border, double quality) {
-  __shared__ __align__(16) unsigned char smem[SEL_LDS_BYTES];
+                                                             int num_features, int border, double quality,
+                                                             uint32_t* __restrict__ grid_scratch) {
+  __shared__ __align__(16) unsigned char smem[GRID_GLOBAL ? (SEL_CHUNK * 8 + SEL_THREADS * 4 * 3 + 2048) : SEL_LDS_BYTES];
   const int slot = first + blockIdx.x;
   const uint64_t* __restrict__ cand = cand_all + (size_t)slot * cand_cap;
   const int n_cand = min(meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], (int)cand_cap);
@@ -262,9 +267,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   // LDS carve-up (all regions 8-byte aligned)
   uint64_t* keys = (uint64_t*)smem;                 // SEL_CHUNK sorted keys
   SelShared* sh = (SelShared*)(keys + SEL_CHUNK);
-  uint32_t* acc = (uint32_t*)(sh + 1);              // cells * 2 accepted corners, packed x | y << 16
-  int* head = (int*)(acc + 2 * (size_t)cells);      // cells: batch list heads (-1 = empty)
-  int* next = head + cells;                         // SEL_THREADS
+  // cells * 2 accepted corners, packed x | y << 16, then cells batch list heads (-1 = empty); volatile:
+  // the global variant must not keep them in registers / stale L1 lines between workgroup barriers
+  volatile uint32_t* acc = GRID_GLOBAL ? (volatile uint32_t*)(grid_scratch + (size_t)slot * cells * 3) : (volatile uint32_t*)(sh + 1);
+  volatile int* head = (volatile int*)(acc + 2 * (size_t)cells);
+  int* next = GRID_GLOBAL ? (int*)(sh + 1) : (int*)(head + cells);  // SEL_THREADS
   uint32_t* cxy = (uint32_t*)(next + SEL_THREADS);  // SEL_THREADS: batch candidate position
   int* state = (int*)(cxy + SEL_THREADS);           // SEL_THREADS: 0 undecided, 1 accepted, 2 rejected
   const int tid = threadIdx.x;
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       }
       cxy[tid] = (uint32_t)px | ((uint32_t)py << 16);
       state[tid] = alive ? 0 : 2;
-      if (alive) next[tid] = atomicExch(&head[cell], tid);
+      if (alive) next[tid] = atomicExch((int*)&head[cell], tid);
       __syncthreads();
       bool undecided = alive;
       while (true) {
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       }
       if (keep) {
         const uint32_t packed = (uint32_t)px | ((uint32_t)py << 16);
-        if (atomicCAS(&acc[2 * cell], SEL_EMPTY, packed) != SEL_EMPTY) atomicCAS(&acc[2 * cell + 1], SEL_EMPTY, packed);
+        if (atomicCAS((uint32_t*)&acc[2 * cell], SEL_EMPTY, packed) != SEL_EMPTY) atomicCAS((uint32_t*)&acc[2 * cell + 1], SEL_EMPTY, packed);
       }
       if (alive) head[cell] = -1;
       n_acc = min(num_features, n_acc + total);
@@ -443,8 +450,11 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
   if (num_features < 1 || num_features > f->F)
     return vsl_fail(ctx, VSL_ERR_INVALID, "num_features %d not in [1, %d]", num_features, f->F);
   static_assert(sizeof(SelShared) <= 2048, "SelShared fits its LDS slot");
-  if (((f->w + 7) / 8) * ((f->h + 7) / 8) > SEL_MAX_CELLS)
-    return vsl_fail(ctx, VSL_ERR_CAPACITY, "image %dx%d has more than %d 8x8 cells (selection kernel LDS limit)", f->w, f->h, SEL_MAX_CELLS);
+  const int cells = ((f->w + 7) / 8) * ((f->h + 7) / 8);
+  const bool grid_global = cells > SEL_MAX_CELLS;
+  if (grid_global && !f->sel_grid) {
+    VSL_HIP(ctx, hipMalloc((void**)&f->sel_grid, sizeof(uint32_t) * 3 * (size_t)cells * f->max_images));
+  }
   const int w = f->w, h = f->h;
   {
     VslStage st(ctx, VSL_STAGE_RESPONSE);
@@ -456,8 +466,12 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
   }
   {
     VslStage st(ctx, VSL_STAGE_SELECT);
-    hipLaunchKernelGGL(select_kernel, dim3(n), dim3(SEL_THREADS), 0, ctx->stream, f->cand, f->meta, f->kp_xy,
-                       f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01);
+    if (grid_global)
+      hipLaunchKernelGGL(select_kernel<true>, dim3(n), dim3(SEL_THREADS), 0, ctx->stream, f->cand, f->meta, f->kp_xy,
+                         f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, f->sel_grid);
+    else
+      hipLaunchKernelGGL(select_kernel<false>, dim3(n), dim3(SEL_THREADS), 0, ctx->stream, f->cand, f->meta, f->kp_xy,
+                         f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, (uint32_t*)nullptr);
     VSL_CHECK_LAUNCH(ctx);
   }
   return VSL_OK;

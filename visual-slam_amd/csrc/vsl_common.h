@@ -98,6 +98,7 @@ struct vsl_frames {
   uint32_t* second_key = nullptr;  // [max_pairs][2][F]
   int32_t* matches = nullptr;      // [max_pairs][F][2]
   int32_t* match_count = nullptr;  // [max_pairs]
+  uint32_t* sel_grid = nullptr;    // [max_images][cells][3]: selection grid of images too large for LDS (lazy)
   // rBRIEF near-tie records (see describe.hip)
   int32_t* tie_count = nullptr;    // [1]
   int32_t* tie_rec = nullptr;      // [tie_cap][4]  (slot, keypoint, bit, unused)
