@@ -348,20 +348,62 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
     while (N < n_chunk) N <<= 1;
     for (int i = n_chunk + tid; i < N; i += SEL_THREADS) keys[i] = 0ull;
     __syncthreads();
-    // ---- bitonic sort, descending
-    for (int k = 2; k <= N; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int l = i | j;
-          const uint64_t a = keys[i], b = keys[l];
-          const bool desc = (i & k) == 0;
-          if (desc ? (a < b) : (a > b)) {
-            keys[i] = b;
-            keys[l] = a;
+    // ---- bitonic sort, descending.  With a full chunk (N = SEL_CHUNK = 8 keys per thread) the three
+    // finest sub-steps of every stage (j = 4, 2, 1) run in registers on the thread's 8 consecutive keys:
+    // 68 workgroup barriers instead of 91 and a third less LDS traffic.
+    if (N == SEL_CHUNK) {
+      const int base = tid * 8;
+      for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j >= 8; j >>= 1) {
+          for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const uint64_t a = keys[i], b = keys[l];
+            const bool desc = (i & k) == 0;
+            if (desc ? (a < b) : (a > b)) {
+              keys[i] = b;
+              keys[l] = a;
+            }
+          }
+          __syncthreads();
+        }
+        uint64_t rk[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) rk[a] = keys[base + a];
+#pragma unroll
+        for (int jj = 4; jj > 0; jj >>= 1) {
+          if (jj <= (k >> 1)) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+              if ((a & jj) == 0) {
+                const bool desc = ((base + a) & k) == 0;
+                const uint64_t x = rk[a], y = rk[a | jj];
+                const bool sw = desc ? (x < y) : (x > y);
+                rk[a] = sw ? y : x;
+                rk[a | jj] = sw ? x : y;
+              }
+            }
           }
         }
+#pragma unroll
+        for (int a = 0; a < 8; a++) keys[base + a] = rk[a];
         __syncthreads();
+      }
+    } else {
+      for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const uint64_t a = keys[i], b = keys[l];
+            const bool desc = (i & k) == 0;
+            if (desc ? (a < b) : (a > b)) {
+              keys[i] = b;
+              keys[l] = a;
+            }
+          }
+          __syncthreads();
+        }
       }
     }
     // ---- greedy, SEL_THREADS ranks per batch
