@@ -219,6 +219,7 @@ int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_
   ok = ok && dalloc(&f->second_key, P * 2 * F) == hipSuccess;
   ok = ok && dalloc(&f->matches, P * F * 2) == hipSuccess;
   ok = ok && dalloc(&f->match_count, P) == hipSuccess;
+  ok = ok && dalloc(&f->exact_list, M * VSL_EXACT_CAP) == hipSuccess;
   ok = ok && dalloc(&f->tie_count, 1) == hipSuccess;
   ok = ok && dalloc(&f->tie_rec, (size_t)f->tie_cap * 4) == hipSuccess;
   if (!ok) {
@@ -228,6 +229,7 @@ int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_
   (void)hipMemsetAsync(f->kp_count, 0, M * sizeof(int32_t), ctx->stream);
   (void)hipMemsetAsync(f->match_count, 0, P * sizeof(int32_t), ctx->stream);
   (void)hipMemsetAsync(f->tie_count, 0, sizeof(int32_t), ctx->stream);
+  (void)hipMemsetAsync(f->meta, 0, M * VSL_META_STRIDE * sizeof(int32_t), ctx->stream);
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = f;
   return VSL_OK;
@@ -244,7 +246,7 @@ extern "C" int vsl_frames_destroy(vsl_frames* f) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {f->images, f->response, f->meta, f->cand, f->kp_xy, f->kp_count,
                   f->kp_moments, f->kp_angle, f->kp_desc, f->pair_slots, f->best_key, f->second_key,
-                  f->matches, f->match_count, f->tie_count, f->tie_rec, f->sel_grid};
+                  f->matches, f->match_count, f->tie_count, f->tie_rec, f->sel_grid, f->exact_list};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;

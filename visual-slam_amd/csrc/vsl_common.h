@@ -16,6 +16,8 @@
 #define VSL_META_STRIDE 32  // ints: 128 bytes per image
 #define VSL_META_MAX 0      // order-preserving int encoding of the fp32 response maximum
 #define VSL_META_NCAND 1    // number of corner candidates
+#define VSL_META_NEXACT 3   // rBRIEF bits whose rotated coordinates need the exact (integer) rounding
+#define VSL_EXACT_CAP 16384 // capacity of that per-image list
 
 struct vsl_ctx {
   int device = 0;
@@ -98,12 +100,14 @@ struct vsl_frames {
   uint32_t* second_key = nullptr;  // [max_pairs][2][F]
   int32_t* matches = nullptr;      // [max_pairs][F][2]
   int32_t* match_count = nullptr;  // [max_pairs]
+  uint32_t* exact_list = nullptr;  // [max_images][VSL_EXACT_CAP]: (keypoint << 8) | bit, see describe.hip
   uint32_t* sel_grid = nullptr;    // [max_images][cells][3]: selection grid of images too large for LDS (lazy)
   // rBRIEF near-tie records (see describe.hip)
   int32_t* tie_count = nullptr;    // [1]
   int32_t* tie_rec = nullptr;      // [tie_cap][4]  (slot, keypoint, bit, unused)
   int tie_cap = 0;
   bool ties_pending = false, ties_from_angles = false;
+  bool exact_overflow_check = false;  // diagnostic (tests): verify no exact-rounding list overflowed
   bool store_response = false;  // K1 writes the fp32 response image only for the parity hook
   std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
 };
