@@ -23,7 +23,8 @@
 #ifndef VSL_MATCH_WAVES
 #define VSL_MATCH_WAVES 8
 #endif
-#define KEY_SHIFT 23
+// key = (distance << KEY_SHIFT) | index: 10 bits of distance headroom (256 + 256 never overflows), 22 bits of index
+#define KEY_SHIFT 22
 #define KEY_INIT ((256u << KEY_SHIFT) | 0u)
 
 // v_med3_u32: median of three unsigned values (one VALU op; no clang builtin for the integer form)
@@ -212,9 +213,7 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[s], acc1, 0, 0, 0);
     }
     // accumulator register g*4+j of lane (c, h) = -2 <database row 8g + 4h + j of the tile, query c>;
-    // key = ((|q| + |d_m| - 2<q, d_m>) << KEY_SHIFT) | m.  A padded row has rowkey = KEY_INIT and a zero
-    // accumulator; adding |q| << KEY_SHIFT to it can only make the key larger than every real key's
-    // distance field allows only if |q| = 0 -- so padded rows are clamped back to KEY_INIT.
+    // key = ((|q| + |d_m| - 2<q, d_m>) << KEY_SHIFT) | m.
 #pragma unroll
     for (int half = 0; half < 2; half++) {
 #pragma unroll
@@ -224,8 +223,10 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int av = half ? acc1[4 * g + j] : acc0[4 * g + j];
-          uint32_t key = rks[j] + pq_key + ((uint32_t)av << KEY_SHIFT);
-          key = rks[j] == KEY_INIT ? KEY_INIT : key;
+          // a padded row has rowkey = KEY_INIT and a zero accumulator: its key is KEY_INIT + (|q| << KEY_SHIFT)
+          // >= KEY_INIT >= sk >= b (no 32-bit overflow: the distance field holds up to 1023), so neither the
+          // minimum nor the median moves -- no clamp needed
+          const uint32_t key = rks[j] + pq_key + ((uint32_t)av << KEY_SHIFT);
           sk = umed3(b, key, sk);
           b = min(b, key);
         }

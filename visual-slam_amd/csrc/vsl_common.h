@@ -96,7 +96,7 @@ struct vsl_frames {
   uint64_t* kp_desc = nullptr;  // [max_images][F][4]
   // matcher
   int32_t* pair_slots = nullptr;   // [max_pairs][2]
-  uint32_t* best_key = nullptr;    // [max_pairs][2][F]   (distance << 23 | index), direction 0: a->b
+  uint32_t* best_key = nullptr;    // [max_pairs][2][F]   (distance << 22 | index), direction 0: a->b
   uint32_t* second_key = nullptr;  // [max_pairs][2][F]
   int32_t* matches = nullptr;      // [max_pairs][F][2]
   int32_t* match_count = nullptr;  // [max_pairs]
