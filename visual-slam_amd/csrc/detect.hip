@@ -25,10 +25,11 @@ struct RowF {
   float rx, ry;
 };
 
-__device__ __forceinline__ RowF rowfilt(const uint8_t* __restrict__ img, int w, int yr, int xm, int xe, int xp,
-                                        float s, float s2) {
-  const int off = yr * w;  // 32-bit offsets from the (wave-uniform) image base: saddr + voffset loads
-  const float l = (float)img[off + xm], m = (float)img[off + xe], r = (float)img[off + xp];
+__device__ __forceinline__ RowF rowfilt(const uint8_t* __restrict__ img, int w, int yr, unsigned xm, unsigned xe,
+                                        unsigned xp, float s, float s2) {
+  // yr is wave-uniform: scalar row base + one 32-bit lane offset per load (saddr + voffset form)
+  const uint8_t* __restrict__ row = img + (size_t)(unsigned)(yr * w);
+  const float l = (float)row[xm], m = (float)row[xe], r = (float)row[xp];
   RowF o;
   o.rx = r - l;
   float t = s * l;
@@ -52,6 +53,33 @@ __device__ __forceinline__ float from_lane_above(float v) {  // lane i <- lane i
 __device__ __forceinline__ float fmax3(float a, float b, float c) {
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ float fmax2(float a, float b) {  // no NaN canonicalisation moves
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// Correctly rounded fp32 square root = what sqrtf compiles to under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt (v_sqrt_f32 is good to 1 ulp; the two exact FMA residuals of
+// the neighbouring floats pick the correctly rounded one), minus that expansion's denormal pre-scaling
+// and inf/zero class test: t = 0 falls through both residual tests (NaN / zero compare false), and the
+// rare denormal-range t (rounding-noise gradients in an otherwise flat patch) takes the library path.
+__device__ __forceinline__ float sqrt_rn(float t) {
+  float r = __builtin_amdgcn_sqrtf(t);
+  const float rm = __builtin_bit_cast(float, __builtin_bit_cast(int, r) - 1);
+  const float rp = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
+  const float em = __builtin_fmaf(-rm, r, t);
+  const float ep = __builtin_fmaf(-rp, r, t);
+  r = (0.f >= em) ? rm : r;
+  r = (0.f < ep) ? rp : r;
+  const bool tiny = t < 0x1p-96f && t > 0.f;
+  if (__ballot(tiny) != 0ull) {  // wave-uniform branch: keeps the library expansion off the common path
+    asm volatile("" ::: "memory");  // not speculatable: stops the compiler from flattening the branch
+    if (tiny) r = sqrtf(t);
+  }
   return r;
 }
 
@@ -90,7 +118,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
   const uint8_t* __restrict__ img = images + (size_t)slot * w * h;
   float* __restrict__ resp = response + (size_t)slot * w * h;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping below stays scalar
   const int xs = blockIdx.x * K1_COLS;
   const int y0 = (blockIdx.y * 4 + wave) * K1_ROWS;
   if (threadIdx.x == 0) n_list = 0;
@@ -99,8 +127,8 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
     const float s2 = 2.0f * s;
     const int x = xs - 2 + lane;
-    const int xe = reflect101(min(max(x, -1), w), w);  // out-of-range lanes are parked on a valid column
-    const int xm = reflect101(xe - 1, w), xp = reflect101(xe + 1, w);
+    const unsigned xe = (unsigned)reflect101(min(max(x, -1), w), w);  // out-of-range lanes are parked on a valid column
+    const unsigned xm = (unsigned)reflect101((int)xe - 1, w), xp = (unsigned)reflect101((int)xe + 1, w);
     const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
 
     // Three generations of row sums / response rows live in registers; the row loop is unrolled by
@@ -151,16 +179,16 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const float bb = b * b;
       t = t + bb;
       // sqrtf is correctly rounded under hipcc's default flags; __fsqrt_rn is the approximate native sqrt
-      const float v_dn = (a + c) - sqrtf(t);
+      const float v_dn = (a + c) - sqrt_rn(t);
       const float l_dn = from_lane_below(v_dn), r_dn = from_lane_above(v_dn);
       if (own_col && y >= y0 && y < y_end) {
         if (store_response) resp[y * w + x] = v_dn;
-        vmax = fmaxf(vmax, v_dn);
+        vmax = fmax2(vmax, v_dn);
       }
       // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn)
       const int yc = q - 2;
       if (own_col && yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1 && x >= 1 && x < w - 1 && v_mid > 0.f) {
-        const float m8 = fmax3(fmax3(l_up, v_up, r_up), fmax3(l_mid, r_mid, l_dn), fmaxf(v_dn, r_dn));
+        const float m8 = fmax3(fmax3(l_up, v_up, r_up), fmax3(l_mid, r_mid, l_dn), fmax2(v_dn, r_dn));
         if (!(m8 > v_mid)) {
           const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
           const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
