@@ -183,6 +183,11 @@ int vsl_frames_detect_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, in
 int vsl_frames_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
 /* Diagnostic knob: width of that guard band (default 1e-12; tests widen it to exercise the path). */
 int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
+/* Diagnostic knobs for the parity tests (results never change, only which kernel path produces them):
+ *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
+ *   "force_generic_describe" (0/1)  f64 describe kernel for every call
+ *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path) */
+int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value);
 
 /* matchDescriptors for n_pairs (slot_a, slot_b) pairs; slot_pairs is a HOST
  * array of 2*n_pairs slot indices; results land in pair slots [0, n_pairs)

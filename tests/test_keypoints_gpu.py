@@ -95,6 +95,33 @@ def test_near_tie_guard_path(ctx, orc, images):
     assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("cap", [0, 3])
+def test_response_kernel_list_overflow_path(ctx, orc, images, cap):
+    # shrink the response kernel's per-wave LDS candidate list so that (almost) every candidate takes the
+    # direct global append; the selected corners must not change
+    img = images["left"]
+    ctx.set_diagnostic("k1_list_cap", cap)
+    try:
+        xy, ang, desc = ctx.detect_describe(img, 1500, True)
+    finally:
+        ctx.set_diagnostic("k1_list_cap", 256)
+    oxy, oang, odesc = orc.detect_describe(img, 1500, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+
+
+def test_generic_describe_kernel_matches_fast_one(ctx, orc, images):
+    img = images["right"]
+    ctx.set_diagnostic("force_generic_describe", 1)
+    try:
+        xy, ang, desc = ctx.detect_describe(img, 700, True)
+    finally:
+        ctx.set_diagnostic("force_generic_describe", 0)
+    oxy, oang, odesc = orc.detect_describe(img, 700, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(ang, oang) and np.array_equal(desc, odesc)
+    with pytest.raises(Exception):
+        ctx.set_diagnostic("no_such_knob", 1)
+
+
 @pytest.mark.parametrize("k", [0, 1])
 def test_golden_euroc(ctx, k):
     g = np.load(GOLDEN / ("euroc_pair%d.npz" % k))

@@ -36,6 +36,24 @@ def test_match_random_planted(ctx, orc, synth, n1, n2):
     assert np.array_equal(got, exp)
 
 
+def test_valu_matcher_variant_agrees(ctx, orc, synth):
+    # the popcount (VALU) kernel is kept as an independent second implementation of the same contract
+    d1, d2 = _planted(synth, 77, 1100, 900)
+    # all-zero / all-one descriptors: |q| = 0 and 256 are the extremes of the matrix-core key arithmetic
+    d1[3] = 0
+    d2[5] = 0
+    d1[7] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    d2[9] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    exp = orc.match_descriptors(d1, d2, 70, 1.2)
+    assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
+    ctx.set_diagnostic("match_use_valu", 1)
+    try:
+        got = ctx.match_descriptors(d1, d2, 70, 1.2)
+    finally:
+        ctx.set_diagnostic("match_use_valu", 0)
+    assert np.array_equal(got, exp)
+
+
 def test_match_thresholds_and_ratios(ctx, orc, synth):
     d1, d2 = _planted(synth, 5, 700, 650)
     for thr, ratio in ((70, 1.2), (1, 1.2), (256, 1.0), (257, 1.0), (100, 2.5), (70, 1.0)):

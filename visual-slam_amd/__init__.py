@@ -149,6 +149,9 @@ class Context:
     def set_tie_eps(self, eps):
         self._ck(self.L.vsl_ctx_set_tie_eps(self.h, C.c_double(eps)))
 
+    def set_diagnostic(self, name, value):
+        self._ck(self.L.vsl_ctx_set_diagnostic(self.h, name.encode(), C.c_int(int(value))))
+
     # ---- keypoints.h drop-ins (host buffers)
     def detect_describe(self, img, num_features=1500, rotate=True):
         img, p, w, h, pitch = _img(img)

@@ -16,7 +16,7 @@
 #include "vsl_common.h"
 
 #define K1_ROWS 16
-#define K1_LIST 1024  // LDS candidate slots per workgroup; overflow goes straight to global memory
+#define K1_WLIST 256  // LDS candidate slots per wave (60 x 16 pixels); overflow goes straight to global memory
 #define K1_COLS 60  // owned columns per wave: 64 lanes minus two halo lanes on each side
 
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -111,9 +111,9 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
                                                                float* __restrict__ response, int32_t* __restrict__ meta,
                                                                uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
-                                                               int first, int store_response) {
-  __shared__ uint64_t list[K1_LIST];
-  __shared__ int n_list, g_base;
+                                                               int first, int store_response, int wlist_cap) {
+  __shared__ uint64_t list[4][K1_WLIST];  // wave-private lists: appended with a scalar counter, no atomics
+  __shared__ int wave_n[4], g_base;
   const int slot = first + blockIdx.z;
   const uint8_t* __restrict__ img = images + (size_t)slot * w * h;
   float* __restrict__ resp = response + (size_t)slot * w * h;
@@ -121,8 +121,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping below stays scalar
   const int xs = blockIdx.x * K1_COLS;
   const int y0 = (blockIdx.y * 4 + wave) * K1_ROWS;
-  if (threadIdx.x == 0) n_list = 0;
-  __syncthreads();
+  int n_wave = 0;  // wave-uniform
   if (y0 < h) {
     const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
     const float s2 = 2.0f * s;
@@ -130,6 +129,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const unsigned xe = (unsigned)reflect101(min(max(x, -1), w), w);  // out-of-range lanes are parked on a valid column
     const unsigned xm = (unsigned)reflect101((int)xe - 1, w), xp = (unsigned)reflect101((int)xe + 1, w);
     const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
+    const bool cand_col = own_col && x >= 1 && x < w - 1;
 
     // Three generations of row sums / response rows live in registers; the row loop is unrolled by
     // three with the roles rotated by NAME (no register-to-register moves).
@@ -187,18 +187,24 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       }
       // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn)
       const int yc = q - 2;
-      if (own_col && yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1 && x >= 1 && x < w - 1 && v_mid > 0.f) {
+      if (yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1) {  // scalar
         const float m8 = fmax3(fmax3(l_up, v_up, r_up), fmax3(l_mid, r_mid, l_dn), fmax2(v_dn, r_dn));
-        if (!(m8 > v_mid)) {
-          const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
-          const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
-          const int p = atomicAdd(&n_list, 1);
-          if (p < K1_LIST) {
-            list[p] = key;
-          } else {  // more than K1_LIST candidates in one 60 x 64 tile (plateaus): rare direct append
-            const int g = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], 1);
-            if ((size_t)g < cand_cap) cand[(size_t)slot * cand_cap + g] = key;
+        const bool is_cand = cand_col && v_mid > 0.f && !(m8 > v_mid);
+        const unsigned long long mask = __ballot(is_cand);
+        if (mask != 0ull) {
+          if (is_cand) {
+            const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
+            const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
+            const int p = n_wave + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (p < wlist_cap) {
+              list[wave][p] = key;
+            } else {  // more than K1_WLIST candidates in one 60 x 16 strip (plateaus): rare direct append
+              const int g = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], 1);
+              if ((size_t)g < cand_cap) cand[(size_t)slot * cand_cap + g] = key;
+            }
           }
+          n_wave += __popcll(mask);
         }
       }
       // the response of row q-1 is stored in the slot of the row sums of row q-1 (pm1) for the next steps
@@ -220,14 +226,17 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if (lane == 0) atomicMax(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_MAX], vsl_float_to_ordered(vmax));
   }
+  if (lane == 0) wave_n[wave] = min(n_wave, wlist_cap);
   __syncthreads();
-  const int n = min(n_list, K1_LIST);
+  const int c0 = wave_n[0], c1 = wave_n[1], c2 = wave_n[2], c3 = wave_n[3];
+  const int n = c0 + c1 + c2 + c3;
   if (n == 0) return;
   if (threadIdx.x == 0) g_base = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], n);
   __syncthreads();
-  const int base = g_base;
-  for (int i = threadIdx.x; i < n; i += 256)
-    if ((size_t)(base + i) < cand_cap) cand[(size_t)slot * cand_cap + base + i] = list[i];
+  const int base = g_base + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+  const int mine = wave_n[wave];
+  for (int i = lane; i < mine; i += 64)
+    if ((size_t)(base + i) < cand_cap) cand[(size_t)slot * cand_cap + base + i] = list[wave][i];
 }
 
 // ------------------------------------------------------------------------------------------ K2b
@@ -531,7 +540,7 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     hipLaunchKernelGGL(detect_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f->meta, first, n);
     hipLaunchKernelGGL(min_eig_response_kernel, dim3((w + K1_COLS - 1) / K1_COLS, (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS), n),
                        dim3(256), 0, ctx->stream, f->images, f->response, f->meta, f->cand, f->cand_cap, w, h, first,
-                       f->store_response ? 1 : 0);
+                       f->store_response ? 1 : 0, min(max(ctx->k1_list_cap, 0), K1_WLIST));
     VSL_CHECK_LAUNCH(ctx);
   }
   {

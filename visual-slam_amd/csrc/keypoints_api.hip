@@ -1,11 +1,22 @@
 // keypoints_api.hip -- C-ABI entry points of the keypoint path (host-buffer and device-resident).
 #include <cmath>
+#include <string>
 
 #include "vsl_common.h"
 
 extern "C" int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps) {
   if (!ctx || !(eps >= 0.0) || eps > 0.5) return vsl_fail(ctx, VSL_ERR_INVALID, "tie eps must be in [0, 0.5]");
   ctx->tie_eps = eps;
+  return VSL_OK;
+}
+
+extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return VSL_ERR_INVALID;
+  const std::string k(name);
+  if (k == "match_use_valu") ctx->match_use_valu = value != 0;
+  else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
+  else if (k == "k1_list_cap") ctx->k1_list_cap = value;
+  else return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ctx_set_diagnostic: unknown knob '%s'", name);
   return VSL_OK;
 }
 
