@@ -9,7 +9,10 @@ One STEP = one pass of the per-frame hot path over a batch of B stereo frames al
 HBM:   detectKeypointsAndDescriptors on 2B images (K1 response, K2 selection, K3+K4 orientation +
 rBRIEF-256)  ->  exactness guard (vsl_frames_resolve_ties: one stream sync + 4-byte readback)  ->
 matchDescriptors(left, right, 70, 1.2) on B pairs (K5).  Outputs stay in HBM (the PCIe-inclusive
-host-buffer rate is reported in DESIGN.md, never as `value`).
+host-buffer rate is reported in DESIGN.md, never as `value`).  The batch is split over S HIP streams
+(default 2 x 128 stereo frames): the selection kernel is one latency-bound workgroup per image and
+leaves most of each CU's issue slots free, so the other stream's response / describe kernels run
+underneath it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -57,7 +60,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="stereo frames per step per GPU (256 images: one selection workgroup per CU)")
+    ap.add_argument("--batch", type=int, default=256, help="stereo frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the batch is split over (128 frames = 256 images per launch: one selection workgroup per CU)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs per rank")
     ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -79,21 +84,29 @@ def main():
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("VSL_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; "gloo" for rehearsals
     vdist.init(backend)  # a no-op at world size 1
-    B = args.batch
-    n_img = 2 * B
+    B, S = args.batch, args.streams
+    if S < 1 or B % S:
+        raise SystemExit("--batch must be a multiple of --streams")
+    Bu = B // S          # stereo frames per launch
+    n_img = 2 * Bu       # images per launch
 
-    stream = torch.cuda.Stream()
-    ctx = vsl.Context(local_rank, stream=stream.cuda_stream)
-    frames = vsl.Frames(ctx, n_img, W, H, NUM_FEATURES, max_pairs=B)
     pairs_img = [synth.stereo_pair(seed) for seed in vdist.stream_seeds(rank, args.distinct)]
-    batch = np.stack([pairs_img[(k // 2) % args.distinct][k % 2] for k in range(n_img)])
-    frames.upload(0, batch)  # inputs resident in HBM before the timed region
-    slot_pairs = np.array([[2 * k, 2 * k + 1] for k in range(B)], np.int32)
+    slot_pairs = np.array([[2 * k, 2 * k + 1] for k in range(Bu)], np.int32)
+    units = []  # one (stream, context, frame store) per HIP stream; inputs resident in HBM before the timed region
+    for u in range(S):
+        stream = torch.cuda.Stream()
+        ctx = vsl.Context(local_rank, stream=stream.cuda_stream)
+        frames = vsl.Frames(ctx, n_img, W, H, NUM_FEATURES, max_pairs=Bu)
+        batch = np.stack([pairs_img[(u * Bu + k // 2) % args.distinct][k % 2] for k in range(n_img)])
+        frames.upload(0, batch)
+        units.append((stream, ctx, frames))
 
     def step():
-        frames.detect_describe(0, n_img, NUM_FEATURES, True)
-        frames.resolve_ties()
-        frames.match(slot_pairs, 70, 1.2)
+        for _, _, frames in units:
+            frames.detect_describe(0, n_img, NUM_FEATURES, True)
+        for _, _, frames in units:
+            frames.resolve_ties()
+            frames.match(slot_pairs, 70, 1.2)
 
     def barrier():
         vdist.barrier()
@@ -108,7 +121,10 @@ def main():
     barrier()
     elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
 
-    nk, nm = frames.counts(n_img, B)
+    counts = [frames.counts(n_img, Bu) for _, _, frames in units]
+    nk = np.concatenate([c[0] for c in counts])
+    nm = np.concatenate([c[1] for c in counts])
+    ctx, frames = units[0][1], units[0][2]
     if not (nk.min() > 0 and nm.min() > 0):
         raise SystemExit("benchmark produced empty outputs: keypoints %s matches %s" % (nk.min(), nm.min()))
 
@@ -123,33 +139,53 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic 752x480 stereo, 1500 feats/frame (BASELINE configs[1]); "
                                    "independent streams per GPU (configs[3])",
-                       "stereo_frames_per_step_per_gpu": B, "num_features": NUM_FEATURES,
+                       "stereo_frames_per_step_per_gpu": B, "hip_streams": S, "stereo_frames_per_launch": Bu,
+                       "num_features": NUM_FEATURES,
                        "match": "threshold 70, ratio 1.2, cross-check",
                        "mean_keypoints_per_image": round(float(nk.mean()), 1),
                        "mean_matches_per_pair": round(float(nm.mean()), 1)},
         }
 
-        # ---- per-stage device time (HIP events on the kernels' stream), outside the timed region
-        ctx.set_profiling(True)
-        ctx.reset_profiling()
-        for _ in range(args.profile_steps):
-            step()
-        st = ctx.stage_ms()
-        ctx.set_profiling(False)
-        stages = {k: (ms / max(n, 1)) for k, (ms, n) in st.items() if n > 0}
+        # ---- per-stage device time, HIP events around every stage on the stream each kernel is launched on.
+        # Pass 1: one stream at a time (kernel durations in isolation -> roofline); pass 2: all streams active
+        # as in the timed region (durations stretch because kernels of different streams share the CUs).
+        def staged(fn):
+            for _, c, _ in units:
+                c.set_profiling(True)
+                c.reset_profiling()
+            for _ in range(args.profile_steps):
+                fn()
+            tot = {}
+            for _, c, _ in units:
+                for k, (ms, n) in c.stage_ms().items():
+                    a = tot.setdefault(k, [0.0, 0])
+                    a[0] += ms
+                    a[1] += n
+                c.set_profiling(False)
+            return {k: ms / n for k, (ms, n) in tot.items() if n > 0}   # average per launch (Bu frames)
+
+        def step_one_stream_at_a_time():
+            for _, c, fr in units:
+                fr.detect_describe(0, n_img, NUM_FEATURES, True)
+                fr.resolve_ties()
+                fr.match(slot_pairs, 70, 1.2)
+                c.synchronize()
+
+        stages = staged(step_one_stream_at_a_time)
+        stages_overlapped = staged(step) if S > 1 else None
         dom = max(stages, key=stages.get)
-        # candidate counts for the byte model: read back once
-        kp_total, match_total = int(nk.sum()), int(nm.sum())
+        # counts for the byte model: read back once (unit 0 = one launch)
+        kp_total, match_total = int(counts[0][0].sum()), int(counts[0][1].sum())
         cand_total = int(frames.candidate_counts(n_img).sum())
         out["config"]["mean_candidates_per_image"] = round(cand_total / n_img, 1)
-        ab = stage_algorithmic_bytes(dom, n_img, B, kp_total, cand_total, match_total)
+        ab = stage_algorithmic_bytes(dom, n_img, Bu, kp_total, cand_total, match_total)
         achieved = ab / (stages[dom] * 1e-3) / 1e9
         # HBM traffic of that stage per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
         # uncorrected -- see profiles/r01_pmc_traffic.json); only valid for the batch size it was taken at
         traffic = None
         try:
             pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            if pm.get("batch_stereo_frames") == B and dom in pm["kernels"]:
+            if pm.get("batch_stereo_frames") == Bu and dom in pm["kernels"]:
                 traffic = pm["kernels"][dom]["bytes_per_launch_uncorrected"]
         except Exception:
             traffic = None
@@ -157,7 +193,9 @@ def main():
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(ab),
                            "avg_launch_ms": round(stages[dom], 5)}
-        out["stage_ms_per_step"] = {k: round(v, 5) for k, v in stages.items()}
+        out["stage_ms_per_launch"] = {k: round(v, 5) for k, v in stages.items()}
+        if stages_overlapped:
+            out["stage_ms_per_launch_streams_overlapped"] = {k: round(v, 5) for k, v in stages_overlapped.items()}
 
         # ---- CPU baseline: the oracle (port of the reference path), 1 core, bounded sample
         if args.cpu_frames > 0:
@@ -206,8 +244,9 @@ def main():
                                "cpu_threads": ncpu}
         print(json.dumps(out), flush=True)
 
-    frames.close()
-    ctx.close()
+    for _, c, f in units:
+        f.close()
+        c.close()
     vdist.barrier()
     if world > 1:
         import torch.distributed as dist

@@ -302,7 +302,7 @@ extern "C" int vsl_frames_download_candidate_counts(vsl_ctx* ctx, vsl_frames* f,
   std::vector<int32_t> m((size_t)n_images * VSL_META_STRIDE);
   VSL_HIP(ctx, hipMemcpyAsync(m.data(), f->meta, sizeof(int32_t) * m.size(), hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < n_images; i++) n_candidates[i] = m[(size_t)i * VSL_META_STRIDE + VSL_META_NCAND];
+  for (int i = 0; i < n_images; i++) n_candidates[i] = m[(size_t)i * VSL_META_STRIDE + VSL_META_NCAND_LAST];
   return VSL_OK;
 }
 

@@ -25,11 +25,23 @@ struct RowF {
   float rx, ry;
 };
 
-__device__ __forceinline__ RowF rowfilt(const uint8_t* __restrict__ img, int w, int yr, unsigned xm, unsigned xe,
-                                        unsigned xp, float s, float s2) {
-  // yr is wave-uniform: scalar row base + one 32-bit lane offset per load (saddr + voffset form)
+struct RowRaw {
+  unsigned l, m, r;
+};
+
+// yr is wave-uniform: scalar row base + one 32-bit lane offset per load
+__device__ __forceinline__ RowRaw rowload(const uint8_t* __restrict__ img, int w, int yr, unsigned xm, unsigned xe,
+                                          unsigned xp) {
   const uint8_t* __restrict__ row = img + (size_t)(unsigned)(yr * w);
-  const float l = (float)row[xm], m = (float)row[xe], r = (float)row[xp];
+  RowRaw o;
+  o.l = row[xm];
+  o.m = row[xe];
+  o.r = row[xp];
+  return o;
+}
+
+__device__ __forceinline__ RowF rowfilt(RowRaw p, float s, float s2) {
+  const float l = (float)p.l, m = (float)p.m, r = (float)p.r;
   RowF o;
   o.rx = r - l;
   float t = s * l;
@@ -139,7 +151,8 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     };
     Gen g0 = {0, 0, 0, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
     RowF f0, f1, f2;  // row filters of rows ye-1, ye, ye+1
-    int prev_ye = -100;
+    int prev_ye = -100, pre_row = -100;
+    RowRaw pre = {0u, 0u, 0u};
     float vmax = -3.0e38f;
     const int y_end = min(h, y0 + K1_ROWS);
     // one step: q = row whose row sums are produced into `cur`; `pm1`/`pm2` hold rows q-1 / q-2.
@@ -150,12 +163,16 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       if (ye == prev_ye + 1 && ye + 1 < h) {
         f0 = f1;
         f1 = f2;
-        f2 = rowfilt(img, w, ye + 1, xm, xe, xp, s, s2);
+        if (pre_row != ye + 1) pre = rowload(img, w, ye + 1, xm, xe, xp);  // scalar branch, not taken in steady state
+        f2 = rowfilt(pre, s, s2);
       } else {
-        f0 = rowfilt(img, w, reflect101(ye - 1, h), xm, xe, xp, s, s2);
-        f1 = rowfilt(img, w, ye, xm, xe, xp, s, s2);
-        f2 = rowfilt(img, w, reflect101(ye + 1, h), xm, xe, xp, s, s2);
+        f0 = rowfilt(rowload(img, w, reflect101(ye - 1, h), xm, xe, xp), s, s2);
+        f1 = rowfilt(rowload(img, w, ye, xm, xe, xp), s, s2);
+        f2 = rowfilt(rowload(img, w, reflect101(ye + 1, h), xm, xe, xp), s, s2);
       }
+      // bytes of the row the next step will filter: in flight during this step's arithmetic
+      pre_row = min(ye + 2, h - 1);
+      pre = rowload(img, w, pre_row, xm, xe, xp);
       prev_ye = ye;
       const float dx = (f0.rx + f2.rx) * s + f1.rx * s2;
       const float dy = f2.ry - f0.ry;
@@ -291,7 +308,7 @@ static_assert(SEL_LDS_BYTES <= 160 * 1024, "selection kernel LDS budget");
 // in a global scratch (grid_scratch, 3 words per cell per image, L2-resident) -- same algorithm, slower.
 template <bool GRID_GLOBAL>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __restrict__ cand_all,
-                                                             const int32_t* __restrict__ meta,
+                                                             int32_t* meta,
                                                              int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_count,
                                                              int w, int h, size_t cand_cap, int F, int first,
                                                              int num_features, int border, double quality,
@@ -299,7 +316,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   __shared__ __align__(16) unsigned char smem[GRID_GLOBAL ? (SEL_CHUNK * 8 + SEL_THREADS * 4 * 3 + 2048) : SEL_LDS_BYTES];
   const int slot = first + blockIdx.x;
   const uint64_t* __restrict__ cand = cand_all + (size_t)slot * cand_cap;
-  const int n_cand = min(meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], (int)cand_cap);
+  const int n_cand_raw = meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND];
+  const int n_cand = min(n_cand_raw, (int)cand_cap);
   const int gw = (w + 7) / 8, gh = (h + 7) / 8, cells = gw * gh;
   // LDS carve-up (all regions 8-byte aligned)
   uint64_t* keys = (uint64_t*)smem;                 // SEL_CHUNK sorted keys
@@ -521,7 +539,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
     hi = lo;
     remaining -= n_chunk;
   }
-  if (tid == 0) kp_count[slot] = n_out;
+  if (tid == 0) {
+    kp_count[slot] = n_out;
+    // every thread read MAX / NCAND before the first barrier: leave them reset for the next detect call
+    meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND_LAST] = n_cand_raw;
+    meta[(size_t)slot * VSL_META_STRIDE + VSL_META_MAX] = INT32_MIN;
+    meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND] = 0;
+  }
 }
 
 int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features) {
@@ -537,7 +561,9 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
   const int w = f->w, h = f->h;
   {
     VslStage st(ctx, VSL_STAGE_RESPONSE);
-    hipLaunchKernelGGL(detect_init_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f->meta, first, n);
+    if (f->detect_meta_dirty)
+      hipLaunchKernelGGL(detect_init_kernel, dim3((f->max_images + 255) / 256), dim3(256), 0, ctx->stream, f->meta, 0, f->max_images);
+    f->detect_meta_dirty = true;  // until the selection kernel (which resets the counters) is in the queue
     hipLaunchKernelGGL(min_eig_response_kernel, dim3((w + K1_COLS - 1) / K1_COLS, (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS), n),
                        dim3(256), 0, ctx->stream, f->images, f->response, f->meta, f->cand, f->cand_cap, w, h, first,
                        f->store_response ? 1 : 0, min(max(ctx->k1_list_cap, 0), K1_WLIST));
@@ -553,5 +579,6 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
                          f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, (uint32_t*)nullptr);
     VSL_CHECK_LAUNCH(ctx);
   }
+  f->detect_meta_dirty = false;
   return VSL_OK;
 }

@@ -17,6 +17,10 @@
 #define VSL_META_MAX 0      // order-preserving int encoding of the fp32 response maximum
 #define VSL_META_NCAND 1    // number of corner candidates
 #define VSL_META_NEXACT 3   // rBRIEF bits whose rotated coordinates need the exact (integer) rounding
+// MAX / NCAND / NEXACT are consumed and reset by the kernel that reads them (selection, exact bits), so a
+// detect / describe call needs no separate clearing launch; the last values stay readable here:
+#define VSL_META_NCAND_LAST 4
+#define VSL_META_NEXACT_LAST 5
 #define VSL_EXACT_CAP 16384 // capacity of that per-image list
 
 struct vsl_ctx {
@@ -108,6 +112,8 @@ struct vsl_frames {
   int32_t* tie_rec = nullptr;      // [tie_cap][4]  (slot, keypoint, bit, unused)
   int tie_cap = 0;
   bool ties_pending = false, ties_from_angles = false;
+  bool detect_meta_dirty = true;    // MAX / NCAND not in their reset state (first use, or a failed launch)
+  bool describe_meta_dirty = true;  // same for NEXACT
   bool exact_overflow_check = false;  // diagnostic (tests): verify no exact-rounding list overflowed
   bool store_response = false;  // K1 writes the fp32 response image only for the parity hook
   std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
