@@ -1,0 +1,396 @@
+// harness/odometry.h -- headless restatement of the reference's per-frame pipeline, i.e. the call order
+// of next_step() (src/slam.cpp:1087-1458) with the GUI, relocalisation and loop-closure branches left
+// out (enable_relocalization = enable_loop_closure = false), written against the SAME operator names the
+// reference calls: detectKeypointsAndDescriptors, matchDescriptors, project_landmarks,
+// find_matches_landmarks, bundle_adjustment -- here the MI355X drop-ins of include/visnav_amd/ -- plus the
+// host-side pieces the reference takes from OpenGV (harness/pnp.h) and its own small helpers:
+//   computeEssential / findInliersEssential   include/visnav/matching_utils.h:56-88
+//   localize_camera                           include/visnav/vo_utils.h:170-226
+//   add_new_landmarks                         include/visnav/vo_utils.h:228-322
+//   remove_old_keyframes                      include/visnav/vo_utils.h:324-380
+//   optimize() + the merge-back of its result src/slam.cpp:1510-1571, :1379-1412
+//   alignSVD / align_svd (ATE)                src/slam.cpp:1618-1722
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <set>
+#include <thread>
+#include <vector>
+
+#include "../bundle_adjustment.h"
+#include "../keypoints.h"
+#include "../vo_utils.h"
+#include "ate.h"
+#include "camera.h"
+#include "geometry.h"
+#include "io.h"
+#include "pnp.h"
+
+namespace visnav {
+namespace harness {
+
+struct OdometryOptions {  // defaults = the pangolin::Var defaults of src/slam.cpp:258-309
+  int num_features_per_image = 1500;
+  bool rotate_features = true;
+  int feature_match_max_dist = 70;
+  double feature_match_test_next_best = 1.2;
+  double match_max_dist_2d = 20.0;
+  int new_kf_min_inliers = 80;
+  int max_num_kfs = 10;
+  double cam_z_threshold = 0.1;
+  double reprojection_error_pnp_inlier_threshold_pixel = 3.0;
+  double reprojection_error_huber_pixel = 1.0;
+  int ba_max_iterations = 20;
+  int ba_verbose = 0;
+  bool async_ba = false;  // true: optimize() runs in its own thread like the reference (result depends on timing)
+};
+
+struct StageClock {
+  double detect_ms = 0, stereo_match_ms = 0, project_match_ms = 0, localize_ms = 0, map_ms = 0, ba_ms = 0;
+  int ba_runs = 0;
+};
+
+// non-owning pangolin::ManagedImage over a decoded image
+struct ImageRef {
+  pangolin::ManagedImage<uint8_t> img;
+  explicit ImageRef(const GreyImage& g) {
+    img.ptr = const_cast<uint8_t*>(g.px.data());
+    img.w = (size_t)g.w;
+    img.h = (size_t)g.h;
+    img.pitch = (size_t)g.w;
+  }
+  ~ImageRef() { img.ptr = nullptr; }
+};
+
+inline Vec3 unproject(const std::shared_ptr<AmdCameraD>& cam, const Eigen::Vector2d& p) {
+  return harness::unproject(camera_kind(cam->name()), cam->data(), p[0], p[1]);
+}
+inline Vec3 to_vec3(const Eigen::Vector3d& p) { return {p[0], p[1], p[2]}; }
+inline Eigen::Vector3d to_eigen(const Vec3& p) { return Eigen::Vector3d(p.x, p.y, p.z); }
+inline Pose to_pose(const Sophus::SE3d& T) { return pose_from7(T.data()); }
+inline Sophus::SE3d to_se3(const Pose& T) {
+  Sophus::SE3d r;
+  pose_to7(T, r.data());
+  return r;
+}
+
+// matching_utils.h:56-62
+inline Mat3 compute_essential(const Pose& T_0_1) { return skew(normalized(T_0_1.t)) * T_0_1.R; }
+
+// matching_utils.h:64-88
+inline void find_inliers_essential(const KeypointsData& kd1, const KeypointsData& kd2, const std::shared_ptr<AmdCameraD>& cam1,
+                                   const std::shared_ptr<AmdCameraD>& cam2, const Mat3& E, double epipolar_error_threshold,
+                                   MatchData& md) {
+  md.inliers.clear();
+  for (const auto& m : md.matches) {
+    const Vec3 p0 = unproject(cam1, kd1.corners[m.first]);
+    const Vec3 p1 = unproject(cam2, kd2.corners[m.second]);
+    const double err = dot(p0, E * p1);
+    if (!(std::fabs(err) > epipolar_error_threshold)) md.inliers.push_back(m);
+  }
+}
+
+// vo_utils.h:170-226
+inline void localize_camera(const Sophus::SE3d& current_pose, const std::shared_ptr<AmdCameraD>& cam, const KeypointsData& kdl,
+                            const Landmarks& landmarks, double reprojection_error_pnp_inlier_threshold_pixel,
+                            LandmarkMatchData& md, XorShift& rng) {
+  md.inliers.clear();
+  md.T_w_c = current_pose;  // default to previous pose if not enough inliers
+  if (md.matches.size() < 10) return;
+  std::vector<Vec3> points, bearings;
+  for (const auto& kv : md.matches) {
+    points.push_back(to_vec3(landmarks.at(kv.second).p));
+    bearings.push_back(unproject(cam, kdl.corners[kv.first]));
+  }
+  const double threshold = 1.0 - std::cos(std::atan(reprojection_error_pnp_inlier_threshold_pixel / 500.0));
+  RansacResult rr = ransac_p3p(bearings, points, threshold, rng);
+  if (!rr.ok) return;
+  const Pose refined = refine_pose(rr.T_w_c, bearings, points, rr.inliers);
+  md.T_w_c = to_se3(refined);
+  std::vector<int> inl;
+  select_within(refined, bearings, points, threshold, inl);
+  for (int i : inl) md.inliers.push_back(md.matches[i]);
+}
+
+// vo_utils.h:228-322
+inline void add_new_landmarks(const FrameCamId fcidl, const FrameCamId fcidr, const KeypointsData& kdl, const KeypointsData& kdr,
+                              const Calibration& calib_cam, const MatchData& md_stereo, const LandmarkMatchData& md,
+                              Landmarks& landmarks, TrackId& next_landmark_id) {
+  const Pose T_0_1 = inverse(to_pose(calib_cam.T_i_c[0])) * to_pose(calib_cam.T_i_c[1]);
+  const Pose T_w_c = to_pose(md.T_w_c);
+  std::map<FeatureId, FeatureId> stereo_of;  // left feature -> right feature (first inlier pair wins, like the linear scan)
+  for (const auto& s : md_stereo.inliers) stereo_of.emplace(s.first, s.second);
+  std::set<FeatureId> localized;
+  for (const auto& kv : md.inliers) {
+    const FeatureId f_id = kv.first;
+    const TrackId t_id = kv.second;
+    localized.insert(f_id);
+    auto it = landmarks.find(t_id);
+    if (it == landmarks.end()) continue;
+    Landmark& lm = it->second;
+    lm.modified = true;
+    lm.obs.emplace(fcidl, f_id);
+    lm.all_obs.emplace(fcidl, f_id);
+    auto st = stereo_of.find(f_id);
+    if (st != stereo_of.end()) {
+      lm.obs.emplace(fcidr, st->second);
+      lm.all_obs.emplace(fcidr, st->second);
+    }
+  }
+  for (const auto& kv : md_stereo.inliers) {
+    const FeatureId f_idl = kv.first, f_idr = kv.second;
+    if (localized.count(f_idl)) continue;  // already attached to an existing landmark
+    const Vec3 b1 = unproject(calib_cam.intrinsics[fcidl.cam_id], kdl.corners.at(f_idl));
+    const Vec3 b2 = unproject(calib_cam.intrinsics[fcidr.cam_id], kdr.corners.at(f_idr));
+    const Vec3 p_c = triangulate_midpoint(b1, b2, T_0_1.R, T_0_1.t);
+    Landmark l;
+    l.p = to_eigen(T_w_c * p_c);
+    l.p_c = to_eigen(inverse(T_w_c) * (T_w_c * p_c));
+    l.from_fcid = fcidl;
+    l.active = true;
+    l.obs.emplace(fcidl, f_idl);
+    l.obs.emplace(fcidr, f_idr);
+    l.all_obs.emplace(fcidl, f_idl);
+    l.all_obs.emplace(fcidr, f_idr);
+    landmarks.emplace(next_landmark_id, l);
+    next_landmark_id++;
+  }
+}
+
+// vo_utils.h:324-380
+inline void remove_old_keyframes(const FrameCamId fcidl, const int max_num_kfs, Cameras& cameras, Landmarks& landmarks,
+                                 std::set<FrameId>& kf_frames) {
+  kf_frames.emplace(fcidl.frame_id);
+  while ((int)kf_frames.size() > max_num_kfs) {
+    const FrameId kf_id = *kf_frames.begin();
+    kf_frames.erase(kf_frames.begin());
+    const FrameCamId removed[2] = {FrameCamId(kf_id, 0), FrameCamId(kf_id, 1)};
+    for (const auto& fcid : removed) {
+      cameras.at(fcid).modified = true;
+      cameras.at(fcid).active = false;
+    }
+    for (auto& tid_lm : landmarks)
+      for (const auto& fcid : removed)
+        if (tid_lm.second.obs.count(fcid)) {
+          tid_lm.second.modified = true;
+          tid_lm.second.obs.erase(fcid);
+        }
+  }
+  for (auto& tid_lm : landmarks) {
+    if (tid_lm.second.obs.size() == 0) {
+      tid_lm.second.modified = true;
+      tid_lm.second.active = false;
+    } else {
+      tid_lm.second.active = true;
+    }
+  }
+}
+
+class Odometry {
+ public:
+  Odometry(const Calibration& calib, const OdometryOptions& options) : calib_cam(calib), opt(options) {
+    T_0_1 = inverse(to_pose(calib_cam.T_i_c[0])) * to_pose(calib_cam.T_i_c[1]);
+  }
+  ~Odometry() {
+    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+  }
+
+  // ---- state, with the names of src/slam.cpp
+  Calibration calib_cam;
+  OdometryOptions opt;
+  Corners feature_corners;
+  Cameras cameras;
+  Landmarks landmarks;
+  std::set<FrameId> kf_frames;
+  TrackId next_landmark_id = 0;
+  Sophus::SE3d current_pose;
+  bool take_keyframe = true;
+  int current_frame = 0;
+  FrameCamId last_kf_fcid;
+  std::vector<Sophus::SE3d> frame_poses;  // T_w_c of every processed frame (for inspection)
+  StageClock clock;
+  int last_inliers = 0, last_matches = 0;
+
+  // One step of the pipeline on the stereo pair of frame `current_frame` (the right image is only
+  // looked at on keyframes).
+  void next_step(const GreyImage& img_left, const GreyImage& img_right) {
+    typedef std::chrono::steady_clock Clk;
+    auto ms = [](Clk::time_point a, Clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const FrameCamId fcidl(current_frame, 0), fcidr(current_frame, 1);
+    std::vector<Eigen::Vector2d, Eigen::aligned_allocator<Eigen::Vector2d>> projected_points;
+    std::vector<TrackId> projected_track_ids;
+    LandmarkMatchData md;
+    if (take_keyframe) {
+      take_keyframe = false;
+      auto t0 = Clk::now();
+      project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
+                        projected_track_ids);
+      auto t1 = Clk::now();
+      MatchData md_stereo;
+      KeypointsData kdl, kdr;
+      {
+        ImageRef l(img_left), r(img_right);
+        detectKeypointsAndDescriptors(l.img, kdl, opt.num_features_per_image, opt.rotate_features);
+        detectKeypointsAndDescriptors(r.img, kdr, opt.num_features_per_image, opt.rotate_features);
+      }
+      auto t2 = Clk::now();
+      md_stereo.T_i_j = to_se3(T_0_1);
+      const Mat3 E = compute_essential(T_0_1);
+      matchDescriptors(kdl.corner_descriptors, kdr.corner_descriptors, md_stereo.matches, opt.feature_match_max_dist,
+                       opt.feature_match_test_next_best);
+      find_inliers_essential(kdl, kdr, calib_cam.intrinsics[0], calib_cam.intrinsics[1], E, 1e-3, md_stereo);
+      auto t3 = Clk::now();
+      feature_corners[fcidl] = kdl;
+      feature_corners[fcidr] = kdr;
+      find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
+                             opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
+      auto t4 = Clk::now();
+      localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md,
+                      rng);
+      current_pose = md.T_w_c;
+      auto t5 = Clk::now();
+      add_new_landmarks(fcidl, fcidr, kdl, kdr, calib_cam, md_stereo, md, landmarks, next_landmark_id);
+      Camera cam_left, cam_right;
+      cam_left.T_w_c = current_pose;
+      cam_left.active = true;
+      cam_left.last_fcid = last_kf_fcid;
+      cam_right.T_w_c = to_se3(to_pose(current_pose) * T_0_1);
+      cam_right.active = true;
+      cameras[fcidl] = cam_left;
+      cameras[fcidr] = cam_right;
+      remove_old_keyframes(fcidl, opt.max_num_kfs, cameras, landmarks, kf_frames);
+      auto t6 = Clk::now();
+      optimize();
+      auto t7 = Clk::now();
+      current_pose = cameras[fcidl].T_w_c;
+      last_kf_fcid = fcidl;
+      clock.project_match_ms += ms(t0, t1) + ms(t3, t4);
+      clock.detect_ms += ms(t1, t2);
+      clock.stereo_match_ms += ms(t2, t3);
+      clock.localize_ms += ms(t4, t5);
+      clock.map_ms += ms(t5, t6);
+      clock.ba_ms += ms(t6, t7);
+    } else {
+      auto t0 = Clk::now();
+      project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
+                        projected_track_ids);
+      auto t1 = Clk::now();
+      KeypointsData kdl;
+      {
+        ImageRef l(img_left);
+        detectKeypointsAndDescriptors(l.img, kdl, opt.num_features_per_image, opt.rotate_features);
+      }
+      auto t2 = Clk::now();
+      feature_corners[fcidl] = kdl;
+      find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
+                             opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
+      auto t3 = Clk::now();
+      localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md,
+                      rng);
+      current_pose = md.T_w_c;
+      auto t4 = Clk::now();
+      if ((int)md.inliers.size() < opt.new_kf_min_inliers && !opt_running && !opt_finished) take_keyframe = true;
+      if (!opt_running && opt_finished) merge_optimized();
+      auto t5 = Clk::now();
+      clock.project_match_ms += ms(t0, t1) + ms(t2, t3);
+      clock.detect_ms += ms(t1, t2);
+      clock.localize_ms += ms(t3, t4);
+      clock.map_ms += ms(t4, t5);
+    }
+    last_inliers = (int)md.inliers.size();
+    last_matches = (int)md.matches.size();
+    frame_poses.push_back(current_pose);
+    current_frame++;
+  }
+
+  // Wait for a running optimisation and merge it (end of sequence).
+  void finish() {
+    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    if (opt_finished) merge_optimized();
+  }
+
+  // src/slam.cpp:1712-1722: keyframe positions of the left camera in the body frame vs ground truth
+  double ate(const std::vector<int64_t>& timestamps, const std::vector<int64_t>& gt_t_ns, const std::vector<Vec3>& gt_t_w_i,
+             int* n_assoc = nullptr) const {
+    std::vector<int64_t> est_t_ns;
+    std::vector<Vec3> est_t_w_i;
+    const Pose T_c_i = inverse(to_pose(calib_cam.T_i_c[0]));
+    for (const auto& kv : cameras)
+      if (kv.first.cam_id == 0) {
+        est_t_w_i.push_back((to_pose(kv.second.T_w_c) * T_c_i).t);
+        est_t_ns.push_back(timestamps[(size_t)kv.first.frame_id]);
+      }
+    return align_svd(est_t_ns, est_t_w_i, gt_t_ns, gt_t_w_i, n_assoc);
+  }
+
+ private:
+  Pose T_0_1;
+  XorShift rng;
+  Cameras cameras_opt;
+  Landmarks landmarks_opt;
+  Corners corners_opt;  // keypoint positions of the active cameras, private to the optimisation thread
+  Calibration calib_cam_opt;
+  std::atomic<bool> opt_running{false}, opt_finished{false};
+  std::unique_ptr<std::thread> opt_thread;
+
+  // src/slam.cpp:1510-1571
+  void optimize() {
+    cameras_opt.clear();
+    landmarks_opt.clear();
+    corners_opt.clear();
+    for (const auto& kv : landmarks)
+      if (kv.second.active) landmarks_opt.emplace(kv.first, kv.second);
+    for (const auto& kv : cameras)
+      if (kv.second.active) {
+        cameras_opt.emplace(kv.first, kv.second);
+        KeypointsData kd;
+        kd.corners = feature_corners.at(kv.first).corners;
+        corners_opt[kv.first] = kd;
+      }
+    const FrameId fid = *kf_frames.begin();
+    BundleAdjustmentOptions ba_options;
+    ba_options.optimize_intrinsics = false;
+    ba_options.use_huber = true;
+    ba_options.huber_parameter = opt.reprojection_error_huber_pixel;
+    ba_options.max_num_iterations = opt.ba_max_iterations;
+    ba_options.verbosity_level = opt.ba_verbose;
+    calib_cam_opt = calib_cam;
+    opt_running = true;
+    clock.ba_runs++;
+    auto work = [this, fid, ba_options] {
+      const std::set<FrameCamId> fixed_cameras = {FrameCamId(fid, 0), FrameCamId(fid, 1)};
+      bundle_adjustment(corners_opt, ba_options, fixed_cameras, calib_cam_opt, cameras_opt, landmarks_opt);
+      opt_finished = true;
+      opt_running = false;
+    };
+    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    if (opt.async_ba)
+      opt_thread.reset(new std::thread(work));
+    else
+      work();
+  }
+
+  // src/slam.cpp:1379-1412
+  void merge_optimized() {
+    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    for (const auto& kv : landmarks_opt) {
+      Landmark& lm = landmarks.at(kv.first);
+      lm = kv.second;
+      lm.modified = true;
+      const Camera& from = cameras_opt.count(lm.from_fcid) ? cameras_opt.at(lm.from_fcid) : cameras.at(lm.from_fcid);
+      lm.p_c = to_eigen(inverse(to_pose(from.T_w_c)) * to_vec3(lm.p));
+    }
+    for (const auto& kv : cameras_opt) {
+      cameras.at(kv.first) = kv.second;
+      cameras.at(kv.first).modified = true;
+    }
+    calib_cam = calib_cam_opt;
+    opt_finished = false;
+  }
+};
+
+}  // namespace harness
+}  // namespace visnav

@@ -1,0 +1,290 @@
+// harness/pnp.h -- host restatement of what the reference's per-frame pose estimation takes from OpenGV
+// [upstream, not in /root/reference: thirdparty/opengv is an empty submodule]:
+//   localize_camera  (include/visnav/vo_utils.h:170-226): AbsolutePoseSacProblem(KNEIP) + Ransac +
+//                    optimize_nonlinear + selectWithinDistance
+//   add_new_landmarks (:228-322): triangulation::triangulate for a calibrated stereo pair
+// Parity with the OpenGV binaries is UNPINNED (no OpenGV, no fixtures).  The algorithms are restated from
+// their published form: a minimal P3P solver (three law-of-cosine equations reduced to a quartic in the
+// ratio of two depths -- Grunert's formulation; any exact P3P has the same solution set as Kneip's), a
+// fourth point to pick the root, RANSAC with OpenGV's adaptive iteration count (p = 0.99, max 1000
+// iterations) on the score 1 - f_meas . f_reproj, Gauss-Newton refinement on the bearing-vector
+// residuals, and midpoint triangulation.  Sampling uses a fixed-seed generator so runs are reproducible
+// (OpenGV seeds from the clock).
+#pragma once
+#include <algorithm>
+#include <complex>
+#include <cstdint>
+#include <vector>
+
+#include "geometry.h"
+
+namespace visnav {
+namespace harness {
+
+// Real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (Durand-Kerner, then Newton polish).
+inline int solve_quartic_real(const double c[5], double roots[4]) {
+  typedef std::complex<double> C;
+  int deg = 4;
+  while (deg > 0 && std::fabs(c[deg]) < 1e-14 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + std::fabs(c[3]) + std::fabs(c[4]) + 1e-300)) deg--;
+  if (deg == 0) return 0;
+  double a[5];
+  for (int i = 0; i <= deg; i++) a[i] = c[i] / c[deg];
+  C z[4];
+  const C seed(0.4, 0.9);
+  C pw(1.0, 0.0);
+  for (int i = 0; i < deg; i++) {
+    z[i] = pw;
+    pw *= seed;
+  }
+  auto eval = [&](C x) {
+    C r(1.0, 0.0);
+    for (int i = deg - 1; i >= 0; i--) r = r * x + a[i];
+    return r;
+  };
+  for (int it = 0; it < 200; it++) {
+    double delta = 0;
+    for (int i = 0; i < deg; i++) {
+      C den(1.0, 0.0);
+      for (int j = 0; j < deg; j++)
+        if (j != i) den *= (z[i] - z[j]);
+      if (std::abs(den) < 1e-300) den = C(1e-300, 0);
+      const C d = eval(z[i]) / den;
+      z[i] -= d;
+      delta = std::max(delta, std::abs(d));
+    }
+    if (delta < 1e-15) break;
+  }
+  int n = 0;
+  for (int i = 0; i < deg; i++) {
+    if (std::fabs(z[i].imag()) > 1e-6 * (1.0 + std::fabs(z[i].real()))) continue;
+    double x = z[i].real();
+    for (int it = 0; it < 3; it++) {  // Newton polish on the real polynomial
+      double f = 1.0, df = 0.0;
+      for (int k = deg - 1; k >= 0; k--) {
+        df = df * x + f;
+        f = f * x + a[k];
+      }
+      if (std::fabs(df) < 1e-300) break;
+      x -= f / df;
+    }
+    roots[n++] = x;
+  }
+  return n;
+}
+
+// P3P: bearing vectors f[i] (unit, camera frame) of world points P[i].  Returns up to 4 poses T_w_c.
+inline int p3p(const Vec3 f[3], const Vec3 P[3], Pose out[4]) {
+  const double a2 = dot(P[1] - P[2], P[1] - P[2]), b2 = dot(P[0] - P[2], P[0] - P[2]), c2 = dot(P[0] - P[1], P[0] - P[1]);
+  if (a2 < 1e-18 || b2 < 1e-18 || c2 < 1e-18) return 0;
+  const double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
+  // s1, s2 = x s1, s3 = y s1 the depths along f1, f2, f3:
+  //   b2 (x^2 + y^2 - 2 x y ca) = a2 (1 + y^2 - 2 y cb),   b2 (1 + x^2 - 2 x cg) = c2 (1 + y^2 - 2 y cb)
+  // x is linear in their difference; substituting gives the quartic in y below (derived symbolically).
+  double A[5];
+  A[4] = a2 * a2 - 2 * a2 * b2 - 2 * a2 * c2 + b2 * b2 - 4 * b2 * c2 * ca * ca + 2 * b2 * c2 + c2 * c2;
+  A[3] = -4 * (a2 * a2 * cb - a2 * b2 * ca * cg - a2 * b2 * cb - 2 * a2 * c2 * cb + b2 * b2 * ca * cg - 2 * b2 * c2 * ca * ca * cb -
+               b2 * c2 * ca * cg + b2 * c2 * cb + c2 * c2 * cb);
+  A[2] = 2 * (2 * a2 * a2 * cb * cb + a2 * a2 - 4 * a2 * b2 * ca * cb * cg - 2 * a2 * b2 * cg * cg - 4 * a2 * c2 * cb * cb - 2 * a2 * c2 +
+              2 * b2 * b2 * ca * ca + 2 * b2 * b2 * cg * cg - b2 * b2 - 2 * b2 * c2 * ca * ca - 4 * b2 * c2 * ca * cb * cg +
+              2 * c2 * c2 * cb * cb + c2 * c2);
+  A[1] = -4 * (a2 * a2 * cb - a2 * b2 * ca * cg - 2 * a2 * b2 * cb * cg * cg + a2 * b2 * cb - 2 * a2 * c2 * cb + b2 * b2 * ca * cg -
+               b2 * c2 * ca * cg - b2 * c2 * cb + c2 * c2 * cb);
+  A[0] = a2 * a2 - 4 * a2 * b2 * cg * cg + 2 * a2 * b2 - 2 * a2 * c2 + b2 * b2 - 2 * b2 * c2 + c2 * c2;
+  double ys[4];
+  const int nr = solve_quartic_real(A, ys);
+  int n = 0;
+  for (int r = 0; r < nr && n < 4; r++) {
+    const double y = ys[r];
+    if (!(y > 0)) continue;
+    const double den = 2 * b2 * (ca * y - cg);
+    if (std::fabs(den) < 1e-12 * b2) continue;
+    const double x = (2 * a2 * cb * y - a2 * y * y - a2 + b2 * y * y - b2 - 2 * c2 * cb * y + c2 * y * y + c2) / den;
+    if (!(x > 0)) continue;
+    const double q = 1 + y * y - 2 * y * cb;
+    if (!(q > 0)) continue;
+    const double s1 = std::sqrt(b2 / q), s2 = x * s1, s3 = y * s1;
+    const Vec3 X[3] = {s1 * f[0], s2 * f[1], s3 * f[2]};  // the three points in the camera frame
+    // congruent triangles -> rotation from the two orthonormal frames they span
+    const Vec3 w1 = normalized(P[1] - P[0]);
+    const Vec3 w3 = normalized(cross(w1, P[2] - P[0]));
+    const Vec3 w2 = cross(w3, w1);
+    const Vec3 c1 = normalized(X[1] - X[0]);
+    const Vec3 c3v = cross(c1, X[2] - X[0]);
+    if (norm(c3v) < 1e-15) continue;
+    const Vec3 c3 = normalized(c3v);
+    const Vec3 c2v = cross(c3, c1);
+    const Mat3 R = Mat3::from_cols(w1, w2, w3) * transpose(Mat3::from_cols(c1, c2v, c3));  // R_w_c
+    out[n].R = R;
+    out[n].t = P[0] - R * X[0];
+    n++;
+  }
+  return n;
+}
+
+struct XorShift {  // fixed-seed sampler (OpenGV: rand() seeded from the clock)
+  uint64_t s;
+  explicit XorShift(uint64_t seed = 0x9E3779B97F4A7C15ull) : s(seed) {}
+  uint32_t next() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return (uint32_t)(s >> 32);
+  }
+  int below(int n) { return (int)(next() % (uint32_t)n); }
+};
+
+// score of OpenGV's AbsolutePoseSacProblem::getDistancesToModel: 1 - f_meas . normalize(R^T (P - t))
+inline double bearing_score(const Pose& T_w_c, const Vec3& f, const Vec3& P) {
+  const Vec3 q = transpose(T_w_c.R) * (P - T_w_c.t);
+  return 1.0 - dot(f, normalized(q));
+}
+
+inline void select_within(const Pose& T, const std::vector<Vec3>& f, const std::vector<Vec3>& P, double threshold,
+                          std::vector<int>& inliers) {
+  inliers.clear();
+  for (size_t i = 0; i < f.size(); i++)
+    if (bearing_score(T, f[i], P[i]) < threshold) inliers.push_back((int)i);
+}
+
+struct RansacResult {
+  bool ok = false;
+  Pose T_w_c;
+  std::vector<int> inliers;
+  int iterations = 0;
+};
+
+// Ransac<AbsolutePoseSacProblem(KNEIP)>::computeModel: 4-point samples (3 for P3P + 1 to pick the root).
+inline RansacResult ransac_p3p(const std::vector<Vec3>& f, const std::vector<Vec3>& P, double threshold, XorShift& rng,
+                               int max_iterations = 1000, double probability = 0.99) {
+  RansacResult res;
+  const int n = (int)f.size();
+  if (n < 4) return res;
+  int best = 0;
+  double k = 1.0;
+  const double log_p = std::log(1.0 - probability);
+  int skipped = 0;
+  const int max_skip = max_iterations * 10;
+  std::vector<int> inl;
+  while (res.iterations < k && skipped < max_skip && res.iterations < max_iterations) {
+    int id[4];
+    for (int i = 0; i < 4; i++) {
+      bool dup;
+      do {
+        id[i] = rng.below(n);
+        dup = false;
+        for (int j = 0; j < i; j++) dup = dup || id[j] == id[i];
+      } while (dup);
+    }
+    const Vec3 fs[3] = {f[id[0]], f[id[1]], f[id[2]]};
+    const Vec3 Ps[3] = {P[id[0]], P[id[1]], P[id[2]]};
+    Pose sol[4];
+    const int ns = p3p(fs, Ps, sol);
+    if (ns == 0) {
+      skipped++;
+      continue;
+    }
+    int pick = 0;
+    double pick_score = 1e300;
+    for (int s = 0; s < ns; s++) {
+      const double sc = bearing_score(sol[s], f[id[3]], P[id[3]]);
+      if (sc < pick_score) {
+        pick_score = sc;
+        pick = s;
+      }
+    }
+    select_within(sol[pick], f, P, threshold, inl);
+    if ((int)inl.size() > best) {
+      best = (int)inl.size();
+      res.T_w_c = sol[pick];
+      res.inliers = inl;
+      res.ok = true;
+      const double w = (double)best / n;
+      double p_no_outliers = 1.0 - std::pow(w, 4.0);
+      p_no_outliers = std::min(std::max(p_no_outliers, 1e-12), 1.0 - 1e-12);
+      k = log_p / std::log(p_no_outliers);
+    }
+    res.iterations++;
+  }
+  return res;
+}
+
+// optimize_nonlinear: Gauss-Newton over T <- T * exp(delta) on r_i = normalize(R^T (P_i - t)) - f_i.
+inline Pose refine_pose(const Pose& T0, const std::vector<Vec3>& f, const std::vector<Vec3>& P, const std::vector<int>& idx,
+                        int iterations = 10) {
+  Pose T = T0;
+  for (int it = 0; it < iterations; it++) {
+    double H[6][6] = {{0}}, g[6] = {0};
+    for (int i : idx) {
+      const Vec3 q = transpose(T.R) * (P[i] - T.t);
+      const double nq = norm(q);
+      if (nq < 1e-12) continue;
+      const Vec3 u = (1.0 / nq) * q;
+      const Vec3 r = u - f[i];
+      // du/dq = (I - u u^T) / |q|;  dq/d(upsilon) = -I,  dq/d(omega) = [q]x
+      double D[3][3];
+      const double uu[3] = {u.x, u.y, u.z};
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) D[a][b] = ((a == b ? 1.0 : 0.0) - uu[a] * uu[b]) / nq;
+      const Mat3 Q = skew(q);
+      double J[3][6];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          J[a][b] = -D[a][b];
+          J[a][3 + b] = D[a][0] * Q.m[0][b] + D[a][1] * Q.m[1][b] + D[a][2] * Q.m[2][b];
+        }
+      const double rr[3] = {r.x, r.y, r.z};
+      for (int a = 0; a < 6; a++) {
+        for (int b = 0; b < 6; b++) H[a][b] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];
+        g[a] += J[0][a] * rr[0] + J[1][a] * rr[1] + J[2][a] * rr[2];
+      }
+    }
+    // solve H d = -g (Gaussian elimination with partial pivoting; tiny damping for rank safety)
+    double M[6][7];
+    for (int a = 0; a < 6; a++) {
+      for (int b = 0; b < 6; b++) M[a][b] = H[a][b] + (a == b ? 1e-12 : 0.0);
+      M[a][6] = -g[a];
+    }
+    bool singular = false;
+    for (int c = 0; c < 6; c++) {
+      int piv = c;
+      for (int r2 = c + 1; r2 < 6; r2++)
+        if (std::fabs(M[r2][c]) > std::fabs(M[piv][c])) piv = r2;
+      if (std::fabs(M[piv][c]) < 1e-300) {
+        singular = true;
+        break;
+      }
+      if (piv != c)
+        for (int b = 0; b < 7; b++) std::swap(M[c][b], M[piv][b]);
+      for (int r2 = 0; r2 < 6; r2++) {
+        if (r2 == c) continue;
+        const double fct = M[r2][c] / M[c][c];
+        for (int b = c; b < 7; b++) M[r2][b] -= fct * M[c][b];
+      }
+    }
+    if (singular) break;
+    double d[6];
+    for (int a = 0; a < 6; a++) d[a] = M[a][6] / M[a][a];
+    const Vec3 ups(d[0], d[1], d[2]), om(d[3], d[4], d[5]);
+    // first-order translation (V(omega) ~ I for the small steps taken here)
+    T.t = T.t + T.R * ups;
+    T.R = T.R * exp_so3(om);
+    if (norm(ups) + norm(om) < 1e-12) break;
+  }
+  return T;
+}
+
+// Stereo triangulation: f1 in frame 1, f2 in frame 2, p_1 = R_1_2 p_2 + t_1_2; returns the point in
+// frame 1 (midpoint of the shortest segment between the two rays).
+inline Vec3 triangulate_midpoint(const Vec3& f1, const Vec3& f2, const Mat3& R_1_2, const Vec3& t_1_2) {
+  const Vec3 d1 = f1, d2 = R_1_2 * f2;
+  const double a = dot(d1, d1), b = dot(d1, d2), c = dot(d2, d2);
+  const double e = dot(d1, t_1_2), g = dot(d2, t_1_2);
+  const double den = a * c - b * b;
+  if (std::fabs(den) < 1e-18) return 1e6 * d1;  // parallel rays: a far point along the ray
+  const double l1 = (e * c - b * g) / den, l2 = (b * e - a * g) / den;
+  const Vec3 p1 = l1 * d1, p2 = t_1_2 + l2 * d2;
+  return 0.5 * (p1 + p2);
+}
+
+}  // namespace harness
+}  // namespace visnav

@@ -89,13 +89,24 @@ struct KeypointsData {
 using Corners = std::unordered_map<FrameCamId, KeypointsData, FrameCamIdHash>;  // tbb::concurrent_unordered_map upstream
 using FeatureTrack = std::map<FrameCamId, FeatureId>;
 
+// include/visnav/common_types.h:204-222 (graph / BoW members omitted: host bookkeeping outside the path)
 struct Camera {
   Sophus::SE3d T_w_c;
+  bool active = true;
+  FrameCamId last_fcid;
+  std::string img_path;
+  bool modified = false;
 };
+// include/visnav/common_types.h:228-252
 struct Landmark {
   Eigen::Vector3d p;
+  Eigen::Vector3d p_c;   // position in the frame of the camera that created it
+  FrameCamId from_fcid;
   FeatureTrack obs;      // inlier observations in the active window
   FeatureTrack all_obs;  // every observation (global BA)
+  FeatureTrack outlier_obs;
+  bool active = true;
+  bool modified = false;
 };
 using Cameras = std::map<FrameCamId, Camera>;
 using Landmarks = std::unordered_map<TrackId, Landmark>;
@@ -110,6 +121,12 @@ struct AbstractCameraD {
   const double* data() const { return param; }
   int width() const { return width_; }
   int height() const { return height_; }
+};
+// include/visnav/common_types.h:138-148
+struct MatchData {
+  Sophus::SE3d T_i_j;
+  std::vector<std::pair<FeatureId, FeatureId>> matches;
+  std::vector<std::pair<FeatureId, FeatureId>> inliers;
 };
 // include/visnav/common_types.h:150-160
 struct LandmarkMatchData {

@@ -1,0 +1,118 @@
+// slam_headless -- the reference's odometry loop without its GUI: load an EuRoC-layout dataset and a
+// calibration file (src/slam.cpp:1006-1079), call next_step for every frame (src/slam.cpp:1087-1458 via
+// include/visnav_amd/harness/odometry.h), report frames/s and the ATE against the dataset's ground truth
+// (src/slam.cpp:1618-1722) as one JSON line.  Every hot-path operator runs on the MI355X through
+// libvslam_hip.so; there is no CPU fallback.
+//
+//   slam_headless --dataset-path <dir with cam0/ cam1/ ...> --cam-calib <calib.json>
+//                 [--frames N] [--async-ba] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "visnav_amd/harness/odometry.h"
+
+using namespace visnav;
+using namespace visnav::harness;
+
+int main(int argc, char** argv) {
+  std::string dataset, calib_path, traj_path;
+  int max_frames = -1;
+  OdometryOptions opt;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto need = [&](const char* what) {
+      if (i + 1 >= argc) {
+        std::fprintf(stderr, "missing value for %s\n", what);
+        std::exit(2);
+      }
+      return std::string(argv[++i]);
+    };
+    if (a == "--dataset-path") dataset = need("--dataset-path");
+    else if (a == "--cam-calib") calib_path = need("--cam-calib");
+    else if (a == "--frames") max_frames = std::atoi(need("--frames").c_str());
+    else if (a == "--traj") traj_path = need("--traj");
+    else if (a == "--async-ba") opt.async_ba = true;
+    else if (a == "--kf-min-inliers") opt.new_kf_min_inliers = std::atoi(need("--kf-min-inliers").c_str());
+    else if (a == "--max-kfs") opt.max_num_kfs = std::atoi(need("--max-kfs").c_str());
+    else if (a == "--num-features") opt.num_features_per_image = std::atoi(need("--num-features").c_str());
+    else if (a == "--ba-verbose") opt.ba_verbose = 1;
+    else {
+      std::fprintf(stderr, "unknown argument %s\n", a.c_str());
+      return 2;
+    }
+  }
+  if (dataset.empty() || calib_path.empty()) {
+    std::fprintf(stderr, "usage: slam_headless --dataset-path DIR --cam-calib FILE [--frames N] [--async-ba] [--traj FILE]\n");
+    return 2;
+  }
+  Calibration calib;
+  if (!load_calibration(calib_path, calib)) {
+    std::fprintf(stderr, "could not load camera calibration %s\n", calib_path.c_str());  // src/slam.cpp:1056-1059
+    return 1;
+  }
+  EurocDataset ds;
+  if (!load_euroc(dataset, ds)) {
+    std::fprintf(stderr, "No dataset found in %s\n", dataset.c_str());
+    return 1;
+  }
+  int n_frames = (int)ds.timestamps.size();
+  if (max_frames > 0 && max_frames < n_frames) n_frames = max_frames;
+
+  typedef std::chrono::steady_clock Clk;
+  // decode every image up front so that the pipeline rate below is not a PNG-decoder benchmark; the
+  // decode time is reported separately
+  std::vector<GreyImage> left(n_frames), right(n_frames);
+  const auto d0 = Clk::now();
+  for (int i = 0; i < n_frames; i++) {
+    if (!load_image(ds.images.at(FrameCamId(i, 0)), left[i]) || !load_image(ds.images.at(FrameCamId(i, 1)), right[i])) {
+      std::fprintf(stderr, "could not read the images of frame %d (%s)\n", i, ds.images.at(FrameCamId(i, 0)).c_str());
+      return 1;
+    }
+  }
+  const double decode_s = std::chrono::duration<double>(Clk::now() - d0).count();
+
+  Odometry odo(calib, opt);
+  // one untimed warm-up call creates the device context and code objects
+  {
+    KeypointsData kd;
+    ImageRef l(left[0]);
+    detectKeypointsAndDescriptors(l.img, kd, opt.num_features_per_image, opt.rotate_features);
+  }
+  int n_kf = 0;
+  const auto t0 = Clk::now();
+  for (int i = 0; i < n_frames; i++) {
+    const bool kf = odo.take_keyframe;
+    odo.next_step(left[i], right[i]);
+    n_kf += kf ? 1 : 0;
+  }
+  odo.finish();
+  const double run_s = std::chrono::duration<double>(Clk::now() - t0).count();
+
+  int n_assoc = 0;
+  const double ate = odo.ate(ds.timestamps, ds.gt_t_ns, ds.gt_t_w_i, &n_assoc);
+  if (!traj_path.empty()) {
+    FILE* f = std::fopen(traj_path.c_str(), "w");
+    if (f) {
+      std::fprintf(f, "#timestamp,tx,ty,tz,qx,qy,qz,qw,keyframe\n");
+      for (int i = 0; i < (int)odo.frame_poses.size(); i++) {
+        const double* d = odo.frame_poses[i].data();
+        std::fprintf(f, "%lld,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%.9f,%d\n", (long long)ds.timestamps[i], d[4], d[5], d[6], d[0], d[1],
+                     d[2], d[3], odo.cameras.count(FrameCamId(i, 0)) ? 1 : 0);
+      }
+      std::fclose(f);
+    }
+  }
+  size_t n_active = 0;
+  for (const auto& kv : odo.landmarks) n_active += kv.second.active ? 1 : 0;
+  const StageClock& c = odo.clock;
+  std::printf(
+      "{\"frames\": %d, \"keyframes\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.3f, \"image_decode_s\": %.3f, "
+      "\"ate_rmse_m\": %.6f, \"ate_associations\": %d, \"landmarks\": %zu, \"active_landmarks\": %zu, \"async_ba\": %s, "
+      "\"stage_ms_total\": {\"detect\": %.1f, \"stereo_match\": %.1f, \"project_match\": %.1f, \"localize\": %.1f, \"map\": %.1f, "
+      "\"ba\": %.1f}, \"ba_runs\": %d}\n",
+      n_frames, n_kf, n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
+      opt.async_ba ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.ba_runs);
+  return 0;
+}
