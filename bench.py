@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-ba", dest="ba", action="store_false", help="skip the local-BA ms/iter measurement")
+    ap.add_argument("--no-e2e", dest="e2e", action="store_false",
+                    help="skip the single-stream end-to-end run of the headless next_step pipeline")
+    ap.add_argument("--e2e-frames", type=int, default=90)
     args = ap.parse_args()
 
     import torch
@@ -242,6 +245,30 @@ def main():
                                "final_cost_rel_diff_vs_oracle": abs(sg.final_cost - sc.final_cost) / sc.final_cost,
                                "cpu_oracle_ms_per_iter": round(cpu_ms / max(sc.iterations, 1), 3),
                                "cpu_threads": ncpu}
+        # ---- third metric: frames/s of ONE stream through the whole per-frame pipeline (the reference's
+        # next_step order: detect, stereo match, landmark projection + guided match on the GPU; P3P-RANSAC,
+        # triangulation and map bookkeeping on the host; local BA on the GPU) and its ATE on a rendered
+        # EuRoC-layout sequence -- a child process so that it owns its HIP context
+        exe = ROOT / "visual-slam_amd" / "slam_headless"
+        if args.e2e and exe.exists():
+            import subprocess
+            import tempfile
+            sq = importlib.import_module("visual_slam_amd.synth_sequence")
+            with tempfile.TemporaryDirectory(prefix="vsl_seq_") as d:
+                sq.render_sequence(d, n_frames=args.e2e_frames, seed=1, step_m=0.04, radius=1.6)
+                r = subprocess.run([str(exe), "--dataset-path", d, "--cam-calib", d + "/calib.json"],
+                                   capture_output=True, text=True, timeout=600)
+            if r.returncode == 0:
+                e = json.loads(r.stdout.strip().splitlines()[-1])
+                out["end_to_end_single_stream"] = {
+                    "workload": "rendered EuRoC-layout stereo sequence (textured room, double-sphere cameras), "
+                                "reference defaults (1500 features, new_kf_min_inliers 80, 10-keyframe window), "
+                                "synchronous local BA, images decoded up front",
+                    "frames": e["frames"], "keyframes": e["keyframes"], "frames_per_s": e["frames_per_s"],
+                    "ms_per_frame": e["ms_per_frame"], "ate_rmse_m": e["ate_rmse_m"],
+                    "stage_ms_total": e["stage_ms_total"]}
+            else:
+                out["end_to_end_single_stream"] = {"error": (r.stderr or r.stdout)[-300:]}
         print(json.dumps(out), flush=True)
 
     for _, c, f in units:
