@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
 #define SEL_THREADS 1024
 #define SEL_CHUNK 8192
 #define SEL_EMPTY 0xFFFFFFFFu
+#define SEL_MAX_BLOCKERS 6  // blockers of a candidate kept in registers (more: the cell lists are walked again)
 
 struct SelShared {
   int wave_tot[16];
@@ -490,32 +491,62 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       state[tid] = alive ? 0 : 2;
       if (alive) next[tid] = atomicExch((int*)&head[cell], tid);
       __syncthreads();
-      bool undecided = alive;
-      while (true) {
-        int ns = 0;
-        if (undecided) {
-          bool rej = false, blocked = false;
-          for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); yy++)
-            for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); xx++)
-              for (int u = head[yy * gw + xx]; u >= 0; u = next[u]) {
-                if (u < tid) {
-                  const uint32_t q = cxy[u];
-                  const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
-                  if (dx * dx + dy * dy < 64) {
-                    const int su = ((volatile int*)state)[u];
-                    rej = rej || (su == 1);
-                    blocked = blocked || (su == 0);
-                  }
+      // Blockers = higher-ranked survivors of this batch within the minimum distance.  A candidate is
+      // decided once all of them are: rejected if one was accepted, accepted otherwise.  The lowest
+      // undecided rank never waits, so free-running polling of the LDS state words terminates; no
+      // workgroup barrier per dependency level (all 16 waves are resident and keep being scheduled).
+      int nb = 0;
+      int blk[SEL_MAX_BLOCKERS];
+      if (alive) {
+        for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); yy++)
+          for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); xx++)
+            for (int u = head[yy * gw + xx]; u >= 0; u = next[u]) {
+              if (u < tid) {
+                const uint32_t q = cxy[u];
+                const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
+                if (dx * dx + dy * dy < 64) {
+                  if (nb < SEL_MAX_BLOCKERS) blk[nb] = u;
+                  nb++;
                 }
               }
-          ns = rej ? 2 : (blocked ? 0 : 1);
-        }
-        if (ns) {
-          ((volatile int*)state)[tid] = ns;
-          undecided = false;
-        }
-        if (__syncthreads_count(undecided) == 0) break;
+            }
       }
+      bool undecided = alive;
+      while (__ballot(undecided) != 0ull) {
+        if (undecided) {
+          bool rej = false, blocked = false;
+          if (nb <= SEL_MAX_BLOCKERS) {
+#pragma unroll
+            for (int k = 0; k < SEL_MAX_BLOCKERS; k++)
+              if (k < nb) {
+                const int su = ((volatile int*)state)[blk[k]];
+                rej = rej || (su == 1);
+                blocked = blocked || (su == 0);
+              }
+          } else {  // crowded neighbourhood: walk the cell lists again
+            for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); yy++)
+              for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); xx++)
+                for (int u = head[yy * gw + xx]; u >= 0; u = next[u]) {
+                  if (u < tid) {
+                    const uint32_t q = cxy[u];
+                    const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
+                    if (dx * dx + dy * dy < 64) {
+                      const int su = ((volatile int*)state)[u];
+                      rej = rej || (su == 1);
+                      blocked = blocked || (su == 0);
+                    }
+                  }
+                }
+          }
+          const int ns = rej ? 2 : (blocked ? 0 : 1);
+          if (ns) {
+            ((volatile int*)state)[tid] = ns;
+            undecided = false;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __syncthreads();
       const bool accepted = alive && state[tid] == 1;
       int total = 0;
       const int rank = n_acc + block_scan(accepted, sh->wave_tot, total);
