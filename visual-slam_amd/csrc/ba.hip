@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
                                                               const double* __restrict__ diag_l, double inv_radius,
                                                               int l_first, int l_count, double* __restrict__ S,
                                                               double* __restrict__ rhs, double* __restrict__ Pinv_out,
-                                                              double* __restrict__ bl_out) {
+                                                              double* __restrict__ bl_out, int lower_only) {
   constexpr int KM = 64;
   __shared__ double Ws[4][KM][18];
   __shared__ double Ys[4][KM][18];
@@ -645,7 +645,9 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
         const int q1 = item / (nb * 36), rem = item - q1 * (nb * 36);
         const int q2 = rem / 36, xy = rem - q2 * 36, x = xy / 6, y = xy - x * 6;
         const int c1 = cs[wave][q1], c2 = cam_free[obs_cam[qb + q2]];
-        if (c1 < 0 || c2 < 0) continue;
+        // lower_only: the Cholesky solve reads only the lower triangle -- blocks above the block diagonal
+        // are not accumulated (half the atomics); the diagonal blocks stay complete
+        if (c1 < 0 || c2 < 0 || (lower_only && c1 < c2)) continue;
         const double* y1 = &Ys[wave][q1][3 * x];
         const double* w2 = &Ws[wave][q2][3 * y];
         unsafeAtomicAdd(&S[(size_t)(6 * c1 + x) * n + 6 * c2 + y], -(y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2]));
@@ -1083,7 +1085,7 @@ int ba_columns(vsl_ctx* ctx, BaState& st) {
 }
 
 // Schur complement of the landmark blocks over landmarks [l0, l0+lc); damping when diag != null.
-int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc, bool keep_backsub) {
+int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc, bool keep_backsub, bool lower_only) {
   const BaDims& D = st.D;
   const int n = D.n;
   if (n == 0) return VSL_OK;
@@ -1110,7 +1112,8 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
     if (lc > 0)
       hipLaunchKernelGGL(ba_schur_atomic_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
-                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S.as<double>(), st.rhs.as<double>(), Pinv, bl);
+                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S.as<double>(), st.rhs.as<double>(), Pinv, bl,
+                         (lower_only && n > 128) ? 1 : 0);  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
     hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
                        st.H.as<double>(), st.g_c.as<double>(), dgc, inv_radius, st.S.as<double>(), st.rhs.as<double>());
   }
@@ -1222,7 +1225,7 @@ extern "C" int vsl_ba_linearize(vsl_ctx* ctx, const vsl_ba_problem* prob, const 
     VSL_CHECK_LAUNCH(ctx);
   }
   if ((rc = ba_columns(ctx, st))) return rc;
-  if ((rc = ba_schur(ctx, st, false, 1.0, l0, lc, false))) return rc;
+  if ((rc = ba_schur(ctx, st, false, 1.0, l0, lc, false, false))) return rc;
   double sc[1];
   if ((rc = read_scalars(ctx, st, sc, 1))) return rc;
   *cost = sc[0];
@@ -1291,7 +1294,7 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
     if (gmax <= 1e-10) { sum.termination = 2; break; }
     if (radius <= 1e-32) { sum.termination = 4; break; }
     iteration++;
-    if ((rc = ba_schur(ctx, st, true, radius, 0, D.L, true))) return rc;
+    if ((rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true))) return rc;
     bool ok = true;
     if ((rc = ba_solve(ctx, st, ok))) return rc;
     double model_change = 0, step_norm = 0, x_norm = 0;
@@ -1631,7 +1634,7 @@ extern "C" int vsl_ba_session_reduce_dev(vsl_ba_session* s, double radius, doubl
   VSL_CHECK_LAUNCH(ctx);
   // Schur with landmark damping only: reuse ba_schur with damping, but with a zero camera diagonal
   VSL_HIP(ctx, hipMemsetAsync(st.diag_c.p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), ctx->stream));
-  int rc = ba_schur(ctx, st, true, radius, 0, D.L, true);
+  int rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true);
   if (rc) return rc;
   if (n > 0) {
     VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
