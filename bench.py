@@ -37,6 +37,7 @@ import __graft_entry__ as entry  # noqa: E402
 
 W, H, NUM_FEATURES = 752, 480, 1500
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achievable)
+I8_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2x the 2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, MFMA table)
 
 
 def stage_algorithmic_bytes(stage, n_img, n_pairs, kp_total, cand_total, match_total):
@@ -196,6 +197,19 @@ def main():
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(ab),
                            "avg_launch_ms": round(stages[dom], 5)}
+        # the matcher is the one matrix-core kernel: int8 MACs of the padded Hamming tiles (queries padded to
+        # 128, database rows to 64, 256 bits each, both directions) against the dense int8 MFMA peak
+        if "match" in stages:
+            nk0 = counts[0][0].astype(np.int64)
+            macs = 0
+            for k in range(Bu):
+                a, b = int(nk0[2 * k]), int(nk0[2 * k + 1])
+                pad = lambda v, m: (v + m - 1) // m * m  # noqa: E731
+                macs += (pad(a, 128) * pad(b, 64) + pad(b, 128) * pad(a, 64)) * 256
+            tops = 2.0 * macs / (stages["match"] * 1e-3) / 1e12
+            out["roofline_matcher"] = {"bound": "mfma", "kernel": "match", "achieved": round(tops, 1), "peak": I8_PEAK_TOPS,
+                                       "unit": "TOP/s", "frac": round(tops / I8_PEAK_TOPS, 4),
+                                       "avg_launch_ms": round(stages["match"], 5)}
         out["stage_ms_per_launch"] = {k: round(v, 5) for k, v in stages.items()}
         if stages_overlapped:
             out["stage_ms_per_launch_streams_overlapped"] = {k: round(v, 5) for k, v in stages_overlapped.items()}

@@ -5,14 +5,13 @@
 //   add_new_landmarks (:228-322): triangulation::triangulate for a calibrated stereo pair
 // Parity with the OpenGV binaries is UNPINNED (no OpenGV, no fixtures).  The algorithms are restated from
 // their published form: a minimal P3P solver (three law-of-cosine equations reduced to a quartic in the
-// ratio of two depths -- Grunert's formulation; any exact P3P has the same solution set as Kneip's), a
+// ratio of two depths (solved in closed form: Ferrari + Newton polish) -- Grunert's formulation; any exact P3P has the same solution set as Kneip's), a
 // fourth point to pick the root, RANSAC with OpenGV's adaptive iteration count (p = 0.99, max 1000
 // iterations) on the score 1 - f_meas . f_reproj, Gauss-Newton refinement on the bearing-vector
 // residuals, and midpoint triangulation.  Sampling uses a fixed-seed generator so runs are reproducible
 // (OpenGV seeds from the clock).
 #pragma once
 #include <algorithm>
-#include <complex>
 #include <cstdint>
 #include <vector>
 
@@ -21,54 +20,108 @@
 namespace visnav {
 namespace harness {
 
-// Real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (Durand-Kerner, then Newton polish).
+// Largest real root of z^3 + A z^2 + B z + C (Cardano / trigonometric form, then Newton polish).
+inline double cubic_largest_real_root(double A, double B, double C) {
+  const double sh = A / 3.0;
+  const double p = B - A * A / 3.0, q = 2.0 * A * A * A / 27.0 - A * B / 3.0 + C;  // t^3 + p t + q, z = t - A/3
+  const double disc = q * q / 4.0 + p * p * p / 27.0;
+  double t;
+  if (disc > 0) {
+    const double sq = std::sqrt(disc);
+    t = std::cbrt(-q / 2.0 + sq) + std::cbrt(-q / 2.0 - sq);
+  } else if (p < 0) {
+    const double m = 2.0 * std::sqrt(-p / 3.0);
+    double arg = 3.0 * q / (p * m);
+    arg = arg < -1.0 ? -1.0 : (arg > 1.0 ? 1.0 : arg);
+    t = m * std::cos(std::acos(arg) / 3.0);  // k = 0 branch = the largest of the three real roots
+  } else {
+    t = 0.0;
+  }
+  double z = t - sh;
+  for (int it = 0; it < 4; it++) {
+    const double f = ((z + A) * z + B) * z + C, df = (3.0 * z + 2.0 * A) * z + B;
+    if (std::fabs(df) < 1e-300) break;
+    z -= f / df;
+  }
+  return z;
+}
+
+// Real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0: Ferrari's factorisation into two quadratics through
+// the resolvent cubic, every root polished with Newton steps on the original polynomial.
 inline int solve_quartic_real(const double c[5], double roots[4]) {
-  typedef std::complex<double> C;
-  int deg = 4;
-  while (deg > 0 && std::fabs(c[deg]) < 1e-14 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + std::fabs(c[3]) + std::fabs(c[4]) + 1e-300)) deg--;
-  if (deg == 0) return 0;
-  double a[5];
-  for (int i = 0; i <= deg; i++) a[i] = c[i] / c[deg];
-  C z[4];
-  const C seed(0.4, 0.9);
-  C pw(1.0, 0.0);
-  for (int i = 0; i < deg; i++) {
-    z[i] = pw;
-    pw *= seed;
-  }
-  auto eval = [&](C x) {
-    C r(1.0, 0.0);
-    for (int i = deg - 1; i >= 0; i--) r = r * x + a[i];
-    return r;
-  };
-  for (int it = 0; it < 200; it++) {
-    double delta = 0;
-    for (int i = 0; i < deg; i++) {
-      C den(1.0, 0.0);
-      for (int j = 0; j < deg; j++)
-        if (j != i) den *= (z[i] - z[j]);
-      if (std::abs(den) < 1e-300) den = C(1e-300, 0);
-      const C d = eval(z[i]) / den;
-      z[i] -= d;
-      delta = std::max(delta, std::abs(d));
-    }
-    if (delta < 1e-15) break;
-  }
+  const double scale = std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + std::fabs(c[3]) + std::fabs(c[4]);
+  if (!(scale > 0)) return 0;
   int n = 0;
-  for (int i = 0; i < deg; i++) {
-    if (std::fabs(z[i].imag()) > 1e-6 * (1.0 + std::fabs(z[i].real()))) continue;
-    double x = z[i].real();
-    for (int it = 0; it < 3; it++) {  // Newton polish on the real polynomial
-      double f = 1.0, df = 0.0;
-      for (int k = deg - 1; k >= 0; k--) {
-        df = df * x + f;
-        f = f * x + a[k];
-      }
+  auto polish = [&](double x) {
+    for (int it = 0; it < 3; it++) {
+      const double f = (((c[4] * x + c[3]) * x + c[2]) * x + c[1]) * x + c[0];
+      const double df = ((4.0 * c[4] * x + 3.0 * c[3]) * x + 2.0 * c[2]) * x + c[1];
       if (std::fabs(df) < 1e-300) break;
       x -= f / df;
     }
-    roots[n++] = x;
+    return x;
+  };
+  auto quadratic = [&](double b1, double b0, double shift) {  // y^2 + b1 y + b0 = 0, x = y + shift
+    const double d = b1 * b1 - 4.0 * b0;
+    if (d < 0) {
+      if (d > -1e-9 * (b1 * b1 + std::fabs(4.0 * b0) + 1e-300)) roots[n++] = polish(-0.5 * b1 + shift);  // double root
+      return;
+    }
+    const double sq = std::sqrt(d);
+    const double y1 = b1 >= 0 ? -0.5 * (b1 + sq) : -0.5 * (b1 - sq);  // the larger-magnitude root first
+    roots[n++] = polish(y1 + shift);
+    if (n < 4) roots[n++] = polish((y1 != 0.0 ? b0 / y1 : -b1 - y1) + shift);
+  };
+  if (std::fabs(c[4]) < 1e-14 * scale) {  // degenerate leading coefficient: cubic or lower -- bisection-free fallback
+    if (std::fabs(c[3]) < 1e-14 * scale) {
+      if (std::fabs(c[2]) < 1e-14 * scale) {
+        if (std::fabs(c[1]) < 1e-14 * scale) return 0;
+        roots[n++] = -c[0] / c[1];
+        return n;
+      }
+      const double b1 = c[1] / c[2], b0 = c[0] / c[2];
+      const double d = b1 * b1 - 4.0 * b0;
+      if (d < 0) return 0;
+      roots[n++] = 0.5 * (-b1 + std::sqrt(d));
+      roots[n++] = 0.5 * (-b1 - std::sqrt(d));
+      return n;
+    }
+    const double z = cubic_largest_real_root(c[2] / c[3], c[1] / c[3], c[0] / c[3]);
+    roots[n++] = z;  // deflate to a quadratic
+    const double A = c[2] / c[3], B = c[1] / c[3];
+    const double q1 = A + z, q0 = B + z * q1;
+    const double d = q1 * q1 - 4.0 * q0;
+    if (d >= 0) {
+      roots[n++] = 0.5 * (-q1 + std::sqrt(d));
+      roots[n++] = 0.5 * (-q1 - std::sqrt(d));
+    }
+    return n;
   }
+  const double a = c[3] / c[4], b = c[2] / c[4], cc = c[1] / c[4], d = c[0] / c[4];
+  const double a2 = a * a;
+  const double p = b - 0.375 * a2, q = cc - 0.5 * a * b + 0.125 * a2 * a;
+  const double r = d - 0.25 * a * cc + a2 * b / 16.0 - 3.0 * a2 * a2 / 256.0;
+  const double shift = -0.25 * a;
+  const double mag = std::fabs(p) + std::sqrt(std::fabs(r)) + 1e-300;
+  if (std::fabs(q) < 1e-12 * mag * std::sqrt(mag)) {  // biquadratic: y^4 + p y^2 + r
+    const double dd = p * p - 4.0 * r;
+    if (dd < 0) return 0;
+    const double sq = std::sqrt(dd);
+    const double u[2] = {0.5 * (-p + sq), 0.5 * (-p - sq)};
+    for (int k = 0; k < 2; k++)
+      if (u[k] >= 0 && n <= 2) {
+        const double y = std::sqrt(u[k]);
+        roots[n++] = polish(y + shift);
+        roots[n++] = polish(-y + shift);
+      }
+    return n;
+  }
+  // resolvent cubic z^3 + 2p z^2 + (p^2 - 4r) z - q^2 = 0 has a positive root (value at 0 is -q^2 < 0)
+  const double z = cubic_largest_real_root(2.0 * p, p * p - 4.0 * r, -q * q);
+  if (!(z > 0)) return 0;
+  const double sz = std::sqrt(z);
+  quadratic(sz, 0.5 * (p + z - q / sz), shift);
+  if (n <= 2) quadratic(-sz, 0.5 * (p + z + q / sz), shift);
   return n;
 }
 
@@ -234,10 +287,12 @@ inline Pose refine_pose(const Pose& T0, const std::vector<Vec3>& f, const std::v
         }
       const double rr[3] = {r.x, r.y, r.z};
       for (int a = 0; a < 6; a++) {
-        for (int b = 0; b < 6; b++) H[a][b] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];
+        for (int b = a; b < 6; b++) H[a][b] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];  // upper triangle
         g[a] += J[0][a] * rr[0] + J[1][a] * rr[1] + J[2][a] * rr[2];
       }
     }
+    for (int a = 0; a < 6; a++)
+      for (int b = 0; b < a; b++) H[a][b] = H[b][a];
     // solve H d = -g (Gaussian elimination with partial pivoting; tiny damping for rank safety)
     double M[6][7];
     for (int a = 0; a < 6; a++) {
@@ -268,7 +323,7 @@ inline Pose refine_pose(const Pose& T0, const std::vector<Vec3>& f, const std::v
     // first-order translation (V(omega) ~ I for the small steps taken here)
     T.t = T.t + T.R * ups;
     T.R = T.R * exp_so3(om);
-    if (norm(ups) + norm(om) < 1e-12) break;
+    if (norm(ups) + norm(om) < 1e-8) break;  // 10 nm / 1e-8 rad: far below the measurement noise
   }
   return T;
 }

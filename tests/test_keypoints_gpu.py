@@ -47,6 +47,20 @@ def test_detect_describe_bit_exact(ctx, orc, images, name, nf):
         assert len(xy) > 1000
 
 
+@pytest.mark.parametrize("w,h", [(40, 40), (41, 57), (59, 40), (60, 64), (61, 65), (121, 49), (333, 251), (640, 480), (753, 481)])
+def test_odd_image_sizes(ctx, orc, w, h):
+    # strip / tile edges of the response kernel (60 columns x 16 rows per wave, 4 waves per workgroup), the
+    # reflect-101 border rows and the row prefetch at the bottom edge, images smaller than one tile
+    rng = np.random.default_rng(w * 1000 + h)
+    base = rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8)).astype(np.float32)
+    img = np.kron(base, np.ones((8, 8), np.float32))[:h, :w]
+    img = np.clip(img + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+    assert np.array_equal(ctx.min_eig_response(img).view(np.uint32), orc.min_eig_response(img).view(np.uint32))
+    xy, ang, desc = ctx.detect_describe(img, 1500, True)
+    oxy, oang, odesc = orc.detect_describe(img, 1500, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(ang, oang) and np.array_equal(desc, odesc)
+
+
 def test_large_image_uses_global_grid(ctx, orc, synth):
     # 1280 x 720 = 14400 8x8 cells > 6144: the selection kernel keeps its per-cell arrays in global memory
     left, _ = synth.stereo_pair(41, w=1280, h=720, n_rects=7000)
