@@ -159,6 +159,7 @@ int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, const uint64_t
  * returns to the host until a download call.  All enqueue on ctx's stream.
  */
 typedef struct vsl_frames vsl_frames;
+typedef struct vsl_map vsl_map;
 
 int vsl_frames_create(vsl_ctx* ctx, int max_images, int w, int h, int max_features,
                       int max_pairs, vsl_frames** out);
@@ -210,6 +211,34 @@ int vsl_frames_download_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_
  * the first n_images slots produced in its last detect call -- the input size of the selection
  * stage, needed to price its traffic. */
 int vsl_frames_download_candidate_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_t* n_candidates);
+
+/* ------------------------------------------------ device-resident map (per-frame tracking) */
+/*
+ * The single-stream path: what project_landmarks + find_matches_landmarks (include/visnav/vo_utils.h:48-167)
+ * need stays in HBM between frames -- landmark positions, each landmark's list of observation descriptors,
+ * and the descriptor pool -- and a frame whose keypoints are already in a frame-store slot is tracked
+ * against it with ONE call (projection, compaction and guided matching chained on the stream); only the
+ * matches return.  Results are those of vsl_project_landmarks followed by vsl_find_matches_landmarks on
+ * the same landmark order.
+ *   pool:   descriptors of keyframe observations, append-only; appended from the host or copied
+ *           device-to-device out of a frame-store slot (feature_ids index that slot's keypoints).
+ *   table:  vsl_map_set_landmarks replaces the landmark table: n points (3 doubles each, in the order the
+ *           caller iterates its map -- that order is the order of the reference's loop, vo_utils.h:60) and
+ *           a CSR list of pool indices per landmark (obs_start[n+1], obs_pool_index[obs_start[n]]).
+ *   track:  pairs = (feature id in the slot, landmark index in the table), ascending feature id, capacity
+ *           2 * max_features int32; *n_projected (nullable) = landmarks that passed the visibility test.
+ */
+int vsl_map_create(vsl_ctx* ctx, int cap_landmarks, int cap_descriptors, vsl_map** out);
+void vsl_map_destroy(vsl_map* map);
+int vsl_map_append_descriptors(vsl_map* map, int n, const uint64_t* desc, int* first_index);
+int vsl_map_append_descriptors_from_frame(vsl_map* map, vsl_frames* f, int slot, int n, const int32_t* feature_ids,
+                                          int* first_index);
+int vsl_map_set_landmarks(vsl_map* map, int n, const double* points, const int32_t* obs_start,
+                          const int32_t* obs_pool_index);
+int vsl_map_info(const vsl_map* map, int* n_landmarks, int* n_observation_refs, int* n_descriptors);
+int vsl_map_track(vsl_map* map, vsl_frames* f, int slot, const double* pose7, int cam_model, const double* intr8, int width,
+                  int height, double cam_z_threshold, double match_max_dist_2d, int feature_match_threshold,
+                  double feature_match_dist_2_best, int32_t* pairs, int* n_pairs, int* n_projected);
 
 /* -------------------------------------------------------- bundle adjustment */
 /*

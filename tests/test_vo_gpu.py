@@ -96,3 +96,95 @@ def test_find_matches_empty(ctx):
     assert len(ctx.find_matches_landmarks(np.zeros((0, 2)), z, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(1, np.int32), z)) == 0
     assert len(ctx.find_matches_landmarks([[50.0, 50.0]], np.zeros((1, 4), np.uint64), np.zeros((0, 2)), np.zeros(0, np.int32),
                                           np.zeros(1, np.int32), z)) == 0
+
+
+def _frame_and_map_inputs(vsl, ctx, synth, seed, n_lms):
+    """A real frame in a frame-store slot + landmarks whose observation descriptors are partly noisy copies of
+    that frame's keypoint descriptors (so that matches exist), partly random."""
+    rng = np.random.default_rng(seed)
+    left, _ = synth.stereo_pair(seed)
+    fr = vsl.Frames(ctx, 2, 752, 480, 1500, max_pairs=1)
+    fr.upload(0, left)
+    fr.detect_describe(0, 1, 1500, True)
+    kp_xy, _, kp_desc = fr.keypoints(0)
+    # landmarks: points along the rays of random pixels at random depth, seen from a slightly moved pose
+    pose = np.array([0.01, -0.02, 0.005, 1.0, 0.03, -0.02, 0.01])
+    pose[:4] /= np.linalg.norm(pose[:4])
+    u = rng.uniform(-50, 802, n_lms)
+    v = rng.uniform(-50, 530, n_lms)
+    z = rng.uniform(-1.0, 8.0, n_lms)   # some behind the camera
+    fx, fy, cx, cy = INTR[1][:4]
+    pts_c = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], 1)
+    q = pose[:4]
+    R = np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[2] * q[3]), 2 * (q[0] * q[2] + q[1] * q[3])],
+                  [2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[0] * q[3])],
+                  [2 * (q[0] * q[2] - q[1] * q[3]), 2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+    points = pts_c @ R.T + pose[4:]
+    # observations
+    start, pool = [0], []
+    for j in range(n_lms):
+        k = int(rng.integers(0, 6))
+        for _ in range(k):
+            if len(kp_desc) and rng.random() < 0.6:
+                # a keypoint near the (pinhole) projection, with a few flipped bits
+                d2 = (kp_xy[:, 0] - u[j]) ** 2 + (kp_xy[:, 1] - v[j]) ** 2
+                src = kp_desc[int(np.argmin(d2))].copy()
+                for b in rng.integers(0, 256, int(rng.integers(0, 30))):
+                    src[b // 64] ^= np.uint64(1) << np.uint64(b % 64)
+                pool.append(src)
+            else:
+                pool.append(rng.integers(0, 2 ** 63, 4).astype(np.uint64))
+        start.append(len(pool))
+    pool = np.array(pool, np.uint64).reshape(-1, 4)
+    return fr, kp_xy, kp_desc, pose, points, np.array(start, np.int32), pool
+
+
+@pytest.mark.parametrize("seed,n_lms", [(3, 1), (4, 700), (5, 5000)])
+def test_map_track_equals_host_buffer_path(vsl, ctx, synth, seed, n_lms):
+    fr, kp_xy, kp_desc, pose, points, start, pool = _frame_and_map_inputs(vsl, ctx, synth, seed, n_lms)
+    model, intr = 1, INTR[1]
+    # host-buffer path (each step verified against the oracle by the tests above)
+    uv, idx = ctx.project_landmarks(pose, model, intr, 752, 480, points, 0.1)
+    exp = ctx.find_matches_landmarks(kp_xy, kp_desc, uv, idx, start, pool, 20.0, 70, 1.2)
+    # device-resident path
+    m = vsl.Map(ctx, 16, 16)   # tiny capacities: growth is part of the test
+    first = m.append_descriptors(pool[:len(pool) // 2])
+    assert first == 0
+    assert m.append_descriptors(pool[len(pool) // 2:]) == len(pool) // 2
+    m.set_landmarks(points, start, np.arange(len(pool), dtype=np.int32))
+    assert m.info() == (n_lms, len(pool), len(pool))
+    got, n_proj = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
+    assert n_proj == len(uv)
+    assert np.array_equal(got, exp)
+    if n_lms >= 700:
+        assert len(exp) > 20   # the fixture does produce matches
+    # tracking twice gives the same answer (scratch state is per call)
+    got2, _ = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
+    assert np.array_equal(got2, exp)
+    m.close()
+    fr.close()
+
+
+def test_map_descriptors_copied_from_a_frame_slot(vsl, ctx, synth):
+    fr, kp_xy, kp_desc, pose, points, start, pool = _frame_and_map_inputs(vsl, ctx, synth, 9, 50)
+    m = vsl.Map(ctx)
+    ids = np.array([5, 0, 17, len(kp_desc) - 1, 5], np.int32)
+    base = m.append_descriptors(pool)                      # host descriptors first
+    first = m.append_descriptors_from_frame(fr, 0, ids)    # then device-to-device copies
+    assert base == 0 and first == len(pool)
+    # landmarks placed exactly on those keypoints (pinhole rays at depth 2), one copied observation each:
+    # every one of them must match its own keypoint at distance 0
+    fx, fy, cx, cy = INTR[1][:4]
+    uvk = kp_xy[ids[:4]]
+    pts = np.stack([(uvk[:, 0] - cx) / fx * 2.0, (uvk[:, 1] - cy) / fy * 2.0, np.full(4, 2.0)], 1)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float64)
+    m.set_landmarks(pts, np.arange(5, dtype=np.int32), first + np.arange(4, dtype=np.int32))
+    got, n_proj = m.track(fr, 0, ident, 1, INTR[1], 752, 480, 0.1, 3.0, 70, 1.2)
+    assert n_proj == 4
+    assert sorted(map(tuple, got.tolist())) == sorted((int(ids[k]), k) for k in range(4))
+    with pytest.raises(Exception):
+        m.set_landmarks(pts, np.arange(5, dtype=np.int32), np.array([0, 1, 2, 10 ** 6], np.int32))
+    with pytest.raises(Exception):
+        m.append_descriptors_from_frame(fr, 0, np.array([99999], np.int32))
+    m.close()
+    fr.close()

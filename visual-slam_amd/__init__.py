@@ -493,3 +493,61 @@ class Frames:
                                                            nk.ctypes.data_as(i32p), int(n_pairs),
                                                            nm.ctypes.data_as(i32p)))
         return nk[:n_images].copy(), nm[:n_pairs].copy()
+
+
+class Map:
+    """vsl_map: device-resident landmark table + observation-descriptor pool (per-frame tracking)."""
+
+    def __init__(self, ctx, cap_landmarks=4096, cap_descriptors=16384):
+        self.ctx = ctx
+        hnd = C.c_void_p()
+        ctx._ck(ctx.L.vsl_map_create(ctx.h, int(cap_landmarks), int(cap_descriptors), C.byref(hnd)))
+        self.h = hnd
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.vsl_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def append_descriptors(self, desc):
+        desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 4)
+        first = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_map_append_descriptors(self.h, len(desc), desc.ctypes.data_as(u64p), C.byref(first)))
+        return first.value
+
+    def append_descriptors_from_frame(self, frames, slot, feature_ids):
+        ids = np.ascontiguousarray(feature_ids, np.int32)
+        first = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_map_append_descriptors_from_frame(self.h, frames.h, int(slot), len(ids),
+                                                                      ids.ctypes.data_as(i32p), C.byref(first)))
+        return first.value
+
+    def set_landmarks(self, points, obs_start, obs_pool_index):
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        obs_start = np.ascontiguousarray(obs_start, np.int32)
+        obs_pool_index = np.ascontiguousarray(obs_pool_index, np.int32)
+        self.ctx._ck(self.ctx.L.vsl_map_set_landmarks(self.h, len(points), points.ctypes.data_as(f64p),
+                                                      obs_start.ctypes.data_as(i32p), obs_pool_index.ctypes.data_as(i32p)))
+
+    def info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_map_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def track(self, frames, slot, pose7, model, intr8, width, height, cam_z_threshold=0.1, max_dist_2d=20.0, threshold=70,
+              dist_2_best=1.2):
+        pose7 = np.ascontiguousarray(pose7, np.float64)
+        intr8 = np.ascontiguousarray(intr8, np.float64)
+        pairs = np.zeros((frames.F, 2), np.int32)
+        n, npj = C.c_int32(), C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_map_track(self.h, frames.h, int(slot), pose7.ctypes.data_as(f64p), int(model),
+                                              intr8.ctypes.data_as(f64p), int(width), int(height), C.c_double(cam_z_threshold),
+                                              C.c_double(max_dist_2d), int(threshold), C.c_double(dist_2_best),
+                                              pairs.ctypes.data_as(i32p), C.byref(n), C.byref(npj)))
+        return pairs[:n.value].copy(), npj.value

@@ -131,11 +131,21 @@ __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restr
                                                            const int32_t* __restrict__ proj_lm, int n_proj,
                                                            const int32_t* __restrict__ lm_obs_start,
                                                            const uint64_t* __restrict__ obs_desc, double max_dist_2d,
-                                                           int threshold, double dist_2_best, int32_t* __restrict__ result) {
+                                                           int threshold, double dist_2_best, int32_t* __restrict__ result,
+                                                           const int32_t* __restrict__ kp_xy_i32,
+                                                           const int32_t* __restrict__ obs_index,
+                                                           const int32_t* __restrict__ n_kp_dev,
+                                                           const int32_t* __restrict__ n_proj_dev) {
+  // Device-resident callers (vsl_map_track) pass the keypoints of a frame store slot (int32 positions,
+  // count on the device), the number of projected landmarks on the device, and observation descriptors
+  // through an index into the map's descriptor pool; the host-buffer entry point passes none of them.
+  if (n_kp_dev) n_kp = *n_kp_dev;
+  if (n_proj_dev) n_proj = *n_proj_dev;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (k >= n_kp) return;  // wave-uniform
-  const double kx = kp_xy[2 * (size_t)k], ky = kp_xy[2 * (size_t)k + 1];
+  const double kx = kp_xy_i32 ? (double)kp_xy_i32[2 * (size_t)k] : kp_xy[2 * (size_t)k];
+  const double ky = kp_xy_i32 ? (double)kp_xy_i32[2 * (size_t)k + 1] : kp_xy[2 * (size_t)k + 1];
   uint32_t d[8];
   {
     const uint32_t* p = (const uint32_t*)(kp_desc + 4 * (size_t)k);
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restr
       const int o0 = lm_obs_start[l], o1 = lm_obs_start[l + 1];
       int best = 256;  // minimal_dist, vo_utils.h:116
       for (int o = o0 + lane; o < o1; o += 64) {
-        const uint32_t* od = (const uint32_t*)(obs_desc + 4 * (size_t)o);
+        const uint32_t* od = (const uint32_t*)(obs_desc + 4 * (size_t)(obs_index ? obs_index[o] : o));
         int dist = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) dist += __builtin_popcount(d[q] ^ od[q]);
@@ -310,7 +320,8 @@ extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, con
   VSL_HIP(ctx, hipMemcpyAsync(dplm, proj_lm, 4 * P, hipMemcpyHostToDevice, ctx->stream));
   VSL_HIP(ctx, hipMemcpyAsync(dstart, lm_obs_start, 4 * (L + 1), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(find_matches_kernel, dim3((n_kp + 3) / 4), dim3(256), 0, ctx->stream, dkxy, dkd, n_kp, dpuv, dplm, n_proj,
-                     dstart, dod, match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, dres);
+                     dstart, dod, match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, dres,
+                     (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
   hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, dres, n_kp, dpairs, dn);
   VSL_CHECK_LAUNCH(ctx);
   int32_t m = 0;
@@ -318,5 +329,237 @@ extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, con
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *n_out = m;
   if (m > 0) VSL_HIP(ctx, hipMemcpy(pairs, dpairs, 8 * (size_t)m, hipMemcpyDeviceToHost));
+  return VSL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-resident map: landmark positions, the per-landmark lists of observation descriptors and the
+// descriptor pool stay in HBM between frames; a frame is tracked against it with ONE call that chains
+// projection, compaction and guided matching on the context's stream and returns only the matches.
+// Same kernels, same results as vsl_project_landmarks + vsl_find_matches_landmarks on the same inputs
+// (tests/test_vo_gpu.py::test_map_track_equals_host_buffer_path).
+struct vsl_map {
+  vsl_ctx* ctx = nullptr;
+  int cap_lms = 0, cap_refs = 0, cap_pool = 0, cap_kp = 0;
+  int n_lms = 0, n_refs = 0, n_pool = 0;
+  double* points = nullptr;     // [cap_lms][3]
+  int32_t* obs_start = nullptr;  // [cap_lms + 1]
+  int32_t* obs_index = nullptr;  // [cap_refs] -> pool
+  uint64_t* pool = nullptr;      // [cap_pool][4]
+  // per-call scratch
+  double* uv = nullptr;       // [cap_lms][2]
+  double* out_uv = nullptr;   // [cap_lms][2]
+  int32_t* out_idx = nullptr;  // [cap_lms]
+  uint8_t* keep = nullptr;    // [cap_lms]
+  double* pose_intr = nullptr;  // 16 doubles
+  int32_t* counters = nullptr;  // [0] = n_proj, [1] = n_matches
+  int32_t* result = nullptr;    // [cap_kp]
+  int32_t* pairs = nullptr;     // [cap_kp][2]
+  int32_t* gather_ids = nullptr;  // [cap_kp]
+};
+
+namespace {
+
+template <class T>
+int map_grow(vsl_ctx* ctx, T** p, size_t old_n, size_t new_n) {
+  T* q = nullptr;
+  VSL_HIP(ctx, hipMalloc((void**)&q, sizeof(T) * (new_n ? new_n : 1)));
+  if (*p && old_n) VSL_HIP(ctx, hipMemcpyAsync(q, *p, sizeof(T) * old_n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (*p) {
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(*p);
+  }
+  *p = q;
+  return VSL_OK;
+}
+
+int map_reserve_lms(vsl_map* m, int n, int refs) {
+  vsl_ctx* ctx = m->ctx;
+  int rc;
+  if (n > m->cap_lms) {
+    const int c = n + n / 2 + 1024;
+    if ((rc = map_grow(ctx, &m->points, 0, 3 * (size_t)c))) return rc;
+    if ((rc = map_grow(ctx, &m->obs_start, 0, (size_t)c + 1))) return rc;
+    if ((rc = map_grow(ctx, &m->uv, 0, 2 * (size_t)c))) return rc;
+    if ((rc = map_grow(ctx, &m->out_uv, 0, 2 * (size_t)c))) return rc;
+    if ((rc = map_grow(ctx, &m->out_idx, 0, (size_t)c))) return rc;
+    if ((rc = map_grow(ctx, &m->keep, 0, (size_t)c))) return rc;
+    m->cap_lms = c;
+  }
+  if (refs > m->cap_refs) {
+    const int c = refs + refs / 2 + 4096;
+    if ((rc = map_grow(ctx, &m->obs_index, 0, (size_t)c))) return rc;
+    m->cap_refs = c;
+  }
+  return VSL_OK;
+}
+
+int map_reserve_pool(vsl_map* m, int n) {
+  if (n <= m->cap_pool) return VSL_OK;
+  const int c = n + n / 2 + 4096;
+  int rc = map_grow(m->ctx, &m->pool, 4 * (size_t)m->n_pool, 4 * (size_t)c);
+  if (rc) return rc;
+  m->cap_pool = c;
+  return VSL_OK;
+}
+
+int map_reserve_kp(vsl_map* m, int n) {
+  if (n <= m->cap_kp) return VSL_OK;
+  int rc;
+  if ((rc = map_grow(m->ctx, &m->result, 0, (size_t)n))) return rc;
+  if ((rc = map_grow(m->ctx, &m->pairs, 0, 2 * (size_t)n))) return rc;
+  if ((rc = map_grow(m->ctx, &m->gather_ids, 0, (size_t)n))) return rc;
+  m->cap_kp = n;
+  return VSL_OK;
+}
+
+__global__ void map_gather_desc_kernel(const uint64_t* __restrict__ frame_desc, const int32_t* __restrict__ ids, int n,
+                                       uint64_t* __restrict__ pool_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 4 * n) return;
+  pool_out[t] = frame_desc[4 * (size_t)ids[t >> 2] + (t & 3)];
+}
+
+}  // namespace
+
+extern "C" int vsl_map_create(vsl_ctx* ctx, int cap_landmarks, int cap_descriptors, vsl_map** out) {
+  if (!ctx || !out || cap_landmarks < 0 || cap_descriptors < 0) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_create: bad arguments");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  vsl_map* m = new vsl_map();
+  m->ctx = ctx;
+  int rc = map_reserve_lms(m, cap_landmarks > 0 ? cap_landmarks : 1, cap_descriptors > 0 ? cap_descriptors : 1);
+  if (!rc) rc = map_reserve_pool(m, cap_descriptors > 0 ? cap_descriptors : 1);
+  if (!rc) rc = map_grow(ctx, &m->pose_intr, 0, 16);
+  if (!rc) rc = map_grow(ctx, &m->counters, 0, 4);
+  if (rc) {
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return VSL_OK;
+}
+
+extern "C" void vsl_map_destroy(vsl_map* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->ctx->device);
+  void* ptrs[] = {m->points, m->obs_start, m->obs_index, m->pool, m->uv, m->out_uv, m->out_idx, m->keep,
+                  m->pose_intr, m->counters, m->result, m->pairs, m->gather_ids};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete m;
+}
+
+extern "C" int vsl_map_append_descriptors(vsl_map* m, int n, const uint64_t* desc, int* first_index) {
+  if (!m || n < 0 || (n > 0 && !desc) || !first_index) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = m->ctx;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = map_reserve_pool(m, m->n_pool + n);
+  if (rc) return rc;
+  *first_index = m->n_pool;
+  if (n > 0) {
+    VSL_HIP(ctx, hipMemcpyAsync(m->pool + 4 * (size_t)m->n_pool, desc, 32 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's buffer may go away
+  }
+  m->n_pool += n;
+  return VSL_OK;
+}
+
+extern "C" int vsl_map_append_descriptors_from_frame(vsl_map* m, vsl_frames* f, int slot, int n, const int32_t* feature_ids,
+                                                     int* first_index) {
+  if (!m || !f || n < 0 || (n > 0 && !feature_ids) || !first_index || slot < 0 || slot >= f->max_images) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = m->ctx;
+  for (int i = 0; i < n; i++)
+    if (feature_ids[i] < 0 || feature_ids[i] >= f->F) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_append_descriptors_from_frame: feature id %d out of range", feature_ids[i]);
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = map_reserve_pool(m, m->n_pool + n);
+  if (!rc) rc = map_reserve_kp(m, n > f->F ? n : f->F);
+  if (rc) return rc;
+  if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;  // the descriptors copied must be final
+  *first_index = m->n_pool;
+  if (n > 0) {
+    VSL_HIP(ctx, hipMemcpyAsync(m->gather_ids, feature_ids, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(map_gather_desc_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, ctx->stream,
+                       f->kp_desc + 4 * (size_t)slot * f->F, m->gather_ids, n, m->pool + 4 * (size_t)m->n_pool);
+    VSL_CHECK_LAUNCH(ctx);
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // feature_ids is the caller's
+  }
+  m->n_pool += n;
+  return VSL_OK;
+}
+
+extern "C" int vsl_map_set_landmarks(vsl_map* m, int n, const double* points, const int32_t* obs_start,
+                                     const int32_t* obs_pool_index) {
+  if (!m || n < 0 || (n > 0 && (!points || !obs_start))) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = m->ctx;
+  const int refs = n > 0 ? obs_start[n] : 0;
+  if (n > 0 && obs_start[0] != 0) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_set_landmarks: obs_start[0] must be 0");
+  for (int i = 0; i < n; i++)
+    if (obs_start[i + 1] < obs_start[i]) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_set_landmarks: obs_start not monotone at %d", i);
+  if (refs > 0 && !obs_pool_index) return VSL_ERR_INVALID;
+  for (int i = 0; i < refs; i++)
+    if (obs_pool_index[i] < 0 || obs_pool_index[i] >= m->n_pool)
+      return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_set_landmarks: descriptor index %d outside the pool (%d)", obs_pool_index[i], m->n_pool);
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = map_reserve_lms(m, n, refs);
+  if (rc) return rc;
+  if (n > 0) {
+    VSL_HIP(ctx, hipMemcpyAsync(m->points, points, 24 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    VSL_HIP(ctx, hipMemcpyAsync(m->obs_start, obs_start, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (refs) VSL_HIP(ctx, hipMemcpyAsync(m->obs_index, obs_pool_index, 4 * (size_t)refs, hipMemcpyHostToDevice, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  m->n_lms = n;
+  m->n_refs = refs;
+  return VSL_OK;
+}
+
+extern "C" int vsl_map_info(const vsl_map* m, int* n_landmarks, int* n_observation_refs, int* n_descriptors) {
+  if (!m) return VSL_ERR_INVALID;
+  if (n_landmarks) *n_landmarks = m->n_lms;
+  if (n_observation_refs) *n_observation_refs = m->n_refs;
+  if (n_descriptors) *n_descriptors = m->n_pool;
+  return VSL_OK;
+}
+
+extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* pose7, int cam_model, const double* intr8,
+                             int width, int height, double cam_z_threshold, double match_max_dist_2d,
+                             int feature_match_threshold, double feature_match_dist_2_best, int32_t* pairs, int* n_pairs,
+                             int* n_projected) {
+  if (!m || !f || !pose7 || !intr8 || !n_pairs || slot < 0 || slot >= f->max_images || cam_model < 0 || cam_model > 3)
+    return VSL_ERR_INVALID;
+  vsl_ctx* ctx = m->ctx;
+  *n_pairs = 0;
+  if (n_projected) *n_projected = 0;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = map_reserve_kp(m, f->F);
+  if (rc) return rc;
+  if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;  // descriptors of the slot must be final
+  const int n = m->n_lms;
+  if (n == 0) return VSL_OK;
+  double hp[16];
+  for (int i = 0; i < 7; i++) hp[i] = pose7[i];
+  hp[7] = 0;
+  for (int i = 0; i < 8; i++) hp[8 + i] = intr8[i];
+  VSL_HIP(ctx, hipMemcpyAsync(m->pose_intr, hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(project_landmarks_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->pose_intr, cam_model,
+                     m->pose_intr + 8, width, height, m->points, n, cam_z_threshold, m->uv, m->keep);
+  hipLaunchKernelGGL(compact_projection_kernel, dim3(1), dim3(1024), 0, ctx->stream, m->uv, m->keep, n, m->out_uv, m->out_idx,
+                     m->counters);
+  VSL_HIP(ctx, hipMemsetAsync(m->result, 0xFF, 4 * (size_t)f->F, ctx->stream));
+  hipLaunchKernelGGL(find_matches_kernel, dim3((f->F + 3) / 4), dim3(256), 0, ctx->stream, (const double*)nullptr,
+                     f->kp_desc + 4 * (size_t)slot * f->F, f->F, m->out_uv, m->out_idx, n, m->obs_start, m->pool,
+                     match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, m->result,
+                     f->kp_xy + 2 * (size_t)slot * f->F, m->obs_index, f->kp_count + slot, m->counters);
+  hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, m->result, f->F, m->pairs, m->counters + 1);
+  VSL_CHECK_LAUNCH(ctx);
+  int32_t cnt[2] = {0, 0};
+  VSL_HIP(ctx, hipMemcpyAsync(cnt, m->counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_projected) *n_projected = cnt[0];
+  *n_pairs = cnt[1];
+  if (cnt[1] > 0) {
+    if (!pairs) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_track: pairs is null");
+    VSL_HIP(ctx, hipMemcpy(pairs, m->pairs, 8 * (size_t)cnt[1], hipMemcpyDeviceToHost));
+  }
   return VSL_OK;
 }
