@@ -46,6 +46,12 @@ struct OdometryOptions {  // defaults = the pangolin::Var defaults of src/slam.c
   int ba_max_iterations = 20;
   int ba_verbose = 0;
   bool async_ba = false;  // true: optimize() runs in its own thread like the reference (result depends on timing)
+  // true: the per-frame device work goes through the device-resident frame store + map (include/vslam_hip.h
+  // "device-resident map"): the image is uploaded once, keypoints and descriptors stay in HBM, landmark
+  // projection + guided matching is ONE call, stereo matching runs slot against slot, and keyframe
+  // descriptors are copied device-to-device into the map's pool.  Same kernels, same matches, same
+  // trajectory as the operator-by-operator sequence (tests/test_headless_gpu.py); fewer PCIe round trips.
+  bool fused_tracking = false;
 };
 
 struct StageClock {
@@ -196,6 +202,8 @@ class Odometry {
   }
   ~Odometry() {
     if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    if (dev_map) vsl_map_destroy(dev_map);
+    if (dev_frames) vsl_frames_destroy(dev_frames);
   }
 
   // ---- state, with the names of src/slam.cpp
@@ -226,12 +234,15 @@ class Odometry {
     if (take_keyframe) {
       take_keyframe = false;
       auto t0 = Clk::now();
-      project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
-                        projected_track_ids);
+      if (!opt.fused_tracking)
+        project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
+                          projected_track_ids);
       auto t1 = Clk::now();
       MatchData md_stereo;
       KeypointsData kdl, kdr;
-      {
+      if (opt.fused_tracking) {
+        fused_detect(img_left, &img_right);
+      } else {
         ImageRef l(img_left), r(img_right);
         detectKeypointsAndDescriptors(l.img, kdl, opt.num_features_per_image, opt.rotate_features);
         detectKeypointsAndDescriptors(r.img, kdr, opt.num_features_per_image, opt.rotate_features);
@@ -239,14 +250,20 @@ class Odometry {
       auto t2 = Clk::now();
       md_stereo.T_i_j = to_se3(T_0_1);
       const Mat3 E = compute_essential(T_0_1);
-      matchDescriptors(kdl.corner_descriptors, kdr.corner_descriptors, md_stereo.matches, opt.feature_match_max_dist,
-                       opt.feature_match_test_next_best);
+      if (opt.fused_tracking) {
+        fused_track(md);  // before the downloads below: they synchronise the stream
+        fused_stereo(kdl, kdr, md_stereo);
+      } else {
+        matchDescriptors(kdl.corner_descriptors, kdr.corner_descriptors, md_stereo.matches, opt.feature_match_max_dist,
+                         opt.feature_match_test_next_best);
+      }
       find_inliers_essential(kdl, kdr, calib_cam.intrinsics[0], calib_cam.intrinsics[1], E, 1e-3, md_stereo);
       auto t3 = Clk::now();
       feature_corners[fcidl] = kdl;
       feature_corners[fcidr] = kdr;
-      find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
-                             opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
+      if (!opt.fused_tracking)
+        find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
+                               opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
       auto t4 = Clk::now();
       localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md,
                       rng);
@@ -262,6 +279,7 @@ class Odometry {
       cameras[fcidl] = cam_left;
       cameras[fcidr] = cam_right;
       remove_old_keyframes(fcidl, opt.max_num_kfs, cameras, landmarks, kf_frames);
+      if (opt.fused_tracking) fused_register_observations(fcidl, fcidr);
       auto t6 = Clk::now();
       optimize();
       auto t7 = Clk::now();
@@ -275,18 +293,27 @@ class Odometry {
       clock.ba_ms += ms(t6, t7);
     } else {
       auto t0 = Clk::now();
-      project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
-                        projected_track_ids);
+      if (!opt.fused_tracking)
+        project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
+                          projected_track_ids);
       auto t1 = Clk::now();
       KeypointsData kdl;
-      {
+      if (opt.fused_tracking) {
+        fused_detect(img_left, nullptr);
+      } else {
         ImageRef l(img_left);
         detectKeypointsAndDescriptors(l.img, kdl, opt.num_features_per_image, opt.rotate_features);
       }
       auto t2 = Clk::now();
-      feature_corners[fcidl] = kdl;
-      find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
-                             opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
+      if (opt.fused_tracking) {
+        fused_track(md);
+        fused_download_corners(0, kdl);
+        feature_corners[fcidl] = kdl;
+      } else {
+        feature_corners[fcidl] = kdl;
+        find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
+                               opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
+      }
       auto t3 = Clk::now();
       localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md,
                       rng);
@@ -389,6 +416,101 @@ class Odometry {
     }
     calib_cam = calib_cam_opt;
     opt_finished = false;
+    map_dirty = true;  // landmark positions moved
+  }
+
+  // ---- fused device path (OdometryOptions::fused_tracking)
+  vsl_frames* dev_frames = nullptr;  // slot 0 = left, slot 1 = right image of the current frame
+  vsl_map* dev_map = nullptr;
+  bool map_dirty = true;
+  std::vector<TrackId> table_ids;    // landmark table row -> TrackId
+  std::map<std::pair<FrameCamId, FeatureId>, int32_t> pool_index;  // keyframe observation -> descriptor pool entry
+
+  void fused_init(const GreyImage& img) {
+    if (dev_frames) return;
+    amd::check(vsl_frames_create(amd::ctx(), 2, img.w, img.h, opt.num_features_per_image, 1, &dev_frames), "vsl_frames_create");
+    amd::check(vsl_map_create(amd::ctx(), 8192, 32768, &dev_map), "vsl_map_create");
+  }
+
+  void fused_detect(const GreyImage& left, const GreyImage* right) {
+    fused_init(left);
+    vsl_ctx* c = amd::ctx();
+    amd::check(vsl_frames_upload(c, dev_frames, 0, 1, left.px.data(), (size_t)left.w, (size_t)left.w * left.h), "vsl_frames_upload");
+    if (right)
+      amd::check(vsl_frames_upload(c, dev_frames, 1, 1, right->px.data(), (size_t)right->w, (size_t)right->w * right->h),
+                 "vsl_frames_upload");
+    amd::check(vsl_frames_detect_describe(c, dev_frames, 0, right ? 2 : 1, opt.num_features_per_image, opt.rotate_features ? 1 : 0),
+               "vsl_frames_detect_describe");
+  }
+
+  // project_landmarks + find_matches_landmarks of the reference against the device-resident table
+  void fused_track(LandmarkMatchData& md) {
+    md.matches.clear();
+    if (map_dirty) {
+      std::vector<double> pts;
+      std::vector<int32_t> start(1, 0), idx;
+      table_ids.clear();
+      for (const auto& kv : landmarks) {  // the reference's iteration order defines the candidate order (vo_utils.h:60)
+        table_ids.push_back(kv.first);
+        pts.insert(pts.end(), kv.second.p.data(), kv.second.p.data() + 3);
+        for (const auto& ob : kv.second.all_obs) idx.push_back(pool_index.at(std::make_pair(ob.first, ob.second)));
+        start.push_back((int32_t)idx.size());
+      }
+      amd::check(vsl_map_set_landmarks(dev_map, (int)table_ids.size(), pts.data(), start.data(), idx.data()), "vsl_map_set_landmarks");
+      map_dirty = false;
+    }
+    std::vector<int32_t> pairs(2 * (size_t)opt.num_features_per_image);
+    int n = 0, n_proj = 0;
+    const auto& cam = calib_cam.intrinsics[0];
+    amd::check(vsl_map_track(dev_map, dev_frames, 0, current_pose.data(), amd::camera_model_id(cam->name()), cam->data(),
+                             cam->width(), cam->height(), opt.cam_z_threshold, opt.match_max_dist_2d, opt.feature_match_max_dist,
+                             opt.feature_match_test_next_best, pairs.data(), &n, &n_proj),
+               "vsl_map_track");
+    for (int i = 0; i < n; i++) md.matches.emplace_back(pairs[2 * i], table_ids[(size_t)pairs[2 * i + 1]]);
+  }
+
+  void fused_download_corners(int slot, KeypointsData& kd) {
+    std::vector<double> xy(2 * (size_t)opt.num_features_per_image);
+    int n = 0;
+    amd::check(vsl_frames_download_keypoints(amd::ctx(), dev_frames, slot, opt.num_features_per_image, xy.data(), nullptr, nullptr, &n),
+               "vsl_frames_download_keypoints");
+    kd.corners.clear();
+    for (int i = 0; i < n; i++) kd.corners.emplace_back(xy[2 * i], xy[2 * i + 1]);
+  }
+
+  void fused_stereo(KeypointsData& kdl, KeypointsData& kdr, MatchData& md_stereo) {
+    const int32_t sp[2] = {0, 1};
+    vsl_ctx* c = amd::ctx();
+    amd::check(vsl_frames_match(c, dev_frames, sp, 1, opt.feature_match_max_dist, opt.feature_match_test_next_best), "vsl_frames_match");
+    std::vector<int32_t> out(2 * (size_t)opt.num_features_per_image);
+    int n = 0;
+    amd::check(vsl_frames_download_matches(c, dev_frames, 0, opt.num_features_per_image, out.data(), &n), "vsl_frames_download_matches");
+    md_stereo.matches.clear();
+    for (int i = 0; i < n; i++) md_stereo.matches.emplace_back(out[2 * i], out[2 * i + 1]);
+    fused_download_corners(0, kdl);
+    fused_download_corners(1, kdr);
+  }
+
+  // the observations add_new_landmarks attached to this keyframe: copy their descriptors from the frame
+  // store into the map's pool (device to device) and remember where they went
+  void fused_register_observations(const FrameCamId fcidl, const FrameCamId fcidr) {
+    const FrameCamId fc[2] = {fcidl, fcidr};
+    for (int slot = 0; slot < 2; slot++) {
+      std::vector<int32_t> ids;
+      for (const auto& kv : landmarks) {
+        auto it = kv.second.all_obs.find(fc[slot]);
+        if (it != kv.second.all_obs.end() && !pool_index.count(std::make_pair(fc[slot], it->second))) {
+          pool_index[std::make_pair(fc[slot], it->second)] = -1;  // reserve: several landmarks may share a feature
+          ids.push_back(it->second);
+        }
+      }
+      if (ids.empty()) continue;
+      int first = 0;
+      amd::check(vsl_map_append_descriptors_from_frame(dev_map, dev_frames, slot, (int)ids.size(), ids.data(), &first),
+                 "vsl_map_append_descriptors_from_frame");
+      for (size_t k = 0; k < ids.size(); k++) pool_index[std::make_pair(fc[slot], ids[k])] = first + (int32_t)k;
+    }
+    map_dirty = true;
   }
 };
 

@@ -54,6 +54,11 @@ def test_headless_pipeline_tracks_the_rendered_trajectory(sequence, tmp_path):
     R = U @ S @ Vt
     err = np.linalg.norm((est - me) @ R.T + mg - gt, axis=1)
     assert err.max() < 0.06 and np.sqrt((err ** 2).mean()) < 0.02, err
+    # the device-resident path (frame store + map, one tracking call per frame) is the same computation
+    traj_f = tmp_path / "traj_fused.csv"
+    out_f = _run(seq_dir, "--traj", str(traj_f), "--kf-min-inliers", "500", "--fused")
+    assert out_f["fused_tracking"] is True and out_f["keyframes"] == out["keyframes"]
+    assert traj_f.read_text() == traj.read_text()
     # deterministic: same inputs, same trajectory (fixed-seed RANSAC, synchronous BA, deterministic kernels)
     traj2 = tmp_path / "traj2.csv"
     _run(seq_dir, "--traj", str(traj2), "--kf-min-inliers", "500")

@@ -5,7 +5,7 @@
 // libvslam_hip.so; there is no CPU fallback.
 //
 //   slam_headless --dataset-path <dir with cam0/ cam1/ ...> --cam-calib <calib.json>
-//                 [--frames N] [--async-ba] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
+//                 [--frames N] [--async-ba] [--fused] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     else if (a == "--frames") max_frames = std::atoi(need("--frames").c_str());
     else if (a == "--traj") traj_path = need("--traj");
     else if (a == "--async-ba") opt.async_ba = true;
+    else if (a == "--fused") opt.fused_tracking = true;
     else if (a == "--kf-min-inliers") opt.new_kf_min_inliers = std::atoi(need("--kf-min-inliers").c_str());
     else if (a == "--max-kfs") opt.max_num_kfs = std::atoi(need("--max-kfs").c_str());
     else if (a == "--num-features") opt.num_features_per_image = std::atoi(need("--num-features").c_str());
@@ -109,10 +110,10 @@ int main(int argc, char** argv) {
   const StageClock& c = odo.clock;
   std::printf(
       "{\"frames\": %d, \"keyframes\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.3f, \"image_decode_s\": %.3f, "
-      "\"ate_rmse_m\": %.6f, \"ate_associations\": %d, \"landmarks\": %zu, \"active_landmarks\": %zu, \"async_ba\": %s, "
+      "\"ate_rmse_m\": %.6f, \"ate_associations\": %d, \"landmarks\": %zu, \"active_landmarks\": %zu, \"async_ba\": %s, \"fused_tracking\": %s, "
       "\"stage_ms_total\": {\"detect\": %.1f, \"stereo_match\": %.1f, \"project_match\": %.1f, \"localize\": %.1f, \"map\": %.1f, "
       "\"ba\": %.1f}, \"ba_runs\": %d}\n",
       n_frames, n_kf, n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
-      opt.async_ba ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.ba_runs);
+      opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.ba_runs);
   return 0;
 }
