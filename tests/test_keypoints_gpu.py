@@ -61,6 +61,21 @@ def test_odd_image_sizes(ctx, orc, w, h):
     assert np.array_equal(xy, oxy) and np.array_equal(ang, oang) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("nf", [5000, 3000])
+def test_reference_maximum_feature_count(ctx, orc, nf):
+    # hidden.num_features ranges up to 5000 in the reference (src/slam.cpp:258-259); 1280x720 so that that many
+    # corners exist (8 px minimum distance), which also takes the selection kernel's global-grid variant
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (90, 160)).astype(np.float32)
+    img = np.clip(np.kron(base, np.ones((8, 8), np.float32)) + rng.normal(0, 8, (720, 1280)), 0, 255).astype(np.uint8)
+    xy, ang, desc = ctx.detect_describe(img, nf, True)
+    oxy, oang, odesc = orc.detect_describe(img, nf, True)
+    assert len(oxy) > 0.9 * nf
+    assert np.array_equal(xy, oxy) and np.array_equal(ang, oang) and np.array_equal(desc, odesc)
+    rev = desc[::-1].copy()
+    assert np.array_equal(ctx.match_descriptors(desc, rev, 70, 1.2), orc.match_descriptors(odesc, rev, 70, 1.2))
+
+
 def test_large_image_uses_global_grid(ctx, orc, synth):
     # 1280 x 720 = 14400 8x8 cells > 6144: the selection kernel keeps its per-cell arrays in global memory
     left, _ = synth.stereo_pair(41, w=1280, h=720, n_rects=7000)
