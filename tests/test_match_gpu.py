@@ -46,12 +46,16 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
     d2[9] = np.uint64(0xFFFFFFFFFFFFFFFF)
     exp = orc.match_descriptors(d1, d2, 70, 1.2)
     assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
-    ctx.set_diagnostic("match_use_valu", 1)
-    try:
-        got = ctx.match_descriptors(d1, d2, 70, 1.2)
-    finally:
-        ctx.set_diagnostic("match_use_valu", 0)
-    assert np.array_equal(got, exp)
+    for knob in ("match_use_valu", "match_full_tracking"):   # popcount kernel; MFMA kernel without its cutoff screen
+        ctx.set_diagnostic(knob, 1)
+        try:
+            got = ctx.match_descriptors(d1, d2, 70, 1.2)
+        finally:
+            ctx.set_diagnostic(knob, 0)
+        assert np.array_equal(got, exp), knob
+    # thresholds / ratios that move the cutoff (including "everything passes" and ratio < 1)
+    for thr, ratio in ((1, 1.2), (70, 1.0), (70, 0.5), (70, 3.0), (130, 1.2), (200, 1.5), (256, 1.2), (300, 2.0)):
+        assert np.array_equal(ctx.match_descriptors(d1, d2, thr, ratio), orc.match_descriptors(d1, d2, thr, ratio)), (thr, ratio)
 
 
 def test_match_thresholds_and_ratios(ctx, orc, synth):
