@@ -186,7 +186,6 @@ int vsl_frames_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
 int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
 /* Diagnostic knobs for the parity tests (results never change, only which kernel path produces them):
  *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
- *   "match_full_tracking" (0/1)     matrix-core matcher without its distance-cutoff screen
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path) */
 int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value);

@@ -46,7 +46,7 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
     d2[9] = np.uint64(0xFFFFFFFFFFFFFFFF)
     exp = orc.match_descriptors(d1, d2, 70, 1.2)
     assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
-    for knob in ("match_use_valu", "match_full_tracking"):   # popcount kernel; MFMA kernel without its cutoff screen
+    for knob in ("match_use_valu",):   # the popcount kernel
         ctx.set_diagnostic(knob, 1)
         try:
             got = ctx.match_descriptors(d1, d2, 70, 1.2)

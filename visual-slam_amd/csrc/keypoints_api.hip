@@ -15,7 +15,6 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   const std::string k(name);
   if (k == "match_use_valu") ctx->match_use_valu = value != 0;
   else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
-  else if (k == "match_full_tracking") ctx->match_full_tracking = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
   else return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ctx_set_diagnostic: unknown knob '%s'", name);
   return VSL_OK;

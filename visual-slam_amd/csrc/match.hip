@@ -119,10 +119,11 @@ __global__ __launch_bounds__(64 * WAVES) void hamming_best2_kernel(
 //     (nibble * 0x00204081 & 0x01010101) into a double-buffered LDS tile shared by the 4 waves;
 //   * both directions of a pair are two independent grid slices (query / database roles swapped);
 //   * query bytes are +1 / -1, database bytes 0 / 1: accumulator = |d| - 2<q, d>, distance = accumulator + |q|;
-//     distances that cannot influence any decision are dismissed by a running minimum (see the kernel).
+//     |q| is a per-lane constant and is added to the two surviving keys once, at the end.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 
+#define MM_PAD_KEY (1023u << KEY_SHIFT)  // rows past the end of the database: above every real key'
 #define MM_ROW 272  // LDS bytes per expanded descriptor: 256 + 16 pad (conflict-free ds_read_b128)
 
 __device__ __forceinline__ v4i_t expand16(uint32_t bits16) {
@@ -134,25 +135,14 @@ __device__ __forceinline__ v4i_t expand16(uint32_t bits16) {
   return o;
 }
 
-__device__ __forceinline__ int imin3(int a, int b, int c) {
-  int r;
-  asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-
-// `cutoff`: only distances below it are tracked.  matchDescriptors rejects a best distance >= threshold
-// and tests the second best only against best * dist_2_best, so with cutoff > max(threshold, threshold *
-// dist_2_best) every decision is unchanged, while almost all of the N^2 distances (unrelated descriptors
-// sit around 128 +- 8) are dismissed by a running minimum: 9 VALU instructions per 16 accumulators instead
-// of 3 per accumulator.  cutoff = 257 tracks everything.
 __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __restrict__ desc,
                                                            const int32_t* __restrict__ kp_count,
                                                            const int32_t* __restrict__ pair_slots,
                                                            uint32_t* __restrict__ best_key,
-                                                           uint32_t* __restrict__ second_key, int F, int cutoff) {
+                                                           uint32_t* __restrict__ second_key, int F) {
   // a "super tile" = 64 database descriptors = two MFMA tiles per workgroup barrier
   __shared__ __align__(16) unsigned char tile[2][64 * MM_ROW];
-  __shared__ __align__(16) uint32_t rowkey[2][64];  // database index m, or KEY_INIT past the end
+  __shared__ __align__(16) uint32_t rowkey[2][64];  // (256 << KEY_SHIFT) | m, or MM_PAD_KEY past the end
   const int pair = blockIdx.z, dir = blockIdx.y;
   const int slot_q = pair_slots[2 * pair + dir];      // queries (rows of the result)
   const int slot_d = pair_slots[2 * pair + 1 - dir];  // database (columns of the reference's loop)
@@ -180,7 +170,6 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
     bq[s].z = (int)((uint32_t)e.z * 0xFEu + 0x01010101u);
     bq[s].w = (int)((uint32_t)e.w * 0xFEu + 0x01010101u);
   }
-  const int thr = cutoff - pq;  // accumulator < thr  <=>  distance < cutoff
 
   // tile fill: thread t expands words (t & 7) of database rows (t >> 3) and (t >> 3) + 32 of the super tile
   const int frow = tid >> 3, fword = tid & 7;
@@ -198,11 +187,15 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
       *(v4i_t*)dst = expand16(wd & 0xFFFFu);
       *(v4i_t*)(dst + 16) = expand16(wd >> 16);
       const int m = st * 64 + lr;
-      if (fword == 0) rowkey[buf][lr] = m < n_d ? (uint32_t)m : KEY_INIT;
+      if (fword == 0) rowkey[buf][lr] = m < n_d ? ((256u << KEY_SHIFT) | (uint32_t)m) : MM_PAD_KEY;
     }
   };
   const int n_st = (n_d + 63) / 64;
-  uint32_t b = KEY_INIT, sk = KEY_INIT;
+  // Keys are tracked WITHOUT |q| (a per-lane constant, it does not change the order):
+  //   key' = ((accumulator + 256) << KEY_SHIFT) | m = one v_lshl_add_u32 on the accumulator and the row's
+  // constant; |q| - 256 is added once at the end.  accumulator + 256 is in [0, 512], padded rows carry
+  // MM_PAD_KEY (distance field 1023, above every real key', below 2^32).
+  uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu;
   {
     uint32_t w0, w1;
     load_words(0, w0, w1);
@@ -222,33 +215,19 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[s], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[s], acc1, 0, 0, 0);
     }
-    // accumulator register g*4+j of lane (c, h) belongs to database row 8g + 4h + j of its MFMA tile.
-    // Screen the 16 accumulators of a tile with a running minimum; only a wave with a distance below the
-    // cutoff somewhere builds keys ((distance << KEY_SHIFT) | m) and updates best / second for that tile.
-    // (A padded row has a zero accumulator and may pass the screen when |q| < cutoff; its key is KEY_INIT +
-    // (|q| << KEY_SHIFT) >= KEY_INIT >= sk >= b, so neither the minimum nor the median moves.)
+    // accumulator register g*4+j of lane (c, h) belongs to database row 8g + 4h + j of its MFMA tile
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      const v16i_t acc = half ? acc1 : acc0;
-      int mn = imin3(acc[0], acc[1], acc[2]);
-      mn = imin3(mn, acc[3], acc[4]);
-      mn = imin3(mn, acc[5], acc[6]);
-      mn = imin3(mn, acc[7], acc[8]);
-      mn = imin3(mn, acc[9], acc[10]);
-      mn = imin3(mn, acc[11], acc[12]);
-      mn = imin3(mn, acc[13], acc[14]);
-      mn = min(mn, acc[15]);
-      if (__ballot(mn < thr) != 0ull) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const uint4 rk = *(const uint4*)&rowkey[buf][32 * half + 8 * g + 4 * h];
-          const uint32_t rks[4] = {rk.x, rk.y, rk.z, rk.w};
+      for (int g = 0; g < 4; g++) {
+        const uint4 rk = *(const uint4*)&rowkey[buf][32 * half + 8 * g + 4 * h];
+        const uint32_t rks[4] = {rk.x, rk.y, rk.z, rk.w};
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const uint32_t key = rks[j] + ((uint32_t)(acc[4 * g + j] + pq) << KEY_SHIFT);
-            sk = umed3(b, key, sk);
-            b = min(b, key);
-          }
+        for (int j = 0; j < 4; j++) {
+          const int av = half ? acc1[4 * g + j] : acc0[4 * g + j];
+          const uint32_t key = ((uint32_t)av << KEY_SHIFT) + rks[j];
+          sk = umed3(b, key, sk);
+          b = min(b, key);
         }
       }
     }
@@ -260,9 +239,11 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
   sk = min(umed3(b, b2, sk), s2);
   b = min(b, b2);
   if (h == 0 && qc < n_q) {
+    // back to (distance << KEY_SHIFT) | m; anything that is not a real row becomes KEY_INIT
+    const uint32_t fix = (uint32_t)(pq - 256) << KEY_SHIFT;  // modular arithmetic: distance = accumulator + 256 + (|q| - 256)
     const size_t o = ((size_t)pair * 2 + dir) * F + qc;
-    best_key[o] = b;
-    second_key[o] = sk;
+    best_key[o] = (b >> KEY_SHIFT) >= 1023u ? KEY_INIT : b + fix;
+    second_key[o] = (sk >> KEY_SHIFT) >= 1023u ? KEY_INIT : sk + fix;
   }
 }
 
@@ -335,12 +316,8 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
                          f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
     } else {
       dim3 grid((f->F + 127) / 128, 2, n_pairs);
-      // distances at or above max(threshold, threshold * dist_2_best) cannot change any decision (see the kernel)
-      double cut = (double)threshold * (dist_2_best > 1.0 ? dist_2_best : 1.0);
-      cut = cut < 1.0 ? 1.0 : (cut > 256.0 ? 256.0 : cut);
-      const int cutoff = ctx->match_full_tracking ? 257 : (int)ceil(cut) + 1;
       hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(256), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
-                         f->best_key, f->second_key, f->F, cutoff);
+                         f->best_key, f->second_key, f->F);
     }
     VSL_CHECK_LAUNCH(ctx);
   }

@@ -49,7 +49,6 @@ struct vsl_ctx {
   bool select_attr_set = false;
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
-  bool match_full_tracking = false;     // diagnostic: the MFMA matcher tracks every distance (no cutoff screen)
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int k1_list_cap = 256;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
