@@ -120,10 +120,11 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 // differ on an image whose responses are all negative.)
 // Key = (order-preserving fp32 bits << 32) | pixel index: a descending sort on the key is the
 // reference's order (value descending, equal values by address descending).
+template <bool STORE_RESPONSE>
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
                                                                float* __restrict__ response, int32_t* __restrict__ meta,
                                                                uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
-                                                               int first, int store_response, int wlist_cap) {
+                                                               int first, int wlist_cap) {
   __shared__ uint64_t list[4][K1_WLIST];  // wave-private lists: appended with a scalar counter, no atomics
   __shared__ int wave_n[4], g_base;
   const int slot = first + blockIdx.z;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       float v, l, r;      // response row and its left / right neighbours
     };
     Gen g0 = {0, 0, 0, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
-    RowF f0, f1, f2;  // row filters of rows ye-1, ye, ye+1
+    RowF fA = {0.f, 0.f}, fB = fA, fC = fA;  // row filters of three consecutive rows, roles rotated by name like the Gen slots
     int prev_ye = -100, pre_row = -100;
     RowRaw pre = {0u, 0u, 0u};
     float vmax = -3.0e38f;
@@ -158,11 +159,10 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     // one step: q = row whose row sums are produced into `cur`; `pm1`/`pm2` hold rows q-1 / q-2.
     // Afterwards cur.v is the response of row q-1, and the candidate row is q-2 (rows q-3, q-2, q-1 =
     // pm2.v (old), pm1.v (old), cur.v) -- the response slots lag the row-sum slots by one row.
-    auto step = [&](int q, Gen& pm2, Gen& pm1, Gen& cur) {
+    auto step = [&](int q, Gen& pm2, Gen& pm1, Gen& cur, RowF& f0, RowF& f1, RowF& f2) {
+      // on entry (steady state) f0 / f1 hold rows ye-1 / ye from the previous step and f2 is the dead slot
       const int ye = reflect101(min(max(q, -1), h), h);
       if (ye == prev_ye + 1 && ye + 1 < h) {
-        f0 = f1;
-        f1 = f2;
         if (pre_row != ye + 1) pre = rowload(img, w, ye + 1, xm, xe, xp);  // scalar branch, not taken in steady state
         f2 = rowfilt(pre, s, s2);
       } else {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const float v_dn = (a + c) - sqrt_rn(t);
       const float l_dn = from_lane_below(v_dn), r_dn = from_lane_above(v_dn);
       if (own_col && y >= y0 && y < y_end) {
-        if (store_response) resp[y * w + x] = v_dn;
+        if (STORE_RESPONSE) resp[y * w + x] = v_dn;
         vmax = fmax2(vmax, v_dn);
       }
       // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
             const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
             const int p = n_wave + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (p < wlist_cap) {
+            if (__builtin_expect(p < wlist_cap, 1)) {
               list[wave][p] = key;
             } else {  // more than K1_WLIST candidates in one 60 x 16 strip (plateaus): rare direct append
               const int g = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], 1);
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     // read as v_mid = resp(q-1) = resp((q+1)-2) -- consistent with the reads above.
     const int q_first = y0 - 2, q_last = y_end + 1;
     for (int q = q_first; q <= q_last; q += 3) {
-      step(q, g0, g1, g2);
-      step(q + 1, g1, g2, g0);
-      step(q + 2, g2, g0, g1);
+      step(q, g0, g1, g2, fA, fB, fC);
+      step(q + 1, g1, g2, g0, fB, fC, fA);
+      step(q + 2, g2, g0, g1, fC, fA, fB);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
@@ -595,9 +595,14 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     if (f->detect_meta_dirty)
       hipLaunchKernelGGL(detect_init_kernel, dim3((f->max_images + 255) / 256), dim3(256), 0, ctx->stream, f->meta, 0, f->max_images);
     f->detect_meta_dirty = true;  // until the selection kernel (which resets the counters) is in the queue
-    hipLaunchKernelGGL(min_eig_response_kernel, dim3((w + K1_COLS - 1) / K1_COLS, (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS), n),
-                       dim3(256), 0, ctx->stream, f->images, f->response, f->meta, f->cand, f->cand_cap, w, h, first,
-                       f->store_response ? 1 : 0, min(max(ctx->k1_list_cap, 0), K1_WLIST));
+    const dim3 k1_grid((w + K1_COLS - 1) / K1_COLS, (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS), n);
+    const int wcap = min(max(ctx->k1_list_cap, 0), K1_WLIST);
+    if (f->store_response)
+      hipLaunchKernelGGL(min_eig_response_kernel<true>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+                         f->cand, f->cand_cap, w, h, first, wcap);
+    else
+      hipLaunchKernelGGL(min_eig_response_kernel<false>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+                         f->cand, f->cand_cap, w, h, first, wcap);
     VSL_CHECK_LAUNCH(ctx);
   }
   {
