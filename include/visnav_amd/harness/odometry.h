@@ -224,7 +224,10 @@ class Odometry {
 
   // One step of the pipeline on the stereo pair of frame `current_frame` (the right image is only
   // looked at on keyframes).
-  void next_step(const GreyImage& img_left, const GreyImage& img_right) {
+  // `next_left` (fused mode only, may be null): the left image of the FOLLOWING frame.  Its upload and
+  // detect / describe kernels are enqueued as soon as this frame's device results are on the host, so
+  // they run on the GPU while the host does P3P-RANSAC, triangulation and map bookkeeping for this frame.
+  void next_step(const GreyImage& img_left, const GreyImage& img_right, const GreyImage* next_left = nullptr) {
     typedef std::chrono::steady_clock Clk;
     auto ms = [](Clk::time_point a, Clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const FrameCamId fcidl(current_frame, 0), fcidr(current_frame, 1);
@@ -241,7 +244,7 @@ class Odometry {
       MatchData md_stereo;
       KeypointsData kdl, kdr;
       if (opt.fused_tracking) {
-        fused_detect(img_left, &img_right);
+        fused_detect(img_left, &img_right);  // the left image is skipped when the previous step prefetched it
       } else {
         ImageRef l(img_left), r(img_right);
         detectKeypointsAndDescriptors(l.img, kdl, opt.num_features_per_image, opt.rotate_features);
@@ -253,6 +256,7 @@ class Odometry {
       if (opt.fused_tracking) {
         fused_track(md);  // before the downloads below: they synchronise the stream
         fused_stereo(kdl, kdr, md_stereo);
+        fused_prefetch(next_left);
       } else {
         matchDescriptors(kdl.corner_descriptors, kdr.corner_descriptors, md_stereo.matches, opt.feature_match_max_dist,
                          opt.feature_match_test_next_best);
@@ -307,7 +311,8 @@ class Odometry {
       auto t2 = Clk::now();
       if (opt.fused_tracking) {
         fused_track(md);
-        fused_download_corners(0, kdl);
+        fused_download_corners(cur_base, kdl);
+        fused_prefetch(next_left);
         feature_corners[fcidl] = kdl;
       } else {
         feature_corners[fcidl] = kdl;
@@ -420,27 +425,53 @@ class Odometry {
   }
 
   // ---- fused device path (OdometryOptions::fused_tracking)
-  vsl_frames* dev_frames = nullptr;  // slot 0 = left, slot 1 = right image of the current frame
+  vsl_frames* dev_frames = nullptr;  // slots cur_base / cur_base + 1 = left / right image of the current frame,
+                                     // the other pair receives the look-ahead frame
+  int cur_base = 0;
+  bool left_prefetched = false;
   vsl_map* dev_map = nullptr;
   bool map_dirty = true;
   std::vector<TrackId> table_ids;    // landmark table row -> TrackId
-  std::map<std::pair<FrameCamId, FeatureId>, int32_t> pool_index;  // keyframe observation -> descriptor pool entry
+  std::unordered_map<TrackId, std::vector<int32_t>> lm_pool;  // landmark -> pool entries of its observation descriptors
 
   void fused_init(const GreyImage& img) {
     if (dev_frames) return;
-    amd::check(vsl_frames_create(amd::ctx(), 2, img.w, img.h, opt.num_features_per_image, 1, &dev_frames), "vsl_frames_create");
+    amd::check(vsl_frames_create(amd::ctx(), 4, img.w, img.h, opt.num_features_per_image, 1, &dev_frames), "vsl_frames_create");
     amd::check(vsl_map_create(amd::ctx(), 8192, 32768, &dev_map), "vsl_map_create");
   }
 
   void fused_detect(const GreyImage& left, const GreyImage* right) {
     fused_init(left);
     vsl_ctx* c = amd::ctx();
-    amd::check(vsl_frames_upload(c, dev_frames, 0, 1, left.px.data(), (size_t)left.w, (size_t)left.w * left.h), "vsl_frames_upload");
+    if (left_prefetched) {  // the previous step already put this frame's left image through detect / describe
+      cur_base ^= 2;
+      left_prefetched = false;
+      if (right) {
+        amd::check(vsl_frames_upload(c, dev_frames, cur_base + 1, 1, right->px.data(), (size_t)right->w, (size_t)right->w * right->h),
+                   "vsl_frames_upload");
+        amd::check(vsl_frames_detect_describe(c, dev_frames, cur_base + 1, 1, opt.num_features_per_image, opt.rotate_features ? 1 : 0),
+                   "vsl_frames_detect_describe");
+      }
+      return;
+    }
+    amd::check(vsl_frames_upload(c, dev_frames, cur_base, 1, left.px.data(), (size_t)left.w, (size_t)left.w * left.h), "vsl_frames_upload");
     if (right)
-      amd::check(vsl_frames_upload(c, dev_frames, 1, 1, right->px.data(), (size_t)right->w, (size_t)right->w * right->h),
+      amd::check(vsl_frames_upload(c, dev_frames, cur_base + 1, 1, right->px.data(), (size_t)right->w, (size_t)right->w * right->h),
                  "vsl_frames_upload");
-    amd::check(vsl_frames_detect_describe(c, dev_frames, 0, right ? 2 : 1, opt.num_features_per_image, opt.rotate_features ? 1 : 0),
+    amd::check(vsl_frames_detect_describe(c, dev_frames, cur_base, right ? 2 : 1, opt.num_features_per_image, opt.rotate_features ? 1 : 0),
                "vsl_frames_detect_describe");
+  }
+
+  // enqueue (asynchronously) the next frame's left image into the other slot pair
+  void fused_prefetch(const GreyImage* next_left) {
+    if (!next_left) return;
+    vsl_ctx* c = amd::ctx();
+    const int nb = cur_base ^ 2;
+    amd::check(vsl_frames_upload(c, dev_frames, nb, 1, next_left->px.data(), (size_t)next_left->w, (size_t)next_left->w * next_left->h),
+               "vsl_frames_upload");
+    amd::check(vsl_frames_detect_describe(c, dev_frames, nb, 1, opt.num_features_per_image, opt.rotate_features ? 1 : 0),
+               "vsl_frames_detect_describe");
+    left_prefetched = true;
   }
 
   // project_landmarks + find_matches_landmarks of the reference against the device-resident table
@@ -453,7 +484,8 @@ class Odometry {
       for (const auto& kv : landmarks) {  // the reference's iteration order defines the candidate order (vo_utils.h:60)
         table_ids.push_back(kv.first);
         pts.insert(pts.end(), kv.second.p.data(), kv.second.p.data() + 3);
-        for (const auto& ob : kv.second.all_obs) idx.push_back(pool_index.at(std::make_pair(ob.first, ob.second)));
+        auto it = lm_pool.find(kv.first);  // one pool entry per all_obs element (order is irrelevant: a minimum is taken)
+        if (it != lm_pool.end()) idx.insert(idx.end(), it->second.begin(), it->second.end());
         start.push_back((int32_t)idx.size());
       }
       amd::check(vsl_map_set_landmarks(dev_map, (int)table_ids.size(), pts.data(), start.data(), idx.data()), "vsl_map_set_landmarks");
@@ -462,7 +494,7 @@ class Odometry {
     std::vector<int32_t> pairs(2 * (size_t)opt.num_features_per_image);
     int n = 0, n_proj = 0;
     const auto& cam = calib_cam.intrinsics[0];
-    amd::check(vsl_map_track(dev_map, dev_frames, 0, current_pose.data(), amd::camera_model_id(cam->name()), cam->data(),
+    amd::check(vsl_map_track(dev_map, dev_frames, cur_base, current_pose.data(), amd::camera_model_id(cam->name()), cam->data(),
                              cam->width(), cam->height(), opt.cam_z_threshold, opt.match_max_dist_2d, opt.feature_match_max_dist,
                              opt.feature_match_test_next_best, pairs.data(), &n, &n_proj),
                "vsl_map_track");
@@ -479,7 +511,7 @@ class Odometry {
   }
 
   void fused_stereo(KeypointsData& kdl, KeypointsData& kdr, MatchData& md_stereo) {
-    const int32_t sp[2] = {0, 1};
+    const int32_t sp[2] = {cur_base, cur_base + 1};
     vsl_ctx* c = amd::ctx();
     amd::check(vsl_frames_match(c, dev_frames, sp, 1, opt.feature_match_max_dist, opt.feature_match_test_next_best), "vsl_frames_match");
     std::vector<int32_t> out(2 * (size_t)opt.num_features_per_image);
@@ -487,8 +519,8 @@ class Odometry {
     amd::check(vsl_frames_download_matches(c, dev_frames, 0, opt.num_features_per_image, out.data(), &n), "vsl_frames_download_matches");
     md_stereo.matches.clear();
     for (int i = 0; i < n; i++) md_stereo.matches.emplace_back(out[2 * i], out[2 * i + 1]);
-    fused_download_corners(0, kdl);
-    fused_download_corners(1, kdr);
+    fused_download_corners(cur_base, kdl);
+    fused_download_corners(cur_base + 1, kdr);
   }
 
   // the observations add_new_landmarks attached to this keyframe: copy their descriptors from the frame
@@ -497,18 +529,19 @@ class Odometry {
     const FrameCamId fc[2] = {fcidl, fcidr};
     for (int slot = 0; slot < 2; slot++) {
       std::vector<int32_t> ids;
+      std::vector<TrackId> owner;
       for (const auto& kv : landmarks) {
         auto it = kv.second.all_obs.find(fc[slot]);
-        if (it != kv.second.all_obs.end() && !pool_index.count(std::make_pair(fc[slot], it->second))) {
-          pool_index[std::make_pair(fc[slot], it->second)] = -1;  // reserve: several landmarks may share a feature
+        if (it != kv.second.all_obs.end()) {
           ids.push_back(it->second);
+          owner.push_back(kv.first);
         }
       }
       if (ids.empty()) continue;
       int first = 0;
-      amd::check(vsl_map_append_descriptors_from_frame(dev_map, dev_frames, slot, (int)ids.size(), ids.data(), &first),
+      amd::check(vsl_map_append_descriptors_from_frame(dev_map, dev_frames, cur_base + slot, (int)ids.size(), ids.data(), &first),
                  "vsl_map_append_descriptors_from_frame");
-      for (size_t k = 0; k < ids.size(); k++) pool_index[std::make_pair(fc[slot], ids[k])] = first + (int32_t)k;
+      for (size_t k = 0; k < ids.size(); k++) lm_pool[owner[k]].push_back(first + (int32_t)k);
     }
     map_dirty = true;
   }

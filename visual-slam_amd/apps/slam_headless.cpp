@@ -19,6 +19,7 @@ using namespace visnav::harness;
 int main(int argc, char** argv) {
   std::string dataset, calib_path, traj_path;
   int max_frames = -1;
+  bool lookahead = true;  // fused mode: detect of frame t+1 enqueued under the host work of frame t
   OdometryOptions opt;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -35,6 +36,7 @@ int main(int argc, char** argv) {
     else if (a == "--traj") traj_path = need("--traj");
     else if (a == "--async-ba") opt.async_ba = true;
     else if (a == "--fused") opt.fused_tracking = true;
+    else if (a == "--no-lookahead") lookahead = false;
     else if (a == "--kf-min-inliers") opt.new_kf_min_inliers = std::atoi(need("--kf-min-inliers").c_str());
     else if (a == "--max-kfs") opt.max_num_kfs = std::atoi(need("--max-kfs").c_str());
     else if (a == "--num-features") opt.num_features_per_image = std::atoi(need("--num-features").c_str());
@@ -85,7 +87,7 @@ int main(int argc, char** argv) {
   const auto t0 = Clk::now();
   for (int i = 0; i < n_frames; i++) {
     const bool kf = odo.take_keyframe;
-    odo.next_step(left[i], right[i]);
+    odo.next_step(left[i], right[i], (lookahead && i + 1 < n_frames) ? &left[i + 1] : nullptr);
     n_kf += kf ? 1 : 0;
   }
   odo.finish();
