@@ -301,7 +301,10 @@ __device__ __forceinline__ int block_scan(bool p, int* wave_tot, int& total) {
 // Static LDS: sized for up to SEL_MAX_CELLS 8x8-px cells (752x480 needs 5640); gfx950 lets one
 // workgroup own (almost) all 160 KiB of its CU's LDS.
 #define SEL_MAX_CELLS 6144
-#define SEL_LDS_BYTES (SEL_CHUNK * 8 + SEL_MAX_CELLS * 2 * 4 + SEL_THREADS * 4 * 3 + SEL_MAX_CELLS * 4 + 2048)
+// the key array is padded by one key per 32 (bank-conflict relief for the strided layouts of the sort)
+#define SEL_KEYS_PADDED (SEL_CHUNK + SEL_CHUNK / 32)
+#define SEL_PHYS(i) ((i) + ((i) >> 5))
+#define SEL_LDS_BYTES (SEL_KEYS_PADDED * 8 + SEL_MAX_CELLS * 2 * 4 + SEL_THREADS * 4 * 3 + SEL_MAX_CELLS * 4 + 2048)
 static_assert(SEL_LDS_BYTES <= 160 * 1024, "selection kernel LDS budget");
 
 // GRID_GLOBAL = false: the accepted-corner grid and the batch list heads live in LDS (images of up to
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
                                                              int w, int h, size_t cand_cap, int F, int first,
                                                              int num_features, int border, double quality,
                                                              uint32_t* __restrict__ grid_scratch) {
-  __shared__ __align__(16) unsigned char smem[GRID_GLOBAL ? (SEL_CHUNK * 8 + SEL_THREADS * 4 * 3 + 2048) : SEL_LDS_BYTES];
+  __shared__ __align__(16) unsigned char smem[GRID_GLOBAL ? (SEL_KEYS_PADDED * 8 + SEL_THREADS * 4 * 3 + 2048) : SEL_LDS_BYTES];
   const int slot = first + blockIdx.x;
   const uint64_t* __restrict__ cand = cand_all + (size_t)slot * cand_cap;
   const int n_cand_raw = meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND];
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   const int gw = (w + 7) / 8, gh = (h + 7) / 8, cells = gw * gh;
   // LDS carve-up (all regions 8-byte aligned)
   uint64_t* keys = (uint64_t*)smem;                 // SEL_CHUNK sorted keys
-  SelShared* sh = (SelShared*)(keys + SEL_CHUNK);
+  SelShared* sh = (SelShared*)(keys + SEL_KEYS_PADDED);
   // cells * 2 accepted corners, packed x | y << 16, then cells batch list heads (-1 = empty); volatile:
   // the global variant must not keep them in registers / stale L1 lines between workgroup barriers
   volatile uint32_t* acc = GRID_GLOBAL ? (volatile uint32_t*)(grid_scratch + (size_t)slot * cells * 3) : (volatile uint32_t*)(sh + 1);
@@ -395,55 +398,51 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       const unsigned long long key = cand[i];
       if (key >= lo && key < hi && key > floor_key) {
         const int p = atomicAdd(&sh->n_chunk, 1);
-        if (p < SEL_CHUNK) keys[p] = key;
+        if (p < SEL_CHUNK) keys[SEL_PHYS(p)] = key;
       }
     }
     __syncthreads();
     const int n_chunk = min(sh->n_chunk, SEL_CHUNK);
     int N = 1024;
     while (N < n_chunk) N <<= 1;
-    for (int i = n_chunk + tid; i < N; i += SEL_THREADS) keys[i] = 0ull;
+    for (int i = n_chunk + tid; i < N; i += SEL_THREADS) keys[SEL_PHYS(i)] = 0ull;
     __syncthreads();
-    // ---- bitonic sort, descending.  With a full chunk (N = SEL_CHUNK = 8 keys per thread) the three
-    // finest sub-steps of every stage (j = 4, 2, 1) run in registers on the thread's 8 consecutive keys:
-    // 68 workgroup barriers instead of 91 and a third less LDS traffic.
+    // ---- bitonic sort, descending.  With a full chunk (N = SEL_CHUNK = 8 keys per thread) the network is
+    // register-blocked: a thread holds the 8 keys whose indices differ in bits b..b+2, so up to three
+    // consecutive sub-steps (j = 2^(b+2), 2^(b+1), 2^b) are compare-exchanges between its own registers;
+    // between such groups the keys pass through LDS once to change b.  ceil(m/3) exchanges for the stage
+    // k = 2^m: 35 workgroup barriers for 8192 keys instead of 91 (one per sub-step).
     if (N == SEL_CHUNK) {
-      const int base = tid * 8;
-      for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j >= 8; j >>= 1) {
-          for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-            const int l = i | j;
-            const uint64_t a = keys[i], b = keys[l];
-            const bool desc = (i & k) == 0;
-            if (desc ? (a < b) : (a > b)) {
-              keys[i] = b;
-              keys[l] = a;
-            }
-          }
-          __syncthreads();
-        }
-        uint64_t rk[8];
+      for (int m = 1; m <= 13; m++) {
+        const int k = 1 << m;
+        for (int top = m - 1; top >= 0;) {
+          const int b = top >= 2 ? top - 2 : 0;  // this group: bits top .. b
+          const int nb = top - b + 1;
+          const int t_hi = tid >> b, t_lo = tid & ((1 << b) - 1);
+          const int i0 = (t_hi << (b + 3)) | t_lo;  // index of the thread's key r = 0; key r sits at i0 | (r << b)
+          uint64_t rk[8];
 #pragma unroll
-        for (int a = 0; a < 8; a++) rk[a] = keys[base + a];
+          for (int r = 0; r < 8; r++) rk[r] = keys[SEL_PHYS(i0 | (r << b))];
 #pragma unroll
-        for (int jj = 4; jj > 0; jj >>= 1) {
-          if (jj <= (k >> 1)) {
+          for (int x = 2; x >= 0; x--) {
+            if (x < nb) {
 #pragma unroll
-            for (int a = 0; a < 8; a++) {
-              if ((a & jj) == 0) {
-                const bool desc = ((base + a) & k) == 0;
-                const uint64_t x = rk[a], y = rk[a | jj];
-                const bool sw = desc ? (x < y) : (x > y);
-                rk[a] = sw ? y : x;
-                rk[a | jj] = sw ? x : y;
+              for (int r = 0; r < 8; r++) {
+                if ((r & (1 << x)) == 0) {
+                  const bool desc = ((i0 | (r << b)) & k) == 0;
+                  const uint64_t u = rk[r], v = rk[r | (1 << x)];
+                  const bool sw = desc ? (u < v) : (u > v);
+                  rk[r] = sw ? v : u;
+                  rk[r | (1 << x)] = sw ? u : v;
+                }
               }
             }
           }
-        }
 #pragma unroll
-        for (int a = 0; a < 8; a++) keys[base + a] = rk[a];
-        __syncthreads();
+          for (int r = 0; r < 8; r++) keys[SEL_PHYS(i0 | (r << b))] = rk[r];
+          __syncthreads();
+          top = b - 1;
+        }
       }
     } else {
       for (int k = 2; k <= N; k <<= 1) {
@@ -451,11 +450,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
           for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
             const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
             const int l = i | j;
-            const uint64_t a = keys[i], b = keys[l];
+            const uint64_t a = keys[SEL_PHYS(i)], b = keys[SEL_PHYS(l)];
             const bool desc = (i & k) == 0;
             if (desc ? (a < b) : (a > b)) {
-              keys[i] = b;
-              keys[l] = a;
+              keys[SEL_PHYS(i)] = b;
+              keys[SEL_PHYS(l)] = a;
             }
           }
           __syncthreads();
@@ -468,7 +467,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       int px = 0, py = 0, cell = 0, cx = 0, cy = 0;
       bool alive = false;
       if (r < n_chunk) {
-        const uint32_t pix = (uint32_t)(keys[r] & 0xFFFFFFFFull);
+        const uint32_t pix = (uint32_t)(keys[SEL_PHYS(r)] & 0xFFFFFFFFull);
         py = (int)(pix / (uint32_t)w);
         px = (int)(pix - (uint32_t)py * (uint32_t)w);
         cx = px >> 3;
