@@ -216,3 +216,50 @@ def test_frames_batch_equals_single(ctx, orc, vsl, synth):
     xy0, _, desc0 = fr.keypoints(0)
     assert np.array_equal(desc0, descs[0])
     fr.close()
+
+
+def test_full_batch_properties(ctx, orc, vsl, synth):
+    """BASELINE.json's benchmark configuration (128 stereo frames = 256 images of 752x480, 1500 features) through
+    size-independent properties of the reference's algorithms, plus oracle spot checks of a few slots."""
+    B = 128
+    pairs_img = [synth.stereo_pair(300 + s) for s in range(8)]
+    batch = np.stack([pairs_img[(k // 2) % 8][k % 2] for k in range(2 * B)])
+    fr = vsl.Frames(ctx, 2 * B, 752, 480, 1500, max_pairs=B)
+    fr.upload(0, batch)
+    sp = np.array([[2 * k, 2 * k + 1] for k in range(B)], np.int32)
+
+    def run():
+        fr.detect_describe(0, 2 * B, 1500, True)
+        fr.resolve_ties()
+        fr.match(sp, 70, 1.2)
+        return fr.counts(2 * B, B)
+
+    nk, nm = run()
+    assert nk.min() > 500 and nk.max() <= 1500 and nm.min() > 50
+    kps = {}
+    for slot in (0, 1, 77, 254, 255):
+        xy, ang, desc = fr.keypoints(slot)
+        kps[slot] = (xy, desc)
+        assert len(xy) == nk[slot]
+        # InBounds(19) (keypoints.h:147) and goodFeaturesToTrack's minimum distance of 8 px between corners
+        assert xy[:, 0].min() >= 19 and xy[:, 0].max() < 752 - 19 and xy[:, 1].min() >= 19 and xy[:, 1].max() < 480 - 19
+        d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
+        d2[np.arange(len(xy)), np.arange(len(xy))] = 1e9
+        assert d2.min() >= 64
+        # identical images in different slots give identical results
+        twin = (slot + 16) % (2 * B)
+        txy, _, tdesc = fr.keypoints(twin)
+        assert np.array_equal(txy, xy) and np.array_equal(tdesc, desc)
+    oxy, _, odesc = orc.detect_describe(batch[77], 1500, True)
+    assert np.array_equal(kps[77][0], oxy) and np.array_equal(kps[77][1], odesc)
+    for p in (0, 127):
+        m = fr.matches(p)
+        assert len(m) == nm[p]
+        # ascending left index, one-to-one (cross-check), and equal to the oracle on the downloaded descriptors
+        assert np.all(np.diff(m[:, 0]) > 0) and len(set(m[:, 1].tolist())) == len(m)
+        assert np.array_equal(m, orc.match_descriptors(kps[2 * p][1], kps[2 * p + 1][1], 70, 1.2))
+    # idempotent: a second pass over the same resident images reproduces every count, keypoint and match
+    nk2, nm2 = run()
+    assert np.array_equal(nk, nk2) and np.array_equal(nm, nm2)
+    assert np.array_equal(fr.keypoints(254)[2], kps[254][1]) and np.array_equal(fr.matches(127), m)
+    fr.close()
