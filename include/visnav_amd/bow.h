@@ -68,6 +68,25 @@ class ORBVocabularyAmd {
     transform(flat.data(), (int)desc.size(), v, fv, levelsup);
   }
 
+  // compute_bow_vector of include/visnav/keypoints.h:243-254 in one device pass: the ORB front end
+  // (cv::ORB::create(num_features, 1.2, 8, 19, 0, 2, FAST_SCORE)->detectAndCompute, restated -- see
+  // oracle/orc_orb.cpp for the arithmetic conventions) followed by transform(..., levelsup = 4)
+  void compute_bow_vector(const pangolin::ManagedImage<uint8_t>& img_raw, int num_features, DBoW2::BowVector& v,
+                          DBoW2::FeatureVector& fv, int levelsup = 4) const {
+    v.clear();
+    fv.clear();
+    if (!voc_) return;
+    const int cap = 2 * num_features + 512;
+    std::vector<uint32_t> ids(cap), fn(cap), ff(cap);
+    std::vector<double> vals(cap);
+    int nnz = 0, fvn = 0;
+    amd::check(vsl_compute_bow_vector(amd::ctx(), voc_, img_raw.ptr, (int)img_raw.w, (int)img_raw.h, img_raw.pitch, num_features,
+                                      levelsup, cap, ids.data(), vals.data(), &nnz, fn.data(), ff.data(), &fvn),
+               "compute_bow_vector");
+    for (int i = 0; i < nnz; i++) v.emplace_hint(v.end(), ids[i], vals[i]);
+    for (int i = 0; i < fvn; i++) fv[fn[i]].push_back(ff[i]);
+  }
+
   // TemplatedVocabulary.h:1199-1203
   double score(const DBoW2::BowVector& a, const DBoW2::BowVector& b) const {
     std::vector<const DBoW2::BowVector*> one(1, &b);
@@ -94,5 +113,12 @@ class ORBVocabularyAmd {
  private:
   vsl_voc* voc_ = nullptr;
 };
+
+// include/visnav/keypoints.h:243-254 with the reference's argument order; the cv::Ptr<cv::ORB> argument of the
+// reference is re-created inside it on every call with fixed parameters, so it carries no state and is dropped.
+inline void compute_bow_vector(const pangolin::ManagedImage<uint8_t>& img_raw, int num_features, const ORBVocabularyAmd* voc,
+                               DBoW2::BowVector& bow_vector, DBoW2::FeatureVector& feature_vector) {
+  voc->compute_bow_vector(img_raw, num_features, bow_vector, feature_vector, 4);
+}
 
 }  // namespace visnav

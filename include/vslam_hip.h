@@ -361,6 +361,19 @@ int vsl_bow_transform(vsl_ctx* ctx, const vsl_voc* voc, const uint8_t* desc32, i
                       uint32_t* word_ids, double* word_vals, int* nnz, uint32_t* fv_node,
                       uint32_t* fv_feat, int* fv_n);
 
+/* The ORB front end of compute_bow_vector (include/visnav/keypoints.h:243-254:
+ * cv::ORB::create(num_features, 1.2, 8, 19, 0, 2, cv::ORB::FAST_SCORE)->detectAndCompute).  cv::ORB is upstream
+ * OpenCV: parity with its binary is unpinned; the arithmetic conventions are those written down in
+ * oracle/orc_orb.cpp, against which this is bit-exact.  kp5: (x, y in level-0 pixels, angle in degrees,
+ * response, octave) per keypoint, desc32: 32 bytes per keypoint in cv::Mat order; cap >= 2 * num_features + 512
+ * is always enough (retainBest keeps every keypoint tied with the last one of a level). */
+int vsl_orb_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch, int num_features, int cap,
+                            float* kp5, uint8_t* desc32, int* n_out);
+/* compute_bow_vector: that front end followed by vsl_bow_transform (outputs as there, capacity cap). */
+int vsl_compute_bow_vector(vsl_ctx* ctx, const vsl_voc* voc, const uint8_t* img, int w, int h, size_t pitch,
+                           int num_features, int levelsup, int cap, uint32_t* word_ids, double* word_vals, int* nnz,
+                           uint32_t* fv_node, uint32_t* fv_feat, int* fv_n);
+
 /* L1 score of one query BowVector against m candidates given in CSR form
  * (c_offsets[m+1]); ids ascending within each vector. */
 int vsl_bow_score_batch(vsl_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int q_nnz,

@@ -24,7 +24,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force=False):
     so = _DIR / "libvslam_oracle.so"
-    srcs = [_DIR / n for n in ("orc_keypoints.cpp", "orc_bow.cpp", "orc_ba.cpp", "orc_vo.cpp", "vslam_oracle.h",
+    srcs = [_DIR / n for n in ("orc_keypoints.cpp", "orc_bow.cpp", "orc_ba.cpp", "orc_vo.cpp", "orc_orb.cpp", "vslam_oracle.h",
                                "rbrief_pattern.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_DIR)], check=True, capture_output=True)
@@ -162,6 +162,55 @@ def bytes_to_bitset(b):
     for i in range(len(b)):
         lib().orc_bytes_to_bitset(b[i].ctypes.data_as(u8p), out[i].ctypes.data_as(u64p))
     return out
+
+
+# ---- ORB front end of compute_bow_vector ([upstream] cv::ORB restated, parity unpinned)
+def orb_level_sizes(w, h, nlevels=8):
+    lw, lh = np.zeros(nlevels, np.int32), np.zeros(nlevels, np.int32)
+    sc = np.zeros(nlevels, np.float32)
+    lib().orc_orb_level_sizes(int(w), int(h), int(nlevels), lw.ctypes.data_as(i32p), lh.ctypes.data_as(i32p), sc.ctypes.data_as(f32p))
+    return lw, lh, sc
+
+
+def orb_level_quota(nfeatures, nlevels=8):
+    q = np.zeros(nlevels, np.int32)
+    lib().orc_orb_level_quota(int(nfeatures), int(nlevels), q.ctypes.data_as(i32p))
+    return q
+
+
+def orb_resize(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_orb_resize(src.ctypes.data_as(u8p), src.shape[1], src.shape[0], dst.ctypes.data_as(u8p), int(dw), int(dh))
+    return dst
+
+
+def orb_fast_score(img, x, y, thr=20):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_orb_fast_score(img.ctypes.data_as(u8p), img.shape[1], img.shape[0], int(x), int(y), int(thr))
+
+
+def orb_gauss7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().orc_orb_gauss7(img.ctypes.data_as(u8p), img.shape[1], img.shape[0], out.ctypes.data_as(u8p))
+    return out
+
+
+def orb_fast_atan2(y, x):
+    f = lib().orc_orb_fast_atan2
+    f.restype = C.c_float
+    return float(f(C.c_float(y), C.c_float(x)))
+
+
+def orb_detect_describe(img, nfeatures=1500):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = 2 * nfeatures + 64   # retainBest keeps ties beyond the quota
+    kp = np.zeros((cap, 5), np.float32)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = lib().orc_orb_detect_describe(img.ctypes.data_as(u8p), img.shape[1], img.shape[0], C.c_size_t(img.strides[0]),
+                                      int(nfeatures), kp.ctypes.data_as(f32p), desc.ctypes.data_as(u8p), cap)
+    return kp[:n].copy(), desc[:n].copy()
 
 
 def project_landmarks(pose7, model, intr8, width, height, points, cam_z_threshold=0.1):

@@ -14,6 +14,7 @@
  *        cv::goodFeaturesToTrack (OpenCV 4.7 imgproc)      -- orc_min_eig_response, orc_good_features
  *        ceres::Solve (Ceres 2.0/2.1 LM + SPARSE_SCHUR)    -- orc_bundle_adjust
  *        Sophus SE3 exp / Dx_this_mul_exp_x_at_0           -- orc_ba_*
+ *        cv::ORB (OpenCV 4.x features2d)                   -- orc_orb_*
  *   - Functions that restate code that IS in the reference tree, line by line in
  *     behaviour, are pinned by hand-checkable known-answer tests
  *     (tests/test_oracle_kat.py) and by the one assertion the reference's own
@@ -70,6 +71,16 @@ int orc_find_matches_landmarks(const double* kp_xy, const uint64_t* kp_desc, int
                                const int32_t* proj_lm, int n_proj, const int32_t* lm_obs_start, const uint64_t* obs_desc,
                                double match_max_dist_2d, int feature_match_threshold, double feature_match_dist_2_best,
                                int32_t* pairs);
+
+/* ---- ORB front end of compute_bow_vector (keypoints.h:243-254) -- [upstream] cv::ORB, parity unpinned -- */
+void orc_orb_level_sizes(int w, int h, int nlevels, int* lw, int* lh, float* scale);
+void orc_orb_level_quota(int nfeatures, int nlevels, int* quota);
+void orc_orb_resize(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+int orc_orb_fast_score(const uint8_t* img, int w, int h, int x, int y, int thr);
+void orc_orb_gauss7(const uint8_t* src, int w, int h, uint8_t* dst);
+float orc_orb_fast_atan2(float y, float x);
+/* kp: 5 floats per keypoint (x, y in level-0 pixels, angle in degrees, response, octave); desc: 32 bytes each */
+int orc_orb_detect_describe(const uint8_t* img, int w, int h, size_t pitch, int nfeatures, float* kp, uint8_t* desc, int cap);
 
 /* ---- DBoW2 ---------------------------------------------------------------- */
 typedef struct orc_voc orc_voc;

@@ -242,6 +242,17 @@ class Context:
                                                    pairs.ctypes.data_as(i32p), C.byref(m)))
         return pairs[:m.value].copy()
 
+    def orb_detect_describe(self, img, num_features=1500):
+        """ORB front end of compute_bow_vector: (kp[n, 5] = x, y, angle_deg, response, octave; desc[n, 32])."""
+        img, p, w, h, pitch = _img(img)
+        cap = 2 * num_features + 512
+        kp = np.zeros((cap, 5), np.float32)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32()
+        self._ck(self.L.vsl_orb_detect_describe(self.h, p, w, h, pitch, int(num_features), cap,
+                                                kp.ctypes.data_as(C.POINTER(C.c_float)), desc.ctypes.data_as(u8p), C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
     # ---- bundle adjustment
     def _ba_struct(self, arr):
         st = BaProblem()
@@ -398,6 +409,20 @@ class Vocabulary:
                                                   C.byref(fvn)))
         return (ids[:nnz.value].copy(), vals[:nnz.value].copy(), fn[:fvn.value].copy(),
                 ff[:fvn.value].copy())
+
+    def compute_bow_vector(self, img, num_features=1500, levelsup=4):
+        """compute_bow_vector (keypoints.h:243-254): ORB front end + transform, one call."""
+        img, p, w, h, pitch = _img(img)
+        cap = 2 * num_features + 512
+        ids = np.zeros(cap, np.uint32)
+        vals = np.zeros(cap, np.float64)
+        fn = np.zeros(cap, np.uint32)
+        ff = np.zeros(cap, np.uint32)
+        nnz, fvn = C.c_int32(), C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_compute_bow_vector(self.ctx.h, self.h, p, w, h, pitch, int(num_features), int(levelsup), cap,
+                                                       ids.ctypes.data_as(u32p), vals.ctypes.data_as(f64p), C.byref(nnz),
+                                                       fn.ctypes.data_as(u32p), ff.ctypes.data_as(u32p), C.byref(fvn)))
+        return (ids[:nnz.value].copy(), vals[:nnz.value].copy(), fn[:fvn.value].copy(), ff[:fvn.value].copy())
 
     def close(self):
         if getattr(self, "h", None):
