@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "../bow.h"
 #include "../bundle_adjustment.h"
 #include "../keypoints.h"
 #include "../vo_utils.h"
@@ -55,7 +56,7 @@ struct OdometryOptions {  // defaults = the pangolin::Var defaults of src/slam.c
 };
 
 struct StageClock {
-  double detect_ms = 0, stereo_match_ms = 0, project_match_ms = 0, localize_ms = 0, map_ms = 0, ba_ms = 0;
+  double detect_ms = 0, stereo_match_ms = 0, project_match_ms = 0, localize_ms = 0, map_ms = 0, ba_ms = 0, bow_ms = 0;
   int ba_runs = 0;
 };
 
@@ -219,6 +220,12 @@ class Odometry {
   int current_frame = 0;
   FrameCamId last_kf_fcid;
   std::vector<Sophus::SE3d> frame_poses;  // T_w_c of every processed frame (for inspection)
+  // optional: the vocabulary of the reference's --voc-path.  With it every keyframe gets its BowVector /
+  // FeatureVector like current_cam_left.bow_vector in src/slam.cpp:1206-1208 (the loop detector that would
+  // consume them is outside this harness).
+  const ORBVocabularyAmd* orb_voc = nullptr;
+  std::map<FrameCamId, DBoW2::BowVector> bow_vectors;
+  std::map<FrameCamId, DBoW2::FeatureVector> feature_vectors;
   StageClock clock;
   int last_inliers = 0, last_matches = 0;
 
@@ -284,6 +291,12 @@ class Odometry {
       cameras[fcidr] = cam_right;
       remove_old_keyframes(fcidl, opt.max_num_kfs, cameras, landmarks, kf_frames);
       if (opt.fused_tracking) fused_register_observations(fcidl, fcidr);
+      if (orb_voc) {  // src/slam.cpp:1206-1208
+        auto tb = Clk::now();
+        ImageRef l(img_left);
+        compute_bow_vector(l.img, opt.num_features_per_image, orb_voc, bow_vectors[fcidl], feature_vectors[fcidl]);
+        clock.bow_ms += ms(tb, Clk::now());
+      }
       auto t6 = Clk::now();
       optimize();
       auto t7 = Clk::now();

@@ -71,3 +71,15 @@ def test_headless_pipeline_reference_defaults_and_asynchronous_ba(sequence):
     out = _run(seq_dir, "--async-ba")
     assert out["async_ba"] is True and out["keyframes"] >= 3
     assert out["ate_rmse_m"] < 0.02, out
+
+
+def test_headless_pipeline_computes_bow_vectors_per_keyframe(sequence, tmp_path, synth):
+    # --voc-path like the reference binary: every keyframe goes through compute_bow_vector (ORB front end +
+    # vocabulary transform, keypoints.h:243-254 / src/slam.cpp:1206-1208); the odometry itself is unaffected
+    seq_dir, _ = sequence
+    voc = tmp_path / "voc.txt"
+    voc.write_text(synth.vocabulary_text(3, 10, 3))
+    a = _run(seq_dir, "--kf-min-inliers", "500", "--fused")
+    b = _run(seq_dir, "--kf-min-inliers", "500", "--fused", "--voc-path", str(voc))
+    assert b["bow_vectors"] == b["keyframes"] == a["keyframes"] and a["bow_vectors"] == 0
+    assert b["ate_rmse_m"] == a["ate_rmse_m"]

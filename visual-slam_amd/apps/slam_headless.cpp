@@ -5,7 +5,7 @@
 // libvslam_hip.so; there is no CPU fallback.
 //
 //   slam_headless --dataset-path <dir with cam0/ cam1/ ...> --cam-calib <calib.json>
-//                 [--frames N] [--async-ba] [--fused] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
+//                 [--voc-path ORBvoc.txt] [--frames N] [--async-ba] [--fused] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -17,7 +17,7 @@ using namespace visnav;
 using namespace visnav::harness;
 
 int main(int argc, char** argv) {
-  std::string dataset, calib_path, traj_path;
+  std::string dataset, calib_path, traj_path, voc_path;
   int max_frames = -1;
   bool lookahead = true;  // fused mode: detect of frame t+1 enqueued under the host work of frame t
   OdometryOptions opt;
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     else if (a == "--cam-calib") calib_path = need("--cam-calib");
     else if (a == "--frames") max_frames = std::atoi(need("--frames").c_str());
     else if (a == "--traj") traj_path = need("--traj");
+    else if (a == "--voc-path") voc_path = need("--voc-path");
     else if (a == "--async-ba") opt.async_ba = true;
     else if (a == "--fused") opt.fused_tracking = true;
     else if (a == "--no-lookahead") lookahead = false;
@@ -77,6 +78,14 @@ int main(int argc, char** argv) {
   const double decode_s = std::chrono::duration<double>(Clk::now() - d0).count();
 
   Odometry odo(calib, opt);
+  ORBVocabularyAmd voc;
+  if (!voc_path.empty()) {
+    if (!voc.loadFromTextFile(voc_path)) {
+      std::fprintf(stderr, "could not load the vocabulary %s\n", voc_path.c_str());
+      return 1;
+    }
+    odo.orb_voc = &voc;
+  }
   // one untimed warm-up call creates the device context and code objects
   {
     KeypointsData kd;
@@ -114,8 +123,8 @@ int main(int argc, char** argv) {
       "{\"frames\": %d, \"keyframes\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.3f, \"image_decode_s\": %.3f, "
       "\"ate_rmse_m\": %.6f, \"ate_associations\": %d, \"landmarks\": %zu, \"active_landmarks\": %zu, \"async_ba\": %s, \"fused_tracking\": %s, "
       "\"stage_ms_total\": {\"detect\": %.1f, \"stereo_match\": %.1f, \"project_match\": %.1f, \"localize\": %.1f, \"map\": %.1f, "
-      "\"ba\": %.1f}, \"ba_runs\": %d}\n",
+      "\"ba\": %.1f, \"bow\": %.1f}, \"ba_runs\": %d, \"bow_vectors\": %zu}\n",
       n_frames, n_kf, n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
-      opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.ba_runs);
+      opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.bow_ms, c.ba_runs, odo.bow_vectors.size());
   return 0;
 }
