@@ -271,7 +271,8 @@ def main():
             with tempfile.TemporaryDirectory(prefix="vsl_seq_") as d:
                 sq.render_sequence(d, n_frames=args.e2e_frames, seed=1, step_m=0.04, radius=1.6)
                 runs = {}
-                for name, extra in (("operator_sequence", []), ("device_resident", ["--fused"])):
+                for name, extra in (("operator_sequence", []), ("device_resident", ["--fused"]),
+                                    ("device_resident_4_streams", ["--fused", "--replicas", "4"])):
                     r = subprocess.run([str(exe), "--dataset-path", d, "--cam-calib", d + "/calib.json", *extra],
                                        capture_output=True, text=True, timeout=600)
                     runs[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
@@ -285,6 +286,7 @@ def main():
                     "ms_per_frame": e["ms_per_frame"], "ate_rmse_m": e["ate_rmse_m"],
                     "stage_ms_total": e["stage_ms_total"],
                     "frames_per_s_operator_by_operator": runs["operator_sequence"].get("frames_per_s"),
+                    "frames_per_s_4_independent_streams_one_gpu": runs["device_resident_4_streams"].get("frames_per_s"),
                     "same_trajectory_both_ways": runs["operator_sequence"].get("ate_rmse_m") == e["ate_rmse_m"]}
             else:
                 out["end_to_end_single_stream"] = e

@@ -5,11 +5,15 @@
 // libvslam_hip.so; there is no CPU fallback.
 //
 //   slam_headless --dataset-path <dir with cam0/ cam1/ ...> --cam-calib <calib.json>
-//                 [--voc-path ORBvoc.txt] [--frames N] [--async-ba] [--fused] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
+//                 [--voc-path ORBvoc.txt] [--replicas N] [--frames N] [--async-ba] [--fused] [--traj out.csv] [--kf-min-inliers N] [--max-kfs N]
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+
+#include <memory>
 
 #include "visnav_amd/harness/odometry.h"
 
@@ -20,6 +24,7 @@ int main(int argc, char** argv) {
   std::string dataset, calib_path, traj_path, voc_path;
   int max_frames = -1;
   bool lookahead = true;  // fused mode: detect of frame t+1 enqueued under the host work of frame t
+  int replicas = 1;       // BASELINE configs[3] on one GPU: that many independent streams, one host thread each
   OdometryOptions opt;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -38,6 +43,7 @@ int main(int argc, char** argv) {
     else if (a == "--async-ba") opt.async_ba = true;
     else if (a == "--fused") opt.fused_tracking = true;
     else if (a == "--no-lookahead") lookahead = false;
+    else if (a == "--replicas") replicas = std::atoi(need("--replicas").c_str());
     else if (a == "--kf-min-inliers") opt.new_kf_min_inliers = std::atoi(need("--kf-min-inliers").c_str());
     else if (a == "--max-kfs") opt.max_num_kfs = std::atoi(need("--max-kfs").c_str());
     else if (a == "--num-features") opt.num_features_per_image = std::atoi(need("--num-features").c_str());
@@ -86,21 +92,45 @@ int main(int argc, char** argv) {
     }
     odo.orb_voc = &voc;
   }
-  // one untimed warm-up call creates the device context and code objects
-  {
-    KeypointsData kd;
-    ImageRef l(left[0]);
-    detectKeypointsAndDescriptors(l.img, kd, opt.num_features_per_image, opt.rotate_features);
+  // replicas - 1 further streams run the same sequence in their own threads (own HIP context, frame store
+  // and map through the thread-local vsl_ctx); stream 0 below is the one that is reported in detail
+  std::vector<std::unique_ptr<Odometry>> others;
+  for (int r = 1; r < replicas; r++) {
+    others.emplace_back(new Odometry(calib, opt));
+    others.back()->orb_voc = odo.orb_voc;
   }
+  std::atomic<int> ready{0};
+  std::atomic<bool> go{false};
+  auto run_stream = [&](Odometry& o, int* kf_count) {
+    {  // per-thread warm-up: context creation and code objects
+      KeypointsData kd;
+      ImageRef l(left[0]);
+      detectKeypointsAndDescriptors(l.img, kd, opt.num_features_per_image, opt.rotate_features);
+    }
+    ready++;
+    while (!go) std::this_thread::yield();
+    for (int i = 0; i < n_frames; i++) {
+      const bool kf = o.take_keyframe;
+      o.next_step(left[i], right[i], (lookahead && i + 1 < n_frames) ? &left[i + 1] : nullptr);
+      if (kf_count) *kf_count += kf ? 1 : 0;
+    }
+    o.finish();
+    o.release_device();  // the thread-local context dies with this thread
+  };
   int n_kf = 0;
+  std::vector<std::thread> threads;
+  for (auto& o : others) threads.emplace_back([&run_stream, &o] { run_stream(*o, nullptr); });
+  std::thread main_stream([&] { run_stream(odo, &n_kf); });
+  while (ready < replicas) std::this_thread::yield();
   const auto t0 = Clk::now();
-  for (int i = 0; i < n_frames; i++) {
-    const bool kf = odo.take_keyframe;
-    odo.next_step(left[i], right[i], (lookahead && i + 1 < n_frames) ? &left[i + 1] : nullptr);
-    n_kf += kf ? 1 : 0;
-  }
-  odo.finish();
+  go = true;
+  main_stream.join();
+  for (auto& t : threads) t.join();
   const double run_s = std::chrono::duration<double>(Clk::now() - t0).count();
+  bool replicas_agree = true;
+  for (auto& o : others)
+    replicas_agree = replicas_agree && o->frame_poses.size() == odo.frame_poses.size() &&
+                     std::memcmp(o->frame_poses.back().data(), odo.frame_poses.back().data(), 7 * sizeof(double)) == 0;
 
   int n_assoc = 0;
   const double ate = odo.ate(ds.timestamps, ds.gt_t_ns, ds.gt_t_w_i, &n_assoc);
@@ -120,11 +150,11 @@ int main(int argc, char** argv) {
   for (const auto& kv : odo.landmarks) n_active += kv.second.active ? 1 : 0;
   const StageClock& c = odo.clock;
   std::printf(
-      "{\"frames\": %d, \"keyframes\": %d, \"frames_per_s\": %.2f, \"ms_per_frame\": %.3f, \"image_decode_s\": %.3f, "
+      "{\"frames\": %d, \"keyframes\": %d, \"streams\": %d, \"streams_agree\": %s, \"frames_per_s\": %.2f, \"ms_per_frame\": %.3f, \"image_decode_s\": %.3f, "
       "\"ate_rmse_m\": %.6f, \"ate_associations\": %d, \"landmarks\": %zu, \"active_landmarks\": %zu, \"async_ba\": %s, \"fused_tracking\": %s, "
       "\"stage_ms_total\": {\"detect\": %.1f, \"stereo_match\": %.1f, \"project_match\": %.1f, \"localize\": %.1f, \"map\": %.1f, "
       "\"ba\": %.1f, \"bow\": %.1f}, \"ba_runs\": %d, \"bow_vectors\": %zu}\n",
-      n_frames, n_kf, n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
+      n_frames, n_kf, replicas, replicas_agree ? "true" : "false", replicas * n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
       opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.bow_ms, c.ba_runs, odo.bow_vectors.size());
   return 0;
 }
