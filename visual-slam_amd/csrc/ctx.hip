@@ -310,28 +310,44 @@ extern "C" int vsl_frames_download_keypoints(vsl_ctx* ctx, vsl_frames* f, int sl
                                              double* angles, uint64_t* desc, int* n_out) {
   if (!ctx || !f || slot < 0 || slot >= f->max_images || !n_out || cap < 0)
     return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_download_keypoints: bad arguments");
-  {
-    int rc = vsl_resolve_ties(ctx, f, nullptr);
-    if (rc) return rc;
+  // ONE round trip: the near-tie count, the keypoint count and the slot's full-capacity arrays travel in the
+  // same batch of copies into pinned memory (72 KB at 1500 features), one synchronisation.  Only when a tie
+  // was flagged (about once per 3e5 frames) or a diagnostic check is on does the slow path run.
+  const size_t F = (size_t)f->F;
+  void* hp = nullptr;
+  int rc = vsl_ctx_hpinned(ctx, 64 + F * (8 + 8 + 32), &hp);
+  if (rc) return rc;
+  int32_t* hdr = (int32_t*)hp;  // [0] tie count, [1] keypoint count
+  int32_t* hxy = (int32_t*)((char*)hp + 64);
+  int32_t* hmom = hxy + 2 * F;
+  uint64_t* hdesc = (uint64_t*)(hmom + 2 * F);
+  const size_t base = (size_t)slot * F;
+  const bool ties = f->ties_pending && !f->exact_overflow_check;
+  if (f->ties_pending && !ties) {
+    if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;
   }
-  int32_t n = 0;
-  VSL_HIP(ctx, hipMemcpyAsync(&n, f->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  hdr[0] = 0;
+  if (ties) VSL_HIP(ctx, hipMemcpyAsync(&hdr[0], f->tie_count, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(&hdr[1], f->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(hxy, f->kp_xy + base * 2, sizeof(int32_t) * 2 * F, hipMemcpyDeviceToHost, ctx->stream));
+  if (angles) VSL_HIP(ctx, hipMemcpyAsync(hmom, f->kp_moments + base * 2, sizeof(int32_t) * 2 * F, hipMemcpyDeviceToHost, ctx->stream));
+  if (desc) VSL_HIP(ctx, hipMemcpyAsync(hdesc, f->kp_desc + base * 4, sizeof(uint64_t) * 4 * F, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ties) {
+    if (hdr[0] != 0) {  // flagged samples: host libm re-evaluation + device patch, then fetch the patched descriptors
+      if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;
+      if (desc) {
+        VSL_HIP(ctx, hipMemcpyAsync(hdesc, f->kp_desc + base * 4, sizeof(uint64_t) * 4 * F, hipMemcpyDeviceToHost, ctx->stream));
+        VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      }
+    } else {
+      f->ties_pending = false;
+    }
+  }
+  const int n = hdr[1];
   *n_out = n;
   if (n > cap) return vsl_fail(ctx, VSL_ERR_CAPACITY, "keypoint capacity %d < %d", cap, n);
   if (n == 0) return VSL_OK;
-  void* hp = nullptr;
-  int rc = vsl_ctx_hpinned(ctx, (size_t)n * 16, &hp);
-  if (rc) return rc;
-  int32_t* hxy = (int32_t*)hp;
-  int32_t* hmom = hxy + 2 * (size_t)n;
-  const size_t base = (size_t)slot * f->F;
-  VSL_HIP(ctx, hipMemcpyAsync(hxy, f->kp_xy + base * 2, sizeof(int32_t) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
-  if (angles)
-    VSL_HIP(ctx, hipMemcpyAsync(hmom, f->kp_moments + base * 2, sizeof(int32_t) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
-  if (desc)
-    VSL_HIP(ctx, hipMemcpyAsync(desc, f->kp_desc + base * 4, sizeof(uint64_t) * 4 * n, hipMemcpyDeviceToHost, ctx->stream));
-  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (corners_xy)
     for (int i = 0; i < 2 * n; i++) corners_xy[i] = (double)hxy[i];
   if (angles) {
@@ -342,6 +358,7 @@ extern "C" int vsl_frames_download_keypoints(vsl_ctx* ctx, vsl_frames* f, int sl
     // atan2(0, 0) = 0, the reference's value.
     for (int i = 0; i < n; i++) angles[i] = atan2((double)hmom[2 * i], (double)hmom[2 * i + 1]);
   }
+  if (desc) std::memcpy(desc, hdesc, sizeof(uint64_t) * 4 * (size_t)n);
   return VSL_OK;
 }
 

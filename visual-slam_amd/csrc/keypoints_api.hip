@@ -62,8 +62,8 @@ extern "C" int vsl_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, int 
   if ((rc = vsl_launch_detect(ctx, f, 0, 1, num_features))) return rc;
   if (angles || desc) {
     if ((rc = vsl_launch_describe(ctx, f, 0, 1, rotate_features, 0))) return rc;
-    if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;
   }
+  // (the download resolves flagged near-tie samples in the same round trip)
   return vsl_frames_download_keypoints(ctx, f, 0, cap, corners_xy, angles, desc, n_out);
 }
 
