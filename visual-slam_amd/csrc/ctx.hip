@@ -366,15 +366,21 @@ extern "C" int vsl_frames_download_matches(vsl_ctx* ctx, vsl_frames* f, int pair
                                            int* n_out) {
   if (!ctx || !f || pair < 0 || pair >= f->max_pairs || !n_out || cap_pairs < 0)
     return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_download_matches: bad arguments");
-  int32_t n = 0;
-  VSL_HIP(ctx, hipMemcpyAsync(&n, f->match_count + pair, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  // one round trip: the count and the pair's full-capacity list into pinned memory together
+  const size_t F = (size_t)f->F;
+  void* hp = nullptr;
+  int rc = vsl_ctx_hpinned(ctx, 64 + 8 * F, &hp);
+  if (rc) return rc;
+  int32_t* hdr = (int32_t*)hp;
+  int32_t* hpairs = (int32_t*)((char*)hp + 64);
+  VSL_HIP(ctx, hipMemcpyAsync(hdr, f->match_count + pair, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (pairs)
+    VSL_HIP(ctx, hipMemcpyAsync(hpairs, f->matches + (size_t)pair * F * 2, sizeof(int32_t) * 2 * F, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = hdr[0];
   *n_out = n;
   if (n > cap_pairs) return vsl_fail(ctx, VSL_ERR_CAPACITY, "match capacity %d < %d", cap_pairs, n);
-  if (n > 0 && pairs) {
-    VSL_HIP(ctx, hipMemcpyAsync(pairs, f->matches + (size_t)pair * f->F * 2, sizeof(int32_t) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
-    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  if (n > 0 && pairs) std::memcpy(pairs, hpairs, sizeof(int32_t) * 2 * (size_t)n);
   return VSL_OK;
 }
 

@@ -274,13 +274,22 @@ extern "C" int vsl_project_landmarks(vsl_ctx* ctx, const double* pose7, int cam_
                      height, dpts, n, cam_z_threshold, duv, dkeep);
   hipLaunchKernelGGL(compact_projection_kernel, dim3(1), dim3(1024), 0, ctx->stream, duv, dkeep, n, douv, didx, dn);
   VSL_CHECK_LAUNCH(ctx);
-  int32_t m = 0;
-  VSL_HIP(ctx, hipMemcpyAsync(&m, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+  // one round trip: count and full-capacity outputs into pinned memory together
+  void* hp = nullptr;
+  rc = vsl_ctx_hpinned(ctx, 64 + 20 * N, &hp);
+  if (rc) return rc;
+  int32_t* hn = (int32_t*)hp;
+  double* huv = (double*)((char*)hp + 64);
+  int32_t* hidx = (int32_t*)(huv + 2 * N);
+  VSL_HIP(ctx, hipMemcpyAsync(hn, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(huv, douv, 16 * N, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(hidx, didx, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t m = hn[0];
   *n_out = m;
   if (m > 0) {
-    VSL_HIP(ctx, hipMemcpy(proj_uv, douv, 16 * (size_t)m, hipMemcpyDeviceToHost));
-    VSL_HIP(ctx, hipMemcpy(proj_idx, didx, 4 * (size_t)m, hipMemcpyDeviceToHost));
+    std::memcpy(proj_uv, huv, 16 * (size_t)m);
+    std::memcpy(proj_idx, hidx, 4 * (size_t)m);
   }
   return VSL_OK;
 }
@@ -324,11 +333,17 @@ extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, con
                      (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
   hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, dres, n_kp, dpairs, dn);
   VSL_CHECK_LAUNCH(ctx);
-  int32_t m = 0;
-  VSL_HIP(ctx, hipMemcpyAsync(&m, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+  void* hp = nullptr;
+  rc = vsl_ctx_hpinned(ctx, 64 + 8 * K, &hp);
+  if (rc) return rc;
+  int32_t* hn = (int32_t*)hp;
+  int32_t* hpairs = (int32_t*)((char*)hp + 64);
+  VSL_HIP(ctx, hipMemcpyAsync(hn, dn, 4, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(hpairs, dpairs, 8 * K, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t m = hn[0];
   *n_out = m;
-  if (m > 0) VSL_HIP(ctx, hipMemcpy(pairs, dpairs, 8 * (size_t)m, hipMemcpyDeviceToHost));
+  if (m > 0) std::memcpy(pairs, hpairs, 8 * (size_t)m);
   return VSL_OK;
 }
 
@@ -552,14 +567,19 @@ extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* 
                      f->kp_xy + 2 * (size_t)slot * f->F, m->obs_index, f->kp_count + slot, m->counters);
   hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, m->result, f->F, m->pairs, m->counters + 1);
   VSL_CHECK_LAUNCH(ctx);
-  int32_t cnt[2] = {0, 0};
+  void* hpin = nullptr;
+  rc = vsl_ctx_hpinned(ctx, 64 + 8 * (size_t)f->F, &hpin);
+  if (rc) return rc;
+  int32_t* cnt = (int32_t*)hpin;
+  int32_t* hpairs = (int32_t*)((char*)hpin + 64);
   VSL_HIP(ctx, hipMemcpyAsync(cnt, m->counters, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (pairs) VSL_HIP(ctx, hipMemcpyAsync(hpairs, m->pairs, 8 * (size_t)f->F, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (n_projected) *n_projected = cnt[0];
   *n_pairs = cnt[1];
   if (cnt[1] > 0) {
     if (!pairs) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_track: pairs is null");
-    VSL_HIP(ctx, hipMemcpy(pairs, m->pairs, 8 * (size_t)cnt[1], hipMemcpyDeviceToHost));
+    std::memcpy(pairs, hpairs, 8 * (size_t)cnt[1]);
   }
   return VSL_OK;
 }
