@@ -215,7 +215,7 @@ def main():
             out["stage_ms_per_launch_streams_overlapped"] = {k: round(v, 5) for k, v in stages_overlapped.items()}
 
         # ---- CPU baseline: the oracle (port of the reference path), 1 core, bounded sample
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:   # the CPU baseline is an N = 1 measurement
             orc = entry.load_oracle()
             t0 = time.perf_counter()
             n_done = 0
@@ -234,7 +234,7 @@ def main():
             out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         # ---- second metric of BASELINE.json: ms per LM iteration of local bundle adjustment
         # (configs[2]: 7 keyframes = 14 cameras, ~20k landmarks), GPU next to the oracle on all host cores
-        if args.ba:
+        if args.ba and world == 1:
             d = synth.ba_problem(4, n_kf=7, n_lms=20000)
             orc = entry.load_oracle()
             mk = lambda: orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"],  # noqa: E731
@@ -264,7 +264,7 @@ def main():
         # triangulation and map bookkeeping on the host; local BA on the GPU) and its ATE on a rendered
         # EuRoC-layout sequence -- a child process so that it owns its HIP context
         exe = ROOT / "visual-slam_amd" / "slam_headless"
-        if args.e2e and exe.exists():
+        if args.e2e and exe.exists() and world == 1:
             import subprocess
             import tempfile
             sq = importlib.import_module("visual_slam_amd.synth_sequence")
