@@ -6,7 +6,7 @@
 // and tested).  One image per call -- the reference runs this once per keyframe:
 //   pyramid (7 chained bilinear resizes, OpenCV's 8-bit fixed-point weights)  ->  per level: FAST-9/16
 //   score image, strict 3x3 non-maximum suppression + border filter + score histogram, retainBest by the
-//   histogram cut with an order-preserving compaction (one workgroup per level), 7x7 Gaussian blur  ->
+//   histogram cut with an order-preserving compaction (count / scan / emit over 1024-pixel chunks), 7x7 Gaussian blur  ->
 //   intensity-centroid orientation (one wavefront per keypoint)  ->  rotated BRIEF tests on the blurred
 //   level (one thread per descriptor byte).  cos / sin of the keypoint angles are evaluated by the host's
 //   libm between the last two kernels (device cos/sin are not bit-identical to glibc).
@@ -130,64 +130,108 @@ struct OrbLevels {
   int seg_cap[ORB_LEVELS];
   size_t pix_off[ORB_LEVELS];  // offset of the level in the pyramid-shaped buffers
   float scale[ORB_LEVELS];
+  int chunk_base[ORB_LEVELS + 1];  // 1024-pixel chunks of the level = [chunk_base[l], chunk_base[l + 1])
 };
 
-// retainBest + ordered compaction: one workgroup per level.  kp_xy: level coordinates; kp_sl: score | level << 8
-__global__ __launch_bounds__(1024) void orb_select_kernel(OrbLevels L, const uint8_t* __restrict__ score_all,
-                                                          const uint8_t* __restrict__ flag_all, const int* __restrict__ hist_all,
-                                                          int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_sl,
-                                                          int32_t* __restrict__ level_count) {
-  __shared__ int wave_tot[16];
-  __shared__ int base_s, cut_s;
-  const int l = blockIdx.x;
-  const int W = L.W[l], H = L.H[l], quota = L.quota[l];
-  const uint8_t* score = score_all + L.pix_off[l];
-  const uint8_t* flag = flag_all + L.pix_off[l];
-  const int* hist = hist_all + 256 * l;
-  if (threadIdx.x == 0) {
-    int total = 0;
-    for (int s = 1; s < 256; s++) total += hist[s];
-    int cut = 0;
-    if (total > quota) {
-      int acc = 0;
-      for (cut = 255; cut > 0; cut--) {
-        acc += hist[cut];
-        if (acc >= quota) break;
-      }
-    }
-    cut_s = quota == 0 ? 256 : cut;
-    base_s = 0;
+// retainBest + order-preserving compaction in three small launches over 1024-pixel chunks of all levels:
+//   count (kept keypoints per chunk)  ->  scan (exclusive offsets per level, one workgroup)  ->  emit.
+// cut = the score of the quota-th best keypoint of the level: everything at or above it is kept (ties included).
+__device__ __forceinline__ int orb_level_of_chunk(const OrbLevels& L, int chunk) {
+  int l = 0;
+  while (l + 1 < ORB_LEVELS && chunk >= L.chunk_base[l + 1]) l++;
+  return l;
+}
+
+__device__ __forceinline__ int orb_cut(const int* __restrict__ hist, int quota) {
+  // evaluated redundantly by one thread per workgroup (256 loads)
+  if (quota == 0) return 256;
+  int total = 0;
+  for (int s = 1; s < 256; s++) total += hist[s];
+  if (total <= quota) return 0;
+  int acc = 0, cut = 255;
+  for (; cut > 0; cut--) {
+    acc += hist[cut];
+    if (acc >= quota) break;
   }
+  return cut;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(1024) void orb_compact_kernel(OrbLevels L, const uint8_t* __restrict__ score_all,
+                                                           const uint8_t* __restrict__ flag_all, const int* __restrict__ hist_all,
+                                                           int32_t* __restrict__ chunk_count, const int32_t* __restrict__ chunk_offset,
+                                                           int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_sl) {
+  __shared__ int wave_tot[16];
+  __shared__ int cut_s;
+  const int chunk = blockIdx.x;
+  const int l = orb_level_of_chunk(L, chunk);
+  if (threadIdx.x == 0) cut_s = orb_cut(hist_all + 256 * l, L.quota[l]);
   __syncthreads();
-  const int cut = cut_s;
+  const int W = L.W[l], n_pix = W * L.H[l];
+  const int i = (chunk - L.chunk_base[l]) * 1024 + threadIdx.x;
+  const uint8_t* score = score_all + L.pix_off[l];
+  const bool ok = i < n_pix && flag_all[L.pix_off[l] + i] && score[i] >= cut_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_pix = W * H;
-  for (int i0 = 0; i0 < n_pix; i0 += 1024) {
-    const int i = i0 + threadIdx.x;
-    const bool ok = i < n_pix && flag[i] && score[i] >= cut;
-    const unsigned long long m = __ballot(ok);
-    if (lane == 0) wave_tot[wave] = __popcll(m);
-    __syncthreads();
-    int off = base_s;
-    for (int w = 0; w < wave; w++) off += wave_tot[w];
-    if (ok) {
-      const int p = off + __popcll(m & ((1ull << lane) - 1ull));
-      if (p < L.seg_cap[l]) {
-        const int y = i / W, x = i - y * W;
-        kp_xy[2 * (size_t)(L.seg_base[l] + p)] = x;
-        kp_xy[2 * (size_t)(L.seg_base[l] + p) + 1] = y;
-        kp_sl[L.seg_base[l] + p] = (int)score[i] | (l << 8);
-      }
-    }
-    __syncthreads();
+  const unsigned long long m = __ballot(ok);
+  if (lane == 0) wave_tot[wave] = __popcll(m);
+  __syncthreads();
+  if (!EMIT) {
     if (threadIdx.x == 0) {
       int t = 0;
       for (int w = 0; w < 16; w++) t += wave_tot[w];
-      base_s += t;
+      chunk_count[chunk] = t;
     }
+    return;
+  }
+  if (ok) {
+    int off = chunk_offset[chunk];
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (p < L.seg_cap[l]) {
+      const int y = i / W, x = i - y * W;
+      kp_xy[2 * (size_t)(L.seg_base[l] + p)] = x;
+      kp_xy[2 * (size_t)(L.seg_base[l] + p) + 1] = y;
+      kp_sl[L.seg_base[l] + p] = (int)score[i] | (l << 8);
+    }
+  }
+}
+
+// exclusive scan of the chunk counts within each level (one workgroup, levels one after the other)
+__global__ __launch_bounds__(1024) void orb_scan_kernel(OrbLevels L, const int32_t* __restrict__ chunk_count,
+                                                        int32_t* __restrict__ chunk_offset, int32_t* __restrict__ level_count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = 0; l < ORB_LEVELS; l++) {
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    const int c0 = L.chunk_base[l], c1 = L.chunk_base[l + 1];
+    for (int cb = c0; cb < c1; cb += 1024) {
+      const int c = cb + threadIdx.x;
+      const int v = c < c1 ? chunk_count[c] : 0;
+      // inclusive scan inside the wave
+      int x = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+      }
+      if (lane == 63) wave_tot[wave] = x;
+      __syncthreads();
+      int off = base_s;
+      for (int w = 0; w < wave; w++) off += wave_tot[w];
+      if (c < c1) chunk_offset[c] = off + x - v;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; w++) t += wave_tot[w];
+        base_s += t;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) level_count[l] = min(base_s, L.seg_cap[l]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) level_count[l] = min(base_s, L.seg_cap[l]);
 }
 
 __global__ void orb_blur_rows_kernel(const uint8_t* __restrict__ src, int W, int H, float* __restrict__ tmp) {
@@ -350,10 +394,14 @@ extern "C" int vsl_orb_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, 
       L.seg_cap[l] = 2 * L.quota[l] + 64;  // retainBest keeps every keypoint tied with the last one
       n_slots += L.seg_cap[l];
     }
+    L.chunk_base[0] = 0;
+    for (int l = 0; l < ORB_LEVELS; l++) L.chunk_base[l + 1] = L.chunk_base[l] + (L.W[l] * L.H[l] + 1023) / 1024;
   }
+  const int n_chunks = L.chunk_base[ORB_LEVELS];
   // scratch: pyramid | score | flag | blurred (u8, total_pix each) | tmp (f32) | hist | level_count | kp_xy | kp_sl | angle | cs | desc
   void* d = nullptr;
-  const size_t bytes = 4 * total_pix + 4 * total_pix + 4 * (256 * ORB_LEVELS + 16) + (size_t)n_slots * (8 + 4 + 4 + 8 + 32) + 1024;
+  const size_t bytes = 4 * total_pix + 4 * total_pix + 4 * (256 * ORB_LEVELS + 16) + (size_t)n_slots * (8 + 4 + 4 + 8 + 32) +
+                       8 * (size_t)n_chunks + 1024;
   rc = vsl_ctx_dscratch(ctx, bytes, &d);
   if (rc) return rc;
   uint8_t* pyr = (uint8_t*)d;
@@ -367,7 +415,9 @@ extern "C" int vsl_orb_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, 
   int32_t* kp_sl = kp_xy + 2 * (size_t)n_slots;
   float* angle = (float*)(kp_sl + n_slots);
   float* cs = angle + n_slots;
-  uint8_t* ddesc = (uint8_t*)(cs + 2 * (size_t)n_slots);
+  int32_t* chunk_count = (int32_t*)(cs + 2 * (size_t)n_slots);
+  int32_t* chunk_offset = chunk_count + n_chunks;
+  uint8_t* ddesc = (uint8_t*)(chunk_offset + n_chunks);
   hipStream_t st = ctx->stream;
   VSL_HIP(ctx, hipMemcpy2DAsync(pyr, w, img, pitch, w, h, hipMemcpyHostToDevice, st));
   VSL_HIP(ctx, hipMemsetAsync(hist, 0, sizeof(int) * (256 * ORB_LEVELS + 16), st));
@@ -383,7 +433,11 @@ extern "C" int vsl_orb_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, 
     hipLaunchKernelGGL(orb_blur_rows_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, pyr + L.pix_off[l], W, H, tmp + L.pix_off[l]);
     hipLaunchKernelGGL(orb_blur_cols_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, tmp + L.pix_off[l], W, H, blurred + L.pix_off[l]);
   }
-  hipLaunchKernelGGL(orb_select_kernel, dim3(ORB_LEVELS), dim3(1024), 0, st, L, score, flag, hist, kp_xy, kp_sl, level_count);
+  hipLaunchKernelGGL(orb_compact_kernel<false>, dim3(n_chunks), dim3(1024), 0, st, L, score, flag, hist, chunk_count,
+                     (const int32_t*)chunk_offset, kp_xy, kp_sl);
+  hipLaunchKernelGGL(orb_scan_kernel, dim3(1), dim3(1024), 0, st, L, (const int32_t*)chunk_count, chunk_offset, level_count);
+  hipLaunchKernelGGL(orb_compact_kernel<true>, dim3(n_chunks), dim3(1024), 0, st, L, score, flag, hist, chunk_count,
+                     (const int32_t*)chunk_offset, kp_xy, kp_sl);
   hipLaunchKernelGGL(orb_angle_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, st, L, pyr, kp_xy, kp_sl, level_count, n_slots, angle);
   VSL_CHECK_LAUNCH(ctx);
   // host: cos / sin of every angle with libm (fp32 radians -> double cos -> fp32, like the oracle)
