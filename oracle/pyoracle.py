@@ -24,7 +24,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force=False):
     so = _DIR / "libvslam_oracle.so"
-    srcs = [_DIR / n for n in ("orc_keypoints.cpp", "orc_bow.cpp", "orc_ba.cpp", "orc_vo.cpp", "orc_orb.cpp", "vslam_oracle.h",
+    srcs = [_DIR / n for n in ("orc_keypoints.cpp", "orc_bow.cpp", "orc_ba.cpp", "orc_vo.cpp", "orc_orb.cpp", "orc_pgo.cpp", "vslam_oracle.h",
                                "rbrief_pattern.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_DIR)], check=True, capture_output=True)
@@ -381,4 +381,67 @@ def bundle_adjust(arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0, thr
     o = _opts(use_huber, huber, max_iters, verbosity, threads)
     s = BaSummary()
     lib().orc_bundle_adjust(C.byref(st), C.byref(o), C.byref(s))
+    return s
+
+
+# ---- pose graph optimisation ([upstream] Ceres + Sophus restated, parity unpinned)
+class PgoProblem(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("poses", f64p), ("node_fixed", u8p),
+                ("edge_a", i32p), ("edge_b", i32p), ("edge_meas", f64p)]
+
+
+class PgoArrays:
+    """Flattened pose graph: poses [N, 7] (in/out), node_fixed [N] u8, edge_a / edge_b [E] i32, edge_meas [E, 6]."""
+
+    def __init__(self, poses, node_fixed, edge_a, edge_b, edge_meas):
+        self.poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7).copy()
+        self.node_fixed = np.ascontiguousarray(node_fixed, np.uint8)
+        self.edge_a = np.ascontiguousarray(edge_a, np.int32)
+        self.edge_b = np.ascontiguousarray(edge_b, np.int32)
+        self.edge_meas = np.ascontiguousarray(edge_meas, np.float64).reshape(-1, 6)
+
+    def fill(self, st):
+        st.n_nodes, st.n_edges = len(self.poses), len(self.edge_a)
+        st.poses = self.poses.ctypes.data_as(f64p)
+        st.node_fixed = self.node_fixed.ctypes.data_as(u8p)
+        st.edge_a = self.edge_a.ctypes.data_as(i32p)
+        st.edge_b = self.edge_b.ctypes.data_as(i32p)
+        st.edge_meas = self.edge_meas.ctypes.data_as(f64p)
+        return st
+
+    def n_free(self):
+        return int((self.node_fixed == 0).sum())
+
+
+def se3_log(pose7):
+    pose7 = np.ascontiguousarray(pose7, np.float64)
+    out = np.zeros(6)
+    lib().orc_se3_log(pose7.ctypes.data_as(f64p), out.ctypes.data_as(f64p))
+    return out
+
+
+def pgo_residual_jacobian(pose_c, pose_n, meas):
+    pc, pn = np.ascontiguousarray(pose_c, np.float64), np.ascontiguousarray(pose_n, np.float64)
+    m = np.ascontiguousarray(meas, np.float64)
+    r, Jc, Jn = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+    lib().orc_pgo_residual_jacobian(pc.ctypes.data_as(f64p), pn.ctypes.data_as(f64p), m.ctypes.data_as(f64p),
+                                    r.ctypes.data_as(f64p), Jc.ctypes.data_as(f64p), Jn.ctypes.data_as(f64p))
+    return r, Jc, Jn
+
+
+def pgo_linearize(arr, use_huber=True, huber=1.0):
+    st = arr.fill(PgoProblem())
+    o = _opts(use_huber, huber, 0, 0, 1)
+    n = 6 * arr.n_free()
+    H, g = np.zeros((max(n, 1), max(n, 1))), np.zeros(max(n, 1))
+    cost, nf = C.c_double(), C.c_int32()
+    lib().orc_pgo_linearize(C.byref(st), C.byref(o), H.ctypes.data_as(f64p), g.ctypes.data_as(f64p), C.byref(cost), C.byref(nf))
+    return H[:n, :n].copy(), g[:n].copy(), cost.value
+
+
+def pose_graph_optimize(arr, use_huber=True, huber=1.0, max_iters=20):
+    st = arr.fill(PgoProblem())
+    o = _opts(use_huber, huber, max_iters, 0, 1)
+    s = BaSummary()
+    lib().orc_pose_graph_optimize(C.byref(st), C.byref(o), C.byref(s))
     return s

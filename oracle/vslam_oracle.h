@@ -15,6 +15,7 @@
  *        ceres::Solve (Ceres 2.0/2.1 LM + SPARSE_SCHUR)    -- orc_bundle_adjust
  *        Sophus SE3 exp / Dx_this_mul_exp_x_at_0           -- orc_ba_*
  *        cv::ORB (OpenCV 4.x features2d)                   -- orc_orb_*
+ *        ceres::Solve on the pose graph, Sophus::SE3::log  -- orc_pgo_*, orc_se3_log
  *   - Functions that restate code that IS in the reference tree, line by line in
  *     behaviour, are pinned by hand-checkable known-answer tests
  *     (tests/test_oracle_kat.py) and by the one assertion the reference's own
@@ -143,6 +144,22 @@ int orc_ba_linearize(const orc_ba_problem*, const orc_ba_options*, int lm_first,
                      double* g, double* cost, int* n_free);
 /* map_utils.h:337-421 / loop_closure_utils.h:672-748 with [upstream] Ceres LM semantics. */
 int orc_bundle_adjust(const orc_ba_problem*, const orc_ba_options*, orc_ba_summary*);
+
+/* ---- pose graph optimisation (loop_closure_utils.h:446-587, reprojection.h:107-126) ------------- */
+typedef struct orc_pgo_problem {
+  int32_t n_nodes, n_edges;
+  double* poses;             /* [n_nodes][7] qx qy qz qw tx ty tz (T_w_c), in/out */
+  const uint8_t* node_fixed; /* SetParameterBlockConstant */
+  const int32_t* edge_a;     /* the functor's T_w_c */
+  const int32_t* edge_b;     /* the functor's T_w_n */
+  const double* edge_meas;   /* [n_edges][6] upsilon, omega */
+} orc_pgo_problem;
+void orc_se3_log(const double* pose7, double* out6);
+/* r = log(T_w_c^-1 T_w_n) - meas; Jacobians 6x6 row-major w.r.t. the tangent of T exp(delta) of each block */
+void orc_pgo_residual_jacobian(const double* pose_c7, const double* pose_n7, const double* meas6, double* r6, double* J_c,
+                               double* J_n);
+int orc_pgo_linearize(const orc_pgo_problem*, const orc_ba_options*, double* H, double* g, double* cost, int* n_free);
+int orc_pose_graph_optimize(const orc_pgo_problem*, const orc_ba_options*, orc_ba_summary*);
 
 #ifdef __cplusplus
 }

@@ -228,3 +228,74 @@ def vocabulary_text(seed, k=10, L=3, stop_frac=0.02):
                 next_id += 1
         level = nxt
     return "\n".join(lines) + "\n"
+
+
+def pose_graph(seed, n_nodes=60, n_loop_edges=25, meas_noise=0.0, drift=0.02, outlier_edges=0):
+    """Keyframe poses on a noisy loop + relative-pose edges (loop_closure_utils.h:446-587: spanning-tree edges
+    between consecutive keyframes, covisibility edges, one loop constraint).  Returns a dict with
+    poses_gt / poses (drifted initial guess) [N, 7] (qx qy qz qw tx ty tz), node_fixed [N], edge_a, edge_b [E]
+    and edge_meas [E, 6] = log(T_a^-1 T_b) of the ground truth (+ noise), the functor's upsilon_omega."""
+    rng = np.random.default_rng(seed)
+    gt = []
+    for k in range(n_nodes):
+        th = 2 * np.pi * k / n_nodes
+        c = np.array([3.0 * np.cos(th), 0.3 * np.sin(3 * th), 3.0 * np.sin(th)])
+        q = axis_angle_q(np.array([0.1 * np.sin(th), 1.0, 0.1 * np.cos(2 * th)]), th + 0.5 * np.pi)
+        gt.append(np.concatenate([q, c]))
+    gt = np.array(gt)
+
+    def inv(p):
+        R = quat_R(p[:4])
+        qi = np.array([-p[0], -p[1], -p[2], p[3]])
+        return np.concatenate([qi, -R.T @ p[4:]])
+
+    def mul(a, b):
+        ax, ay, az, aw = a[:4]
+        bx, by, bz, bw = b[:4]
+        q = np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                      aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+        return np.concatenate([q / np.linalg.norm(q), quat_R(a[:4]) @ b[4:] + a[4:]])
+
+    def log(p):  # numpy restatement of Sophus::SE3::log for the fixture (independent of the oracle's C++)
+        q, t = p[:4], p[4:]
+        n = np.linalg.norm(q[:3])
+        if n < 1e-12:
+            om = 2.0 / q[3] * q[:3]
+        else:
+            half = np.arctan2(n, q[3]) if q[3] >= 0 else np.arctan2(-n, -q[3])
+            om = 2.0 * half / n * q[:3]
+        th = np.linalg.norm(om)
+        Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+        if th < 1e-8:
+            Vi = np.eye(3) - 0.5 * Om + Om @ Om / 12.0
+        else:
+            Vi = np.eye(3) - 0.5 * Om + (1 - th * np.cos(th / 2) / (2 * np.sin(th / 2))) / th ** 2 * (Om @ Om)
+        return np.concatenate([Vi @ t, om])
+
+    ea, eb = [], []
+    for k in range(n_nodes - 1):
+        ea.append(k + 1)   # the functor's T_w_c is the newer keyframe, T_w_n the older one
+        eb.append(k)
+    for _ in range(n_loop_edges):
+        a = int(rng.integers(2, n_nodes))
+        b = int(rng.integers(0, a - 1))
+        ea.append(a)
+        eb.append(b)
+    ea.append(n_nodes - 1)  # the loop constraint
+    eb.append(0)
+    meas = np.array([log(mul(inv(gt[a]), gt[b])) for a, b in zip(ea, eb)])
+    meas = meas + meas_noise * rng.normal(size=meas.shape)
+    for k in rng.choice(len(ea), outlier_edges, replace=False) if outlier_edges else []:
+        meas[k, :3] += rng.normal(0, 2.0, 3)   # gross outliers for the Huber loss
+    # drifted initial guess: integrate perturbed relative poses
+    poses = [gt[0].copy()]
+    for k in range(1, n_nodes):
+        rel = mul(inv(gt[k - 1]), gt[k])
+        rel[4:] += drift * rng.normal(size=3)
+        dq = axis_angle_q(rng.normal(size=3), drift * 0.3 * rng.normal())
+        rel = mul(rel, np.concatenate([dq, np.zeros(3)]))
+        poses.append(mul(poses[-1], rel))
+    fixed = np.zeros(n_nodes, np.uint8)
+    fixed[n_nodes - 1] = 1  # LoopClosureOptions::set_current_kf_fixed
+    return dict(poses_gt=gt, poses=np.array(poses), node_fixed=fixed, edge_a=np.array(ea, np.int32), edge_b=np.array(eb, np.int32),
+                edge_meas=meas, log=log, mul=mul, inv=inv)
