@@ -335,6 +335,31 @@ int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_full_dev, dou
 int vsl_ba_session_accept(vsl_ba_session* s);
 int vsl_ba_session_download(vsl_ba_session* s, double* poses, double* points_own);
 
+/* ------------------------------------------------------------ pose graph optimisation */
+/*
+ * The numerical core of visnav::pose_graph_optimization (include/visnav/loop_closure_utils.h:446-587): one
+ * residual block r = log(T_w_c^-1 * T_w_n) - upsilon_omega per edge (PoseGraphRelativePoseCostFunctor,
+ * include/visnav/reprojection.h:107-126) on SE3 blocks with the tangent parameterisation T * exp(delta),
+ * HuberLoss(huber_parameter), Levenberg-Marquardt with the same restated Ceres policy as vsl_bundle_adjust
+ * (options: use_huber, huber_parameter, max_num_iterations, verbosity; summary: costs, iterations,
+ * termination).  Which edges exist (spanning tree, covisibility above the essential threshold, the loop
+ * constraint) is the caller's graph bookkeeping; the reference fixes the current keyframe when
+ * LoopClosureOptions::set_current_kf_fixed is set -> node_fixed.
+ */
+typedef struct vsl_pgo_problem {
+  int32_t n_nodes, n_edges;
+  double* poses;             /* [n_nodes][7] qx qy qz qw tx ty tz (T_w_c), optimised in place */
+  const uint8_t* node_fixed; /* [n_nodes] */
+  const int32_t* edge_a;     /* [n_edges] the functor's T_w_c */
+  const int32_t* edge_b;     /* [n_edges] the functor's T_w_n */
+  const double* edge_meas;   /* [n_edges][6] upsilon, omega */
+} vsl_pgo_problem;
+int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary);
+/* Test hook: H = J^T J (n x n row-major, n = 6 x free nodes in node order), g = J^T r and the cost of the
+ * robustified problem at the given poses. */
+int vsl_pgo_linearize(vsl_ctx* ctx, const vsl_pgo_problem* prob, const vsl_ba_options* opt, double* H, double* g, double* cost,
+                      int* n_free);
+
 /* --------------------------------------------------------------- DBoW2 path */
 /*
  * Replaces, for loop-closure candidate scoring:

@@ -58,6 +58,11 @@ class BaSummary(C.Structure):
                 ("schur_ms", C.c_double), ("solve_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class PgoProblem(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("poses", f64p), ("node_fixed", u8p),
+                ("edge_a", i32p), ("edge_b", i32p), ("edge_meas", f64p)]
+
+
 def library_path():
     return _SO
 
@@ -282,6 +287,37 @@ class Context:
         s = BaSummary()
         self._ck(self.L.vsl_bundle_adjust(self.h, C.byref(st), C.byref(o), C.byref(s)))
         return s
+
+    # ---- pose graph optimisation (loop_closure_utils.h:446-587)
+    @staticmethod
+    def _pgo_struct(arr):
+        st = PgoProblem()
+        st.n_nodes, st.n_edges = len(arr.poses), len(arr.edge_a)
+        st.poses = arr.poses.ctypes.data_as(f64p)
+        st.node_fixed = arr.node_fixed.ctypes.data_as(u8p)
+        st.edge_a = arr.edge_a.ctypes.data_as(i32p)
+        st.edge_b = arr.edge_b.ctypes.data_as(i32p)
+        st.edge_meas = arr.edge_meas.ctypes.data_as(f64p)
+        return st
+
+    def pose_graph_optimize(self, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0):
+        """arr: object with the numpy fields of vsl_pgo_problem (poses [N, 7] optimised in place)."""
+        st = self._pgo_struct(arr)
+        o = self._ba_opts(use_huber, huber, max_iters, verbosity)
+        s = BaSummary()
+        self._ck(self.L.vsl_pose_graph_optimize(self.h, C.byref(st), C.byref(o), C.byref(s)))
+        return s
+
+    def pgo_linearize(self, arr, use_huber=True, huber=1.0):
+        st = self._pgo_struct(arr)
+        o = self._ba_opts(use_huber, huber, 0, 0)
+        n = 6 * int((arr.node_fixed == 0).sum())
+        H, g = np.zeros((max(n, 1), max(n, 1))), np.zeros(max(n, 1))
+        cost, nf = C.c_double(), C.c_int32()
+        Hc = np.zeros(n * n)
+        self._ck(self.L.vsl_pgo_linearize(self.h, C.byref(st), C.byref(o), Hc.ctypes.data_as(f64p), g.ctypes.data_as(f64p),
+                                          C.byref(cost), C.byref(nf)))
+        return Hc.reshape(n, n), g[:n].copy(), cost.value
 
     def ba_linearize(self, arr, use_huber=True, huber=1.0, lm_first=0, lm_count=-1):
         st = self._ba_struct(arr)
