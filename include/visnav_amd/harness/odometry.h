@@ -225,7 +225,7 @@ class Odometry {
   Sophus::SE3d current_pose;
   bool take_keyframe = true;
   int current_frame = 0;
-  FrameCamId last_kf_fcid;
+  FrameCamId last_kf_fcid = FrameCamId(-1, 0);
   std::vector<Sophus::SE3d> frame_poses;  // T_w_c of every processed frame (for inspection)
   // optional: the vocabulary of the reference's --voc-path.  With it every keyframe gets its BowVector /
   // FeatureVector like current_cam_left.bow_vector in src/slam.cpp:1206-1208 (the loop detector that would

@@ -93,10 +93,14 @@ using FeatureTrack = std::map<FrameCamId, FeatureId>;
 struct Camera {
   Sophus::SE3d T_w_c;
   bool active = true;
-  FrameCamId last_fcid;
+  std::map<FrameCamId, int> covisible_weights;
+  std::map<FrameCamId, Sophus::SE3d> covisible_rel_poses;
+  FrameCamId last_fcid = FrameCamId(-1, 0);  // parent on the spanning tree; frame_id -1 = none (loop_closure_utils.h:522)
+  std::map<TrackId, FeatureId> map_points;
   std::string img_path;
   bool modified = false;
 };
+using CovisibilityGraph = std::unordered_map<FrameCamId, std::set<FrameCamId>, FrameCamIdHash>;
 // include/visnav/common_types.h:228-252
 struct Landmark {
   Eigen::Vector3d p;
