@@ -263,3 +263,45 @@ def test_full_batch_properties(ctx, orc, vsl, synth):
     assert np.array_equal(nk, nk2) and np.array_equal(nm, nm2)
     assert np.array_equal(fr.keypoints(254)[2], kps[254][1]) and np.array_equal(fr.matches(127), m)
     fr.close()
+
+
+def test_randomized_differential(ctx, orc):
+    """Seeded sweep over image content (smooth / blocky / noisy / saturated / low contrast), sizes and feature
+    counts: the HIP path and the oracle must agree bit for bit on every case, including the matches between
+    each image and a shifted copy of it."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        w = int(rng.integers(48, 400))
+        h = int(rng.integers(48, 300))
+        kind = case % 6
+        if kind == 0:    # blocks + noise
+            b = int(rng.integers(3, 12))
+            base = rng.integers(0, 256, ((h + b - 1) // b, (w + b - 1) // b)).astype(np.float32)
+            img = np.kron(base, np.ones((b, b), np.float32))[:h, :w] + rng.normal(0, 4, (h, w))
+        elif kind == 1:  # smooth gradients with few corners
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = 128 + 100 * np.sin(xx / rng.uniform(5, 30)) * np.cos(yy / rng.uniform(5, 30))
+        elif kind == 2:  # pure noise
+            img = rng.integers(0, 256, (h, w)).astype(np.float32)
+        elif kind == 3:  # saturated regions (exact plateaus) with a textured island
+            img = np.full((h, w), 255.0)
+            img[h // 4:3 * h // 4, w // 4:3 * w // 4] = rng.integers(0, 256, (3 * h // 4 - h // 4, 3 * w // 4 - w // 4))
+        elif kind == 4:  # low contrast: responses near the quality threshold, many equal values
+            img = 100 + rng.integers(0, 4, (h, w)).astype(np.float32)
+        else:            # binary checker with random cell size: exact ties everywhere
+            c = int(rng.integers(4, 20))
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = 255.0 * (((xx // c) + (yy // c)) % 2)
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        nf = int(rng.choice([50, 300, 1500]))
+        rot = bool(case % 2 == 0 or kind == 2)
+        xy, ang, desc = ctx.detect_describe(img, nf, rot)
+        oxy, oang, odesc = orc.detect_describe(img, nf, rot)
+        assert np.array_equal(xy, oxy), (case, kind, w, h)
+        assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64)), (case, kind, w, h)
+        assert np.array_equal(desc, odesc), (case, kind, w, h)
+        shifted = np.roll(img, (1, 2), (0, 1))
+        _, _, d2 = ctx.detect_describe(shifted, nf, rot)
+        _, _, od2 = orc.detect_describe(shifted, nf, rot)
+        assert np.array_equal(d2, od2)
+        assert np.array_equal(ctx.match_descriptors(desc, d2, 70, 1.2), orc.match_descriptors(odesc, od2, 70, 1.2)), (case, kind)
