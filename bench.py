@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-ba", dest="ba", action="store_false", help="skip the local-BA ms/iter measurement")
+    ap.add_argument("--no-gba", dest="gba", action="store_false",
+                    help="skip the global-BA ms/iter measurement (BASELINE configs[4] scale, one rank)")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false",
                     help="skip the single-stream end-to-end run of the headless next_step pipeline")
     ap.add_argument("--e2e-frames", type=int, default=90)
@@ -259,6 +261,40 @@ def main():
                                "final_cost_rel_diff_vs_oracle": abs(sg.final_cost - sc.final_cost) / sc.final_cost,
                                "cpu_oracle_ms_per_iter": round(cpu_ms / max(sc.iterations, 1), 3),
                                "cpu_threads": ncpu}
+        # ---- global bundle adjustment at BASELINE configs[4] scale (500 keyframes = 1000 cameras, ~100k landmarks)
+        # through the step-wise session API (the multi-GPU path at world size 1): marginal time per LM iteration
+        if args.gba and world == 1:
+            ba_dist = importlib.import_module("visual_slam_amd.ba_dist")
+            dg = synth.ba_problem(5, n_kf=500, n_lms=100000, loop_radius=200.0, max_range=15.0)
+
+            class _A:
+                pass
+
+            def mk_g():
+                a = _A()
+                for k in ("poses", "cam_fixed", "cam_intr", "intr", "points", "obs_cam", "obs_lm", "obs_uv"):
+                    setattr(a, k, np.ascontiguousarray(dg[k]).copy())
+                a.obs_uv = np.ascontiguousarray(a.obs_uv, np.float64)
+                a.cam_model = dg["cam_model"]
+                return a
+
+            ba_dist.bundle_adjust_distributed(vsl, ctx, mk_g(), max_iters=1)   # warm-up: allocations, code objects
+            times = {}
+            for iters in (3, 12):
+                a = mk_g()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                sg = ba_dist.bundle_adjust_distributed(vsl, ctx, a, max_iters=iters)
+                ctx.synchronize()
+                times[iters] = (time.perf_counter() - t0, sg.iterations)
+            (t3, i3), (t12, i12) = times[3], times[12]
+            out["global_ba"] = {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d; "
+                                            "session API, 1 rank" % (len(dg["poses"]), int(dg["cam_fixed"].sum()), len(dg["points"]),
+                                                                     len(dg["obs_cam"]), 6 * int((dg["cam_fixed"] == 0).sum()),
+                                                                     6 * int((dg["cam_fixed"] == 0).sum())),
+                               "ms_per_lm_iteration_marginal": round(1e3 * (t12 - t3) / max(i12 - i3, 1), 2),
+                               "ms_total_12_iterations_incl_setup": round(1e3 * t12, 1), "iterations": i12}
+
         # ---- third metric: frames/s of ONE stream through the whole per-frame pipeline (the reference's
         # next_step order: detect, stereo match, landmark projection + guided match on the GPU; P3P-RANSAC,
         # triangulation and map bookkeeping on the host; local BA on the GPU) and its ATE on a rendered
