@@ -39,8 +39,8 @@ def run(units, steps):
     torch.cuda.synchronize()
 
 
-for n_streams in (1, 2, 4, 8):
-    for B in (256, 512, 1024):
+for n_streams in (1, 2, 3, 4):
+    for B in (128 * n_streams, 256 * n_streams):
         units = make(n_streams, B)
         run(units, 3)
         t0 = time.perf_counter()

@@ -309,6 +309,45 @@ __device__ __forceinline__ int block_scan(bool p, int* wave_tot, int& total) {
 #define SEL_LDS_BYTES (SEL_KEYS_PADDED * 8 + SEL_MAX_CELLS * 2 * 4 + SEL_THREADS * 4 * 3 + SEL_MAX_CELLS * 4 + 2048)
 static_assert(SEL_LDS_BYTES <= 160 * 1024, "selection kernel LDS budget");
 
+// Register-blocked bitonic network on N = 1024 << LOGK keys in LDS (descending): a thread holds the 1 << LOGK
+// keys whose indices differ in bits b .. b+LOGK-1, so up to LOGK consecutive sub-steps are compare-exchanges
+// between its own registers; between such groups the keys pass through LDS once to change b.
+template <int LOGK>
+__device__ __forceinline__ void sel_sort_blocked(uint64_t* keys, int tid, int log_n) {
+  constexpr int KPT = 1 << LOGK;
+  for (int m = 1; m <= log_n; m++) {
+    const int k = 1 << m;
+    for (int top = m - 1; top >= 0;) {
+      const int b = top >= LOGK - 1 ? top - (LOGK - 1) : 0;  // this group: bits top .. b
+      const int nb = top - b + 1;
+      const int t_hi = tid >> b, t_lo = tid & ((1 << b) - 1);
+      const int i0 = (t_hi << (b + LOGK)) | t_lo;  // index of the thread's key r = 0; key r sits at i0 | (r << b)
+      uint64_t rk[KPT];
+#pragma unroll
+      for (int r = 0; r < KPT; r++) rk[r] = keys[SEL_PHYS(i0 | (r << b))];
+#pragma unroll
+      for (int x = LOGK - 1; x >= 0; x--) {
+        if (x < nb) {
+#pragma unroll
+          for (int r = 0; r < KPT; r++) {
+            if ((r & (1 << x)) == 0) {
+              const bool desc = ((i0 | (r << b)) & k) == 0;
+              const uint64_t u = rk[r], v = rk[r | (1 << x)];
+              const bool sw = desc ? (u < v) : (u > v);
+              rk[r] = sw ? v : u;
+              rk[r | (1 << x)] = sw ? u : v;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < KPT; r++) keys[SEL_PHYS(i0 | (r << b))] = rk[r];
+      __syncthreads();
+      top = b - 1;
+    }
+  }
+}
+
 // GRID_GLOBAL = false: the accepted-corner grid and the batch list heads live in LDS (images of up to
 // SEL_MAX_CELLS cells, e.g. 752 x 480).  GRID_GLOBAL = true: larger images keep the two per-cell arrays
 // in a global scratch (grid_scratch, 3 words per cell per image, L2-resident) -- same algorithm, slower.
@@ -409,43 +448,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
     while (N < n_chunk) N <<= 1;
     for (int i = n_chunk + tid; i < N; i += SEL_THREADS) keys[SEL_PHYS(i)] = 0ull;
     __syncthreads();
-    // ---- bitonic sort, descending.  With a full chunk (N = SEL_CHUNK = 8 keys per thread) the network is
-    // register-blocked: a thread holds the 8 keys whose indices differ in bits b..b+2, so up to three
-    // consecutive sub-steps (j = 2^(b+2), 2^(b+1), 2^b) are compare-exchanges between its own registers;
-    // between such groups the keys pass through LDS once to change b.  ceil(m/3) exchanges for the stage
-    // k = 2^m: 35 workgroup barriers for 8192 keys instead of 91 (one per sub-step).
-    if (N == SEL_CHUNK) {
-      for (int m = 1; m <= 13; m++) {
-        const int k = 1 << m;
-        for (int top = m - 1; top >= 0;) {
-          const int b = top >= 2 ? top - 2 : 0;  // this group: bits top .. b
-          const int nb = top - b + 1;
-          const int t_hi = tid >> b, t_lo = tid & ((1 << b) - 1);
-          const int i0 = (t_hi << (b + 3)) | t_lo;  // index of the thread's key r = 0; key r sits at i0 | (r << b)
-          uint64_t rk[8];
-#pragma unroll
-          for (int r = 0; r < 8; r++) rk[r] = keys[SEL_PHYS(i0 | (r << b))];
-#pragma unroll
-          for (int x = 2; x >= 0; x--) {
-            if (x < nb) {
-#pragma unroll
-              for (int r = 0; r < 8; r++) {
-                if ((r & (1 << x)) == 0) {
-                  const bool desc = ((i0 | (r << b)) & k) == 0;
-                  const uint64_t u = rk[r], v = rk[r | (1 << x)];
-                  const bool sw = desc ? (u < v) : (u > v);
-                  rk[r] = sw ? v : u;
-                  rk[r | (1 << x)] = sw ? u : v;
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 8; r++) keys[SEL_PHYS(i0 | (r << b))] = rk[r];
-          __syncthreads();
-          top = b - 1;
-        }
-      }
+    // ---- bitonic sort, descending.  With 2, 4 or 8 keys per thread (N = 2048 / 4096 / 8192) the network is
+    // register-blocked (sel_sort_blocked): ceil(m / log2(keys per thread)) LDS exchanges for the stage k = 2^m,
+    // e.g. 35 workgroup barriers for 8192 keys instead of 91 (one per sub-step).
+    if (N >= 2048) {
+      if (N == 8192) sel_sort_blocked<3>(keys, tid, 13);
+      else if (N == 4096) sel_sort_blocked<2>(keys, tid, 12);
+      else sel_sort_blocked<1>(keys, tid, 11);
     } else {
       for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
