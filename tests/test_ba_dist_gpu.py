@@ -97,3 +97,13 @@ def test_session_world2_gloo_shared_gpu(tmp_path, vsl, orc, synth, ctx):
     assert np.allclose(r0["poses"], one.poses, rtol=0, atol=1e-7)
     dp = np.abs(r0["points"] - one.points).max(1)
     assert (dp < 1e-6).mean() > 0.97 and dp.max() < 0.05
+
+
+def test_rccl_backend_collectives_at_world_size_one():
+    # the "nccl" (= RCCL) code path of dist.py / bench.py / ba_dist.py: init with device_id, barrier, MAX and SUM
+    # all-reduce of f64 device buffers.  World size 1 is what a one-GPU box allows; N > 1 runs on the driver's node.
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "rccl_smoke.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl smoke ok" in r.stdout, r.stdout + r.stderr
