@@ -13,6 +13,9 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cmath>
 #include <map>
 #include <memory>
@@ -202,7 +205,7 @@ class Odometry {
     T_0_1 = inverse(to_pose(calib_cam.T_i_c[0])) * to_pose(calib_cam.T_i_c[1]);
   }
   ~Odometry() {
-    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    stop_worker();
     release_device();
   }
   // The device objects belong to the calling thread's vsl_ctx (include/visnav_amd/keypoints.h: one context per
@@ -360,7 +363,7 @@ class Odometry {
 
   // Wait for a running optimisation and merge it (end of sequence).
   void finish() {
-    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    wait_worker();
     if (opt_finished) merge_optimized();
   }
 
@@ -386,7 +389,53 @@ class Odometry {
   Corners corners_opt;  // keypoint positions of the active cameras, private to the optimisation thread
   Calibration calib_cam_opt;
   std::atomic<bool> opt_running{false}, opt_finished{false};
+  // the reference starts a new std::thread per optimisation (src/slam.cpp:1557); here ONE worker thread lives as
+  // long as the object, so its thread-local vsl_ctx (stream, scratch, code objects) is created once
   std::unique_ptr<std::thread> opt_thread;
+  std::mutex job_mutex;
+  std::condition_variable job_cv;
+  std::function<void()> job;
+  bool job_pending = false, worker_exit = false;
+
+  void worker_loop() {
+    while (true) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(job_mutex);
+        job_cv.wait(lk, [this] { return job_pending || worker_exit; });
+        if (worker_exit && !job_pending) return;
+        f = job;
+        job_pending = false;
+      }
+      f();
+      job_cv.notify_all();
+    }
+  }
+  void submit_job(std::function<void()> f) {
+    if (!opt_thread) opt_thread.reset(new std::thread([this] { worker_loop(); }));
+    {
+      std::lock_guard<std::mutex> lk(job_mutex);
+      job = std::move(f);
+      job_pending = true;
+    }
+    job_cv.notify_all();
+  }
+  void wait_worker() {  // returns when no optimisation is queued or running
+    if (!opt_thread) return;
+    std::unique_lock<std::mutex> lk(job_mutex);
+    job_cv.wait(lk, [this] { return !job_pending && !opt_running; });
+  }
+  void stop_worker() {
+    if (!opt_thread) return;
+    wait_worker();
+    {
+      std::lock_guard<std::mutex> lk(job_mutex);
+      worker_exit = true;
+    }
+    job_cv.notify_all();
+    opt_thread->join();
+    opt_thread.reset();
+  }
 
   // src/slam.cpp:1510-1571
   void optimize() {
@@ -418,16 +467,15 @@ class Odometry {
       opt_finished = true;
       opt_running = false;
     };
-    if (opt_thread && opt_thread->joinable()) opt_thread->join();
     if (opt.async_ba)
-      opt_thread.reset(new std::thread(work));
+      submit_job(work);
     else
       work();
   }
 
   // src/slam.cpp:1379-1412
   void merge_optimized() {
-    if (opt_thread && opt_thread->joinable()) opt_thread->join();
+    wait_worker();
     for (const auto& kv : landmarks_opt) {
       Landmark& lm = landmarks.at(kv.first);
       lm = kv.second;
