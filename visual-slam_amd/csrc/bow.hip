@@ -110,7 +110,9 @@ __global__ __launch_bounds__(1024) void bow_assemble_kernel(const uint32_t* __re
                                                             int32_t* __restrict__ counts, uint32_t* __restrict__ fv_node,
                                                             uint32_t* __restrict__ fv_feat) {
   __shared__ unsigned long long keys[BOW_MAX_N];
-  __shared__ int n_kept, n_unique;
+  __shared__ double vals_s[BOW_MAX_N];
+  __shared__ int scan[1024];
+  __shared__ int n_kept;
   __shared__ double norm_s;
   const int tid = threadIdx.x;
   int N = 1024;
@@ -133,23 +135,31 @@ __global__ __launch_bounds__(1024) void bow_assemble_kernel(const uint32_t* __re
   // ---- BowVector
   for (int i = tid; i < N; i += 1024)
     keys[i] = (i < n && f_w[i] > 0.0) ? (((unsigned long long)f_word[i] << 32) | (unsigned)i) : ~0ull;
-  if (tid == 0) n_unique = 0;
   __syncthreads();
   bitonic_sort_u64(keys, N);
-  // a run of equal word ids = one BowVector entry; its first element computes the value
-  for (int i = tid; i < kept; i += 1024) {
-    const uint32_t w = (uint32_t)(keys[i] >> 32);
-    const bool first = i == 0 || (uint32_t)(keys[i - 1] >> 32) != w;
-    if (first) atomicAdd(&n_unique, 1);
+  // a run of equal word ids = one BowVector entry; its first element computes the value.  Ordered
+  // compaction of the run heads by a block scan over contiguous per-thread slices.
+  const int per = N >> 10;
+  int heads = 0;
+  for (int k = 0; k < per; k++) {
+    const int i = tid * per + k;
+    heads += i < kept && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != (uint32_t)(keys[i] >> 32));
   }
+  scan[tid] = heads;
   __syncthreads();
-  // ordered compaction of the run heads: rank = number of heads before i (runs are short; count directly)
-  for (int i = tid; i < kept; i += 1024) {
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int add = tid >= d ? scan[tid - d] : 0;
+    __syncthreads();
+    scan[tid] += add;
+    __syncthreads();
+  }
+  int rank = scan[tid] - heads;
+  const int uniq = scan[1023];
+  for (int k = 0; k < per; k++) {
+    const int i = tid * per + k;
+    if (i >= kept) break;
     const uint32_t w = (uint32_t)(keys[i] >> 32);
-    const bool first = i == 0 || (uint32_t)(keys[i - 1] >> 32) != w;
-    if (!first) continue;
-    int rank = 0;
-    for (int q = 1; q <= i; q++) rank += (uint32_t)(keys[q - 1] >> 32) != (uint32_t)(keys[q] >> 32);
+    if (i != 0 && (uint32_t)(keys[i - 1] >> 32) == w) continue;
     double v = 0.0;
     bool init = false;
     for (int q = i; q < kept && (uint32_t)(keys[q] >> 32) == w; q++) {
@@ -158,21 +168,20 @@ __global__ __launch_bounds__(1024) void bow_assemble_kernel(const uint32_t* __re
       init = true;
     }
     word_ids[rank] = w;
-    word_vals[rank] = v;
+    vals_s[rank] = v;
+    rank++;
   }
   __syncthreads();
-  __threadfence_block();
   if (tid == 0) {
-    double norm = 0.0;
-    for (int i = 0; i < n_unique; i++) norm += fabs(word_vals[i]);
+    double norm = 0.0;  // ascending word order, one accumulator (BowVector.cpp:62-74)
+    for (int i = 0; i < uniq; i++) norm += fabs(vals_s[i]);
     norm_s = norm;
-    counts[0] = n_unique;
+    counts[0] = uniq;
     counts[1] = kept;
   }
   __syncthreads();
   const double norm = norm_s;
-  if (norm > 0.0)
-    for (int i = tid; i < n_unique; i += 1024) word_vals[i] /= norm;
+  for (int i = tid; i < uniq; i += 1024) word_vals[i] = norm > 0.0 ? vals_s[i] / norm : vals_s[i];
 }
 
 // K9: one wavefront per candidate BowVector.  Lane-parallel lookup of every candidate word in the
