@@ -61,11 +61,27 @@ __global__ void orb_resize_kernel(const uint8_t* __restrict__ src, int sw, int s
   dst[(size_t)dy * dw + dx] = (uint8_t)min(max(v, 0), 255);
 }
 
+struct OrbLevels {
+  int W[ORB_LEVELS], H[ORB_LEVELS];
+  int quota[ORB_LEVELS];
+  int seg_base[ORB_LEVELS];  // first keypoint slot of the level's output segment
+  int seg_cap[ORB_LEVELS];
+  size_t pix_off[ORB_LEVELS];  // offset of the level in the pyramid-shaped buffers
+  float scale[ORB_LEVELS];
+  int chunk_base[ORB_LEVELS + 1];  // 1024-pixel chunks of the level = [chunk_base[l], chunk_base[l + 1])
+};
+
 // FAST-9/16 score of every pixel: the largest threshold at which it is still a corner, 0 if it is not one at
 // ORB_FAST_THR.  16 x 16 pixel tiles staged in LDS with a 3-pixel apron.
-__global__ __launch_bounds__(256) void orb_fast_kernel(const uint8_t* __restrict__ img, int W, int H, uint8_t* __restrict__ score) {
+// All levels in one launch: blockIdx.z = level, the grid is sized for level 0 and the workgroups beyond a
+// smaller level's extent leave at once.
+__global__ __launch_bounds__(256) void orb_fast_kernel(OrbLevels L, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score_all) {
   __shared__ uint8_t tile[22][24];
+  const int l = blockIdx.z, W = L.W[l], H = L.H[l];
   const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+  if (x0 >= W || y0 >= H) return;
+  const uint8_t* img = pyr + L.pix_off[l];
+  uint8_t* score = score_all + L.pix_off[l];
   for (int t = threadIdx.x; t < 22 * 22; t += 256) {
     const int ty = t / 22, tx = t - ty * 22;
     const int gx = min(max(x0 + tx - 3, 0), W - 1), gy = min(max(y0 + ty - 3, 0), H - 1);
@@ -101,9 +117,14 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(const uint8_t* __restrict
 }
 
 // strict 3x3 maximum + border filter; flags the survivors and histograms their scores
-__global__ void orb_nms_kernel(const uint8_t* __restrict__ score, int W, int H, uint8_t* __restrict__ flag, int* __restrict__ hist) {
+__global__ void orb_nms_kernel(OrbLevels L, const uint8_t* __restrict__ score_all, uint8_t* __restrict__ flag_all,
+                               int* __restrict__ hist_all) {
+  const int l = blockIdx.z, W = L.W[l], H = L.H[l];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= W) return;
+  if (x >= W || y >= H) return;
+  const uint8_t* score = score_all + L.pix_off[l];
+  uint8_t* flag = flag_all + L.pix_off[l];
+  int* hist = hist_all + 256 * l;
   uint8_t f = 0;
   if (x >= ORB_EDGE && y >= ORB_EDGE && x < W - ORB_EDGE && y < H - ORB_EDGE) {
     const int s = score[(size_t)y * W + x];
@@ -123,15 +144,6 @@ __global__ void orb_nms_kernel(const uint8_t* __restrict__ score, int W, int H, 
   flag[(size_t)y * W + x] = f;
 }
 
-struct OrbLevels {
-  int W[ORB_LEVELS], H[ORB_LEVELS];
-  int quota[ORB_LEVELS];
-  int seg_base[ORB_LEVELS];  // first keypoint slot of the level's output segment
-  int seg_cap[ORB_LEVELS];
-  size_t pix_off[ORB_LEVELS];  // offset of the level in the pyramid-shaped buffers
-  float scale[ORB_LEVELS];
-  int chunk_base[ORB_LEVELS + 1];  // 1024-pixel chunks of the level = [chunk_base[l], chunk_base[l + 1])
-};
 
 // retainBest + order-preserving compaction in three small launches over 1024-pixel chunks of all levels:
 //   count (kept keypoints per chunk)  ->  scan (exclusive offsets per level, one workgroup)  ->  emit.
@@ -142,31 +154,31 @@ __device__ __forceinline__ int orb_level_of_chunk(const OrbLevels& L, int chunk)
   return l;
 }
 
-__device__ __forceinline__ int orb_cut(const int* __restrict__ hist, int quota) {
-  // evaluated redundantly by one thread per workgroup (256 loads)
-  if (quota == 0) return 256;
-  int total = 0;
-  for (int s = 1; s < 256; s++) total += hist[s];
-  if (total <= quota) return 0;
-  int acc = 0, cut = 255;
-  for (; cut > 0; cut--) {
-    acc += hist[cut];
-    if (acc >= quota) break;
-  }
-  return cut;
+// cut of every level in one small launch: workgroup = level, thread s = suffix count of the scores >= s
+__global__ __launch_bounds__(256) void orb_cut_kernel(OrbLevels L, const int* __restrict__ hist_all, int32_t* __restrict__ cuts) {
+  __shared__ int h[256];
+  __shared__ int cut_s, total_s;
+  const int l = blockIdx.x, s = threadIdx.x, quota = L.quota[l];
+  h[s] = s ? hist_all[256 * l + s] : 0;
+  if (s == 0) cut_s = 0;
+  __syncthreads();
+  int acc = 0;
+  for (int k = 255; k >= s; k--) acc += h[k];
+  if (s == 1) total_s = acc;
+  if (s >= 1 && acc >= quota) atomicMax(&cut_s, s);
+  __syncthreads();
+  if (s == 0) cuts[l] = quota == 0 ? 256 : (total_s <= quota ? 0 : cut_s);
 }
 
 template <bool EMIT>
 __global__ __launch_bounds__(1024) void orb_compact_kernel(OrbLevels L, const uint8_t* __restrict__ score_all,
-                                                           const uint8_t* __restrict__ flag_all, const int* __restrict__ hist_all,
+                                                           const uint8_t* __restrict__ flag_all, const int32_t* __restrict__ cuts,
                                                            int32_t* __restrict__ chunk_count, const int32_t* __restrict__ chunk_offset,
                                                            int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_sl) {
   __shared__ int wave_tot[16];
-  __shared__ int cut_s;
   const int chunk = blockIdx.x;
   const int l = orb_level_of_chunk(L, chunk);
-  if (threadIdx.x == 0) cut_s = orb_cut(hist_all + 256 * l, L.quota[l]);
-  __syncthreads();
+  const int cut_s = cuts[l];
   const int W = L.W[l], n_pix = W * L.H[l];
   const int i = (chunk - L.chunk_base[l]) * 1024 + threadIdx.x;
   const uint8_t* score = score_all + L.pix_off[l];
@@ -234,18 +246,24 @@ __global__ __launch_bounds__(1024) void orb_scan_kernel(OrbLevels L, const int32
   }
 }
 
-__global__ void orb_blur_rows_kernel(const uint8_t* __restrict__ src, int W, int H, float* __restrict__ tmp) {
+__global__ void orb_blur_rows_kernel(OrbLevels L, const uint8_t* __restrict__ pyr, float* __restrict__ tmp_all) {
+  const int l = blockIdx.z, W = L.W[l], H = L.H[l];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= W) return;
+  if (x >= W || y >= H) return;
+  const uint8_t* src = pyr + L.pix_off[l];
+  float* tmp = tmp_all + L.pix_off[l];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 7; i++) s = s + c_gauss7[i] * (float)src[(size_t)y * W + d_reflect101(x + i - 3, W)];
   tmp[(size_t)y * W + x] = s;
 }
 
-__global__ void orb_blur_cols_kernel(const float* __restrict__ tmp, int W, int H, uint8_t* __restrict__ dst) {
+__global__ void orb_blur_cols_kernel(OrbLevels L, const float* __restrict__ tmp_all, uint8_t* __restrict__ dst_all) {
+  const int l = blockIdx.z, W = L.W[l], H = L.H[l];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= W) return;
+  if (x >= W || y >= H) return;
+  const float* tmp = tmp_all + L.pix_off[l];
+  uint8_t* dst = dst_all + L.pix_off[l];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 7; i++) s = s + c_gauss7[i] * tmp[(size_t)d_reflect101(y + i - 3, H) * W + x];
@@ -411,6 +429,7 @@ extern "C" int vsl_orb_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, 
   float* tmp = (float*)(blurred + total_pix);
   int* hist = (int*)(tmp + total_pix);
   int32_t* level_count = hist + 256 * ORB_LEVELS;
+  int32_t* cuts = level_count + ORB_LEVELS;
   int32_t* kp_xy = level_count + 16;
   int32_t* kp_sl = kp_xy + 2 * (size_t)n_slots;
   float* angle = (float*)(kp_sl + n_slots);
@@ -424,19 +443,18 @@ extern "C" int vsl_orb_detect_describe(vsl_ctx* ctx, const uint8_t* img, int w, 
   for (int l = 1; l < ORB_LEVELS; l++)
     hipLaunchKernelGGL(orb_resize_kernel, dim3((L.W[l] + 255) / 256, L.H[l]), dim3(256), 0, st, pyr + L.pix_off[l - 1], L.W[l - 1],
                        L.H[l - 1], pyr + L.pix_off[l], L.W[l], L.H[l], (double)L.W[l - 1] / L.W[l], (double)L.H[l - 1] / L.H[l]);
-  for (int l = 0; l < ORB_LEVELS; l++) {
-    const int W = L.W[l], H = L.H[l];
-    hipLaunchKernelGGL(orb_fast_kernel, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, st, pyr + L.pix_off[l], W, H,
-                       score + L.pix_off[l]);
-    hipLaunchKernelGGL(orb_nms_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, score + L.pix_off[l], W, H, flag + L.pix_off[l],
-                       hist + 256 * l);
-    hipLaunchKernelGGL(orb_blur_rows_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, pyr + L.pix_off[l], W, H, tmp + L.pix_off[l]);
-    hipLaunchKernelGGL(orb_blur_cols_kernel, dim3((W + 255) / 256, H), dim3(256), 0, st, tmp + L.pix_off[l], W, H, blurred + L.pix_off[l]);
+  {
+    const int W = L.W[0], H = L.H[0];  // level 0 is the largest
+    hipLaunchKernelGGL(orb_fast_kernel, dim3((W + 15) / 16, (H + 15) / 16, ORB_LEVELS), dim3(256), 0, st, L, (const uint8_t*)pyr, score);
+    hipLaunchKernelGGL(orb_nms_kernel, dim3((W + 255) / 256, H, ORB_LEVELS), dim3(256), 0, st, L, (const uint8_t*)score, flag, hist);
+    hipLaunchKernelGGL(orb_blur_rows_kernel, dim3((W + 255) / 256, H, ORB_LEVELS), dim3(256), 0, st, L, (const uint8_t*)pyr, tmp);
+    hipLaunchKernelGGL(orb_blur_cols_kernel, dim3((W + 255) / 256, H, ORB_LEVELS), dim3(256), 0, st, L, (const float*)tmp, blurred);
   }
-  hipLaunchKernelGGL(orb_compact_kernel<false>, dim3(n_chunks), dim3(1024), 0, st, L, score, flag, hist, chunk_count,
+  hipLaunchKernelGGL(orb_cut_kernel, dim3(ORB_LEVELS), dim3(256), 0, st, L, (const int*)hist, cuts);
+  hipLaunchKernelGGL(orb_compact_kernel<false>, dim3(n_chunks), dim3(1024), 0, st, L, score, flag, (const int32_t*)cuts, chunk_count,
                      (const int32_t*)chunk_offset, kp_xy, kp_sl);
   hipLaunchKernelGGL(orb_scan_kernel, dim3(1), dim3(1024), 0, st, L, (const int32_t*)chunk_count, chunk_offset, level_count);
-  hipLaunchKernelGGL(orb_compact_kernel<true>, dim3(n_chunks), dim3(1024), 0, st, L, score, flag, hist, chunk_count,
+  hipLaunchKernelGGL(orb_compact_kernel<true>, dim3(n_chunks), dim3(1024), 0, st, L, score, flag, (const int32_t*)cuts, chunk_count,
                      (const int32_t*)chunk_offset, kp_xy, kp_sl);
   hipLaunchKernelGGL(orb_angle_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, st, L, pyr, kp_xy, kp_sl, level_count, n_slots, angle);
   VSL_CHECK_LAUNCH(ctx);
