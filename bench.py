@@ -159,7 +159,7 @@ def main():
             for _, c, _ in units:
                 c.set_profiling(True)
                 c.reset_profiling()
-            for _ in range(args.profile_steps):
+            for _ in range(max(1, args.profile_steps)):
                 fn()
             tot = {}
             for _, c, _ in units:

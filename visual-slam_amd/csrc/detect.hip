@@ -13,6 +13,8 @@
 //   response = (a + c) - sqrtf((a-c)*(a-c) + b*b)                                 (fp32)
 // BORDER_REFLECT_101 is applied to the image for the derivative and to the cov image for the box
 // sum (a lane or row outside the image evaluates the cov of its mirror position).
+#include <type_traits>
+
 #include "vsl_common.h"
 
 #define K1_ROWS 32
@@ -29,24 +31,28 @@ struct RowRaw {
   unsigned l, m, r;
 };
 
-// yr is wave-uniform: scalar row base + one 32-bit lane offset per load
-__device__ __forceinline__ RowRaw rowload(const uint8_t* __restrict__ img, int w, int yr, unsigned xm, unsigned xe,
-                                          unsigned xp) {
-  const uint8_t* __restrict__ row = img + (size_t)(unsigned)(yr * w);
+// yr is wave-uniform: buffer loads through the image's descriptor take the row base as the scalar offset and the
+// lane's column as the 32-bit vector offset -- no per-load 64-bit address arithmetic on the VALU (K1 is VALU-bound)
+typedef __amdgpu_buffer_rsrc_t ImgSrd;
+__device__ __forceinline__ RowRaw rowload(ImgSrd img, int w, int yr, unsigned xm, unsigned xe, unsigned xp) {
+  const int row = yr * w;
   RowRaw o;
-  o.l = row[xm];
-  o.m = row[xe];
-  o.r = row[xp];
+  o.l = __builtin_amdgcn_raw_buffer_load_b8(img, (int)xm, row, 0);
+  o.m = __builtin_amdgcn_raw_buffer_load_b8(img, (int)xe, row, 0);
+  o.r = __builtin_amdgcn_raw_buffer_load_b8(img, (int)xp, row, 0);
   return o;
 }
+
+typedef float pk2 __attribute__((ext_vector_type(2)));  // pairs for the packed fp32 VALU ops (two results per issue slot)
 
 __device__ __forceinline__ RowF rowfilt(RowRaw p, float s, float s2) {
   const float l = (float)p.l, m = (float)p.m, r = (float)p.r;
   RowF o;
   o.rx = r - l;
-  float t = s * l;
+  const pk2 sl_sr = pk2{l, r} * pk2{s, s};  // v_pk_mul_f32
+  float t = sl_sr.x;
   t = t + s2 * m;
-  t = t + s * r;
+  t = t + sl_sr.y;
   o.ry = t;
   return o;
 }
@@ -81,14 +87,17 @@ __device__ __forceinline__ float fmax2(float a, float b) {  // no NaN canonicali
 // rare denormal-range t (rounding-noise gradients in an otherwise flat patch) takes the library path.
 __device__ __forceinline__ float sqrt_rn(float t) {
   float r = __builtin_amdgcn_sqrtf(t);
-  const float rm = __builtin_bit_cast(float, __builtin_bit_cast(int, r) - 1);
-  const float rp = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
+  const int rb = __builtin_bit_cast(int, r);
+  const float rm = __builtin_bit_cast(float, rb - 1);
+  const float rp = __builtin_bit_cast(float, rb + 1);
   const float em = __builtin_fmaf(-rm, r, t);
   const float ep = __builtin_fmaf(-rp, r, t);
   r = (0.f >= em) ? rm : r;
   r = (0.f < ep) ? rp : r;
-  const bool tiny = t < 0x1p-96f && t > 0.f;
-  if (__ballot(tiny) != 0ull) {  // wave-uniform branch: keeps the library expansion off the common path
+  // 0 < sqrt(t) < 2^-47 (a superset of 0 < t < 2^-96, where the residuals lose bits), tested on the integer
+  // the correction computed anyway: one unsigned compare (r = 0 wraps to 0xffffffff and is not "tiny")
+  const bool tiny = (unsigned)(rb - 1) < 0x27FFFFFFu;
+  if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {  // wave-uniform branch: keeps the library expansion off the common path
     asm volatile("" ::: "memory");  // not speculatable: stops the compiler from flattening the branch
     if (tiny) r = sqrtf(t);
   }
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
   __shared__ uint64_t list[4][K1_WLIST];  // wave-private lists: appended with a scalar counter, no atomics
   __shared__ int wave_n[4], g_base;
   const int slot = first + blockIdx.z;
-  const uint8_t* __restrict__ img = images + (size_t)slot * w * h;
+  const ImgSrd img = __builtin_amdgcn_make_buffer_rsrc((void*)(images + (size_t)slot * w * h), 0, w * h, 0x00020000);
   float* __restrict__ resp = response + (size_t)slot * w * h;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping below stays scalar
@@ -145,14 +154,15 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const unsigned xm = (unsigned)reflect101((int)xe - 1, w), xp = (unsigned)reflect101((int)xe + 1, w);
     const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
     const bool cand_col = own_col && x >= 1 && x < w - 1;
+    const unsigned long long cand_lanes = __builtin_amdgcn_ballot_w64(cand_col);
 
     // Three generations of row sums / response rows live in registers; the row loop is unrolled by
     // three with the roles rotated by NAME (no register-to-register moves).
     struct Gen {
       double xx, xy, yy;  // fp64 row sums R(x, q)
-      float v, l, r;      // response row and its left / right neighbours
+      float v;            // response row
     };
-    Gen g0 = {0, 0, 0, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
+    Gen g0 = {0, 0, 0, 0.f}, g1 = g0, g2 = g0;
     RowF fA = {0.f, 0.f}, fB = fA, fC = fA;  // row filters of three consecutive rows, roles rotated by name like the Gen slots
     int prev_ye = -100, pre_row = -100;
     RowRaw pre = {0u, 0u, 0u};
@@ -161,29 +171,39 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     // one step: q = row whose row sums are produced into `cur`; `pm1`/`pm2` hold rows q-1 / q-2.
     // Afterwards cur.v is the response of row q-1, and the candidate row is q-2 (rows q-3, q-2, q-1 =
     // pm2.v (old), pm1.v (old), cur.v) -- the response slots lag the row-sum slots by one row.
-    auto step = [&](int q, Gen& pm2, Gen& pm1, Gen& cur, RowF& f0, RowF& f1, RowF& f2) {
+    // STEADY (compile-time): the caller guarantees rows q-1 .. q+1 are inside the image and that the previous
+    // step was row q-1, so f0 / f1 / `pre` are already what this step needs -- no reload path, hence no join
+    // whose register copies would land on the common path.
+    auto step = [&](auto steady_tag, int q, Gen& pm2, Gen& pm1, Gen& cur, RowF& f0, RowF& f1, RowF& f2) {
+      constexpr bool STEADY = decltype(steady_tag)::value;
       // on entry (steady state) f0 / f1 hold rows ye-1 / ye from the previous step and f2 is the dead slot
-      const int ye = reflect101(min(max(q, -1), h), h);
-      if (ye == prev_ye + 1 && ye + 1 < h) {
-        if (pre_row != ye + 1) pre = rowload(img, w, ye + 1, xm, xe, xp);  // scalar branch, not taken in steady state
+      if (STEADY) {
         f2 = rowfilt(pre, s, s2);
+        pre = rowload(img, w, min(q + 2, h - 1), xm, xe, xp);
       } else {
-        f0 = rowfilt(rowload(img, w, reflect101(ye - 1, h), xm, xe, xp), s, s2);
-        f1 = rowfilt(rowload(img, w, ye, xm, xe, xp), s, s2);
-        f2 = rowfilt(rowload(img, w, reflect101(ye + 1, h), xm, xe, xp), s, s2);
+        const int ye = reflect101(min(max(q, -1), h), h);
+        if (ye == prev_ye + 1 && ye + 1 < h) {
+          if (pre_row != ye + 1) pre = rowload(img, w, ye + 1, xm, xe, xp);  // scalar branch, not taken in steady state
+          f2 = rowfilt(pre, s, s2);
+        } else {
+          f0 = rowfilt(rowload(img, w, reflect101(ye - 1, h), xm, xe, xp), s, s2);
+          f1 = rowfilt(rowload(img, w, ye, xm, xe, xp), s, s2);
+          f2 = rowfilt(rowload(img, w, reflect101(ye + 1, h), xm, xe, xp), s, s2);
+        }
+        // bytes of the row the next step will filter: in flight during this step's arithmetic
+        pre_row = min(ye + 2, h - 1);
+        pre = rowload(img, w, pre_row, xm, xe, xp);
+        prev_ye = ye;
       }
-      // bytes of the row the next step will filter: in flight during this step's arithmetic
-      pre_row = min(ye + 2, h - 1);
-      pre = rowload(img, w, pre_row, xm, xe, xp);
-      prev_ye = ye;
       const float dx = (f0.rx + f2.rx) * s + f1.rx * s2;
       const float dy = f2.ry - f0.ry;
-      const float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
+      const pk2 g = pk2{dx, dy}, gg = g * g;  // v_pk_mul_f32
+      const float cxx = gg.x, cxy = dx * dy, cyy = gg.y;
       const float lxx = from_lane_below(cxx), lxy = from_lane_below(cxy), lyy = from_lane_below(cyy);
       const float rxx = from_lane_above(cxx), rxy = from_lane_above(cxy), ryy = from_lane_above(cyy);
       // response rows of the two previous steps, read before `cur` (= the slot of row q-3) is overwritten
-      const float v_up = pm2.v, l_up = pm2.l, r_up = pm2.r;    // response row q-3
-      const float v_mid = pm1.v, l_mid = pm1.l, r_mid = pm1.r;  // response row q-2
+      const float v_up = pm2.v;   // response row q-3
+      const float v_mid = pm1.v;  // response row q-2
       cur.xx = ((double)lxx + (double)cxx) + (double)rxx;
       cur.xy = ((double)lxy + (double)cxy) + (double)rxy;
       cur.yy = ((double)lyy + (double)cyy) + (double)ryy;
@@ -192,26 +212,32 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const double Axx = (pm2.xx + pm1.xx) + cur.xx;
       const double Axy = (pm2.xy + pm1.xy) + cur.xy;
       const double Ayy = (pm2.yy + pm1.yy) + cur.yy;
-      const float a = (float)Axx * 0.5f, b = (float)Axy, c = (float)Ayy * 0.5f;
-      const float d = a - c;
-      float t = d * d;
-      const float bb = b * b;
-      t = t + bb;
+      // lambda_min = (a + c) - sqrt((a - c)^2 + b^2) with a = X/2, c = Y/2.  Halving is exact, so it commutes
+      // with every rounding: a - c = fl(X - Y)/2, fl((a - c)^2) = fl((X - Y)^2)/4, a + c = fl(X + Y)/2; the two
+      // fused multiply-adds below round exactly the sums the unfused sequence rounds (their products are exact).
+      const float X = (float)Axx, b = (float)Axy, Y = (float)Ayy;
+      const pk2 pm = pk2{X, X} + pk2{Y, -Y};  // v_pk_add_f32 with neg_hi: (X + Y, X - Y)
+      const float xpy = pm.x, xmy = pm.y;
+      const pk2 sq = pk2{xmy, b} * pk2{xmy, b};
+      const float t = __builtin_fmaf(0.25f, sq.x, sq.y);
       // sqrtf is correctly rounded under hipcc's default flags; __fsqrt_rn is the approximate native sqrt
-      const float v_dn = (a + c) - sqrt_rn(t);
-      const float l_dn = from_lane_below(v_dn), r_dn = from_lane_above(v_dn);
+      const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t));
       if (own_col && y >= y0 && y < y_end) {
         if (STORE_RESPONSE) resp[y * w + x] = v_dn;
         vmax = fmax2(vmax, v_dn);
       }
-      // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn)
+      // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn): v_mid > 0 and no larger
+      // value among its 8 neighbours  <=>  v_mid >= max(neighbours, smallest positive float); the column maxima
+      // of the two neighbouring lanes bring in the six side neighbours
       const int yc = q - 2;
       if (yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1) {  // scalar
-        const float m8 = fmax3(fmax3(l_up, v_up, r_up), fmax3(l_mid, r_mid, l_dn), fmax2(v_dn, r_dn));
-        const bool is_cand = cand_col && v_mid > 0.f && !(m8 > v_mid);
-        const unsigned long long mask = __ballot(is_cand);
+        const float colmax = fmax3(v_up, v_mid, v_dn);
+        float m8 = fmax3(from_lane_below(colmax), from_lane_above(colmax), __builtin_bit_cast(float, 1));
+        m8 = fmax3(m8, v_up, v_dn);
+        const bool ge = v_mid >= m8;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ge) & cand_lanes;  // the compare's own lane mask
         if (mask != 0ull) {
-          if (is_cand) {
+          if (cand_col && ge) {
             const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
             const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
             const int p = n_wave + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -230,16 +256,27 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       // -- but pm1.v currently holds response row q-2, still needed as "v_up" next step; so the response
       // rows are kept in the slot that is overwritten last: cur (row sums of q) receives response q-1.
       cur.v = v_dn;
-      cur.l = l_dn;
-      cur.r = r_dn;
     };
     // response slots: after a step, cur.v = resp(q-1); at the next step (q+1) that slot is "pm1" and is
     // read as v_mid = resp(q-1) = resp((q+1)-2) -- consistent with the reads above.
     const int q_first = y0 - 2, q_last = y_end + 1;
-    for (int q = q_first; q <= q_last; q += 3) {
-      step(q, g0, g1, g2, fA, fB, fC);
-      step(q + 1, g1, g2, g0, fB, fC, fA);
-      step(q + 2, g2, g0, g1, fC, fA, fB);
+    typedef std::integral_constant<bool, true> Steady;
+    typedef std::integral_constant<bool, false> Generic;
+    if (q_first >= 1 && q_last + 1 < h) {  // scalar: a strip whose halo rows are all interior (13 of 15 at 480 rows)
+      step(Generic{}, q_first, g0, g1, g2, fA, fB, fC);
+      step(Steady{}, q_first + 1, g1, g2, g0, fB, fC, fA);
+      step(Steady{}, q_first + 2, g2, g0, g1, fC, fA, fB);
+      for (int q = q_first + 3; q <= q_last; q += 3) {
+        step(Steady{}, q, g0, g1, g2, fA, fB, fC);
+        step(Steady{}, q + 1, g1, g2, g0, fB, fC, fA);
+        step(Steady{}, q + 2, g2, g0, g1, fC, fA, fB);
+      }
+    } else {
+      for (int q = q_first; q <= q_last; q += 3) {
+        step(Generic{}, q, g0, g1, g2, fA, fB, fC);
+        step(Generic{}, q + 1, g1, g2, g0, fB, fC, fA);
+        step(Generic{}, q + 2, g2, g0, g1, fC, fA, fB);
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
