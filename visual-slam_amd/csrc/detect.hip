@@ -43,16 +43,13 @@ __device__ __forceinline__ RowRaw rowload(ImgSrd img, int w, int yr, unsigned xm
   return o;
 }
 
-typedef float pk2 __attribute__((ext_vector_type(2)));  // pairs for the packed fp32 VALU ops (two results per issue slot)
-
 __device__ __forceinline__ RowF rowfilt(RowRaw p, float s, float s2) {
   const float l = (float)p.l, m = (float)p.m, r = (float)p.r;
   RowF o;
   o.rx = r - l;
-  const pk2 sl_sr = pk2{l, r} * pk2{s, s};  // v_pk_mul_f32
-  float t = sl_sr.x;
+  float t = s * l;
   t = t + s2 * m;
-  t = t + sl_sr.y;
+  t = t + s * r;
   o.ry = t;
   return o;
 }
@@ -64,6 +61,28 @@ __device__ __forceinline__ float from_lane_below(float v) {  // lane i <- lane i
 }
 __device__ __forceinline__ float from_lane_above(float v) {  // lane i <- lane i+1
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// The same shift through the LDS crossbar (ds_bpermute_b32: no LDS memory, no VALU issue slot).  Measured on
+// gfx950 at 8 waves per SIMD (tools/probes/valu_rate.hip): v_add_f32 / v_fma_f32 2 cycles per wave-instruction;
+// v_mov_b32_dpp, v_cvt_f64_f32, v_cvt_f32_ubyte0, v_add_f64, v_pk_*_f32 and v_max3_f32 4; v_sqrt_f32 8.  K1 is
+// VALU-bound, so each product is widened to fp64 ONCE and its neighbours' copies are fetched as fp64: the copy from
+// the lane below by two DPP moves, the copy from the lane above over the otherwise idle LDS pipe (6 ds_bpermute
+// per row step measured best: 0 -> 0.231 ms per 256 images, 4 -> 0.219, 6 -> 0.212, 8 -> 0.219, 10 -> 0.243,
+// all 14 shifts of the step -> 0.295: one ds_bpermute costs about as much LDS time as 2.5 DPP moves cost VALU time).
+// addr = 4 * source lane (lane 0 / 63 wrap around: halo lanes, never used).
+__device__ __forceinline__ double shift_f64(double v, int addr) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)b);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(b >> 32));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// the fp64 value of the lane below as two DPP moves
+__device__ __forceinline__ double dpp_below_f64(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x138, 0xf, 0xf, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x138, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
 // one-instruction maximum of three finite floats (fmaxf chains compile to v_max_f32 pairs with
@@ -155,6 +174,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
     const bool cand_col = own_col && x >= 1 && x < w - 1;
     const unsigned long long cand_lanes = __builtin_amdgcn_ballot_w64(cand_col);
+    const int from_above = ((lane + 1) & 63) << 2;  // ds_bpermute address: the lane above
 
     // Three generations of row sums / response rows live in registers; the row loop is unrolled by
     // three with the roles rotated by NAME (no register-to-register moves).
@@ -197,16 +217,15 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       }
       const float dx = (f0.rx + f2.rx) * s + f1.rx * s2;
       const float dy = f2.ry - f0.ry;
-      const pk2 g = pk2{dx, dy}, gg = g * g;  // v_pk_mul_f32
-      const float cxx = gg.x, cxy = dx * dy, cyy = gg.y;
-      const float lxx = from_lane_below(cxx), lxy = from_lane_below(cxy), lyy = from_lane_below(cyy);
-      const float rxx = from_lane_above(cxx), rxy = from_lane_above(cxy), ryy = from_lane_above(cyy);
+      // fp64 row sums R(x, q) = (left + centre) + right of the three product images: each product is widened once
+      // and its two neighbours' copies are fetched as fp64 (exact either way)
+      const double dxx = (double)(dx * dx), dxy = (double)(dx * dy), dyy = (double)(dy * dy);
       // response rows of the two previous steps, read before `cur` (= the slot of row q-3) is overwritten
       const float v_up = pm2.v;   // response row q-3
       const float v_mid = pm1.v;  // response row q-2
-      cur.xx = ((double)lxx + (double)cxx) + (double)rxx;
-      cur.xy = ((double)lxy + (double)cxy) + (double)rxy;
-      cur.yy = ((double)lyy + (double)cyy) + (double)ryy;
+      cur.xx = (dpp_below_f64(dxx) + dxx) + shift_f64(dxx, from_above);
+      cur.xy = (dpp_below_f64(dxy) + dxy) + shift_f64(dxy, from_above);
+      cur.yy = (dpp_below_f64(dyy) + dyy) + shift_f64(dyy, from_above);
       // response of row y = q - 1 from the row sums of rows q-2, q-1, q
       const int y = q - 1;
       const double Axx = (pm2.xx + pm1.xx) + cur.xx;
@@ -216,10 +235,8 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       // with every rounding: a - c = fl(X - Y)/2, fl((a - c)^2) = fl((X - Y)^2)/4, a + c = fl(X + Y)/2; the two
       // fused multiply-adds below round exactly the sums the unfused sequence rounds (their products are exact).
       const float X = (float)Axx, b = (float)Axy, Y = (float)Ayy;
-      const pk2 pm = pk2{X, X} + pk2{Y, -Y};  // v_pk_add_f32 with neg_hi: (X + Y, X - Y)
-      const float xpy = pm.x, xmy = pm.y;
-      const pk2 sq = pk2{xmy, b} * pk2{xmy, b};
-      const float t = __builtin_fmaf(0.25f, sq.x, sq.y);
+      const float xpy = X + Y, xmy = X - Y;
+      const float t = __builtin_fmaf(0.25f, xmy * xmy, b * b);
       // sqrtf is correctly rounded under hipcc's default flags; __fsqrt_rn is the approximate native sqrt
       const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t));
       if (own_col && y >= y0 && y < y_end) {
