@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
   //   key' = ((accumulator + 256) << KEY_SHIFT) | m = one v_lshl_add_u32 on the accumulator and the row's
   // constant; |q| - 256 is added once at the end.  accumulator + 256 is in [0, 512], padded rows carry
   // MM_PAD_KEY (distance field 1023, above every real key', below 2^32).
-  uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu;
+  // Two independent (best, second) trackers -- one per MFMA tile of the super tile -- halve the length of the
+  // dependent med3 / min chain a wave has to walk per super tile (4 waves per SIMD cannot hide it); they are
+  // merged once, after the last super tile.
+  uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu, bB = 0xFFFFFFFFu, skB = 0xFFFFFFFFu;
   {
     uint32_t w0, w1;
     load_words(0, w0, w1);
@@ -226,14 +229,22 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
         for (int j = 0; j < 4; j++) {
           const int av = half ? acc1[4 * g + j] : acc0[4 * g + j];
           const uint32_t key = ((uint32_t)av << KEY_SHIFT) + rks[j];
-          sk = umed3(b, key, sk);
-          b = min(b, key);
+          if (half) {
+            skB = umed3(bB, key, skB);
+            bB = min(bB, key);
+          } else {
+            sk = umed3(b, key, sk);
+            b = min(b, key);
+          }
         }
       }
     }
     if (st + 1 < n_st) store_rows(buf ^ 1, st + 1, n0, n1);
     __syncthreads();
   }
+  // merge the two trackers (disjoint database rows): second = min(max(b, bB), sk, skB)
+  sk = min(umed3(b, bB, sk), skB);
+  b = min(b, bB);
   // merge the two lane halves of a query column (disjoint database rows)
   const uint32_t b2 = (uint32_t)__shfl_xor((int)b, 32), s2 = (uint32_t)__shfl_xor((int)sk, 32);
   sk = min(umed3(b, b2, sk), s2);
