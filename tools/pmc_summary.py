@@ -50,7 +50,7 @@ def main():
             kernels[stage] = ent
     doc = {
         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no tracing) of `python3 bench.py "
-                "--steps 3 --warmup 1 --cpu-frames 0 --no-ba --profile-steps 0` (batch 128 stereo frames = 256 images "
+                "--steps 3 --warmup 1 --cpu-frames 0 --no-ba --no-gba --no-e2e --profile-steps 1 --batch 128 --streams 1` (tools/refresh_profiles.sh; batch 128 stereo frames = 256 images "
                 "per launch). Raw counter values in KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the "
                 "bytes of a 16 B/lane stream and is uncalibrated for other widths -- the kernels here load 1-4 B per "
                 "lane, so `bytes_per_launch_uncorrected` = (FETCH + WRITE) * 1024 is a lower bound.",
