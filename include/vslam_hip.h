@@ -187,7 +187,9 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
 /* Diagnostic knobs for the parity tests (results never change, only which kernel path produces them):
  *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
- *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path) */
+ *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
+ *   "select_bucket_cap" (default 128) fullest response bin the selection kernel's counting sort accepts; 0 = always
+ *                                   the bitonic network */
 int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value);
 
 /* matchDescriptors for n_pairs (slot_a, slot_b) pairs; slot_pairs is a HOST

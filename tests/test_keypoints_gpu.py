@@ -138,6 +138,20 @@ def test_response_kernel_list_overflow_path(ctx, orc, images, cap):
     assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("cap", [0, 2, 100000])
+def test_selection_sort_paths_agree(ctx, orc, images, cap):
+    # cap 0: always the bitonic network; 2: counting sort only when no response bin holds more than two keys
+    # (falls back otherwise); huge: counting sort whatever the bins look like.  Same corners every way.
+    img = images["left"]
+    ctx.set_diagnostic("select_bucket_cap", cap)
+    try:
+        xy, ang, desc = ctx.detect_describe(img, 1500, True)
+    finally:
+        ctx.set_diagnostic("select_bucket_cap", 128)
+    oxy, oang, odesc = orc.detect_describe(img, 1500, True)
+    assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+
+
 def test_generic_describe_kernel_matches_fast_one(ctx, orc, images):
     img = images["right"]
     ctx.set_diagnostic("force_generic_describe", 1)

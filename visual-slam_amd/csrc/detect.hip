@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
 #define SEL_THREADS 1024
 #define SEL_CHUNK 8192
 #define SEL_EMPTY 0xFFFFFFFFu
+#define SEL_BINS 1024      // response bins of the counting sort (= threads of the workgroup)
 #define SEL_MAX_BLOCKERS 6  // blockers of a candidate kept in registers (more: the cell lists are walked again)
 
 struct SelShared {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
                                                              int32_t* __restrict__ kp_xy, int32_t* __restrict__ kp_count,
                                                              int w, int h, size_t cand_cap, int F, int first,
                                                              int num_features, int border, double quality,
-                                                             uint32_t* __restrict__ grid_scratch) {
+                                                             uint32_t* __restrict__ grid_scratch, int bucket_cap) {
   __shared__ __align__(16) unsigned char smem[GRID_GLOBAL ? (SEL_KEYS_PADDED * 8 + SEL_THREADS * 4 * 3 + 2048) : SEL_LDS_BYTES];
   const int slot = first + blockIdx.x;
   const uint64_t* __restrict__ cand = cand_all + (size_t)slot * cand_cap;
@@ -444,14 +445,64 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   const unsigned long long floor_key =
       (((unsigned long long)((uint32_t)vsl_float_to_ordered(thr) ^ 0x80000000u)) << 32) | 0xFFFFFFFFull;
   int remaining = 0;
+  // Sorting (first chunk, the normal case of at most SEL_CHUNK surviving candidates): a counting sort on the top
+  // bits of the response -- SEL_BINS bins between the threshold and the maximum (both known), bin 0 = largest --
+  // puts every key into its bin's slot range, and a key's final rank inside its bin is the number of larger keys
+  // there (bins hold a handful of keys: the responses of real images spread over ~6 binades = ~850 bins).  Four
+  // passes with a handful of workgroup barriers instead of the 35 LDS exchanges of the bitonic network for 8192
+  // keys, which stays as the path for later chunks and for bins fuller than bucket_cap (plateaus of equal responses).
+  int* bcount = next;                    // the three arrays alias next / cxy / state, which only the greedy uses
+  int* bstart = next + SEL_THREADS;
+  int* bcursor = next + 2 * SEL_THREADS;
+  static_assert(SEL_BINS == SEL_THREADS, "one bin per thread");
+  const uint32_t hi_max = (uint32_t)vsl_float_to_ordered(maxv) ^ 0x80000000u;
+  const uint32_t hi_floor = (uint32_t)vsl_float_to_ordered(thr) ^ 0x80000000u;
+  int bshift = 16;
+  while (bshift < 31 && (hi_max >> bshift) - (hi_floor >> bshift) >= (uint32_t)SEL_BINS) bshift++;
+  const uint32_t bin_top = hi_max >> bshift;
+  bool bucket_sort = false;
   if (maxv > 0.f) {
-    int mine = 0;
-    for (int i = tid; i < n_cand; i += SEL_THREADS) mine += cand[i] > floor_key;
+    bcount[tid] = 0;
     if (tid == 0) sh->n_chunk = 0;
     __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < n_cand; i += SEL_THREADS) {
+      const unsigned long long key = cand[i];
+      if (key > floor_key) {
+        mine++;
+        // a provisional candidate above the image maximum cannot exist; the clamp keeps a corrupted list in range
+        const uint32_t kb = min((uint32_t)(key >> 32) >> bshift, bin_top);
+        atomicAdd(&bcount[bin_top - kb], 1);
+      }
+    }
     if (mine) atomicAdd(&sh->n_chunk, mine);
     __syncthreads();
     remaining = sh->n_chunk;
+    // exclusive prefix of the bin counts (bin 0 first = descending keys) and the fullest bin
+    const int c = bcount[tid];
+    int x = c;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    int cmax = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    __syncthreads();  // everyone has read n_chunk
+    if (lane == 63) sh->wave_tot[wv] = x;
+    if (lane == 0) sh->hist[wv] = cmax;
+    __syncthreads();
+    int off = 0, fullest = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      off += k < wv ? sh->wave_tot[k] : 0;
+      fullest = max(fullest, sh->hist[k]);
+    }
+    bstart[tid] = off + x - c;
+    bcursor[tid] = 0;
+    bucket_sort = remaining <= SEL_CHUNK && fullest <= bucket_cap;
     __syncthreads();
   }
 
@@ -486,43 +537,80 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       }
       lo = prefix;  // = the SEL_CHUNK-th largest remaining key (keys are unique)
     }
-    // ---- gather the chunk into LDS and pad to a power of two
-    if (tid == 0) sh->n_chunk = 0;
-    __syncthreads();
-    for (int i = tid; i < n_cand; i += SEL_THREADS) {
-      const unsigned long long key = cand[i];
-      if (key >= lo && key < hi && key > floor_key) {
-        const int p = atomicAdd(&sh->n_chunk, 1);
-        if (p < SEL_CHUNK) keys[SEL_PHYS(p)] = key;
+    int n_chunk;
+    if (bucket_sort) {
+      // ---- scatter into the bins' slot ranges, then rank inside each bin
+      for (int i = tid; i < n_cand; i += SEL_THREADS) {
+        const unsigned long long key = cand[i];
+        if (key > floor_key) {
+          const int bin = (int)(bin_top - min((uint32_t)(key >> 32) >> bshift, bin_top));
+          const int p = bstart[bin] + atomicAdd(&bcursor[bin], 1);  // (SEL_PHYS evaluates its argument twice)
+          keys[SEL_PHYS(p)] = key;
+        }
       }
-    }
-    __syncthreads();
-    const int n_chunk = min(sh->n_chunk, SEL_CHUNK);
-    int N = 1024;
-    while (N < n_chunk) N <<= 1;
-    for (int i = n_chunk + tid; i < N; i += SEL_THREADS) keys[SEL_PHYS(i)] = 0ull;
-    __syncthreads();
-    // ---- bitonic sort, descending.  With 2, 4 or 8 keys per thread (N = 2048 / 4096 / 8192) the network is
-    // register-blocked (sel_sort_blocked): ceil(m / log2(keys per thread)) LDS exchanges for the stage k = 2^m,
-    // e.g. 35 workgroup barriers for 8192 keys instead of 91 (one per sub-step).
-    if (N >= 2048) {
-      if (N == 8192) sel_sort_blocked<3>(keys, tid, 13);
-      else if (N == 4096) sel_sort_blocked<2>(keys, tid, 12);
-      else sel_sort_blocked<1>(keys, tid, 11);
+      __syncthreads();
+      n_chunk = remaining;
+      unsigned long long mykey[SEL_CHUNK / SEL_THREADS];
+      int mypos[SEL_CHUNK / SEL_THREADS];
+#pragma unroll
+      for (int k = 0; k < SEL_CHUNK / SEL_THREADS; k++) {
+        const int p = tid + SEL_THREADS * k;
+        mypos[k] = -1;
+        if (p < n_chunk) {
+          const unsigned long long key = keys[SEL_PHYS(p)];
+          const int bin = (int)(bin_top - min((uint32_t)(key >> 32) >> bshift, bin_top));
+          const int s0 = bstart[bin], e0 = s0 + bcount[bin];
+          int larger = 0;
+          for (int q = s0; q < e0; q++) larger += keys[SEL_PHYS(q)] > key;
+          mykey[k] = key;
+          mypos[k] = s0 + larger;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < SEL_CHUNK / SEL_THREADS; k++)
+        if (mypos[k] >= 0) keys[SEL_PHYS(mypos[k])] = mykey[k];
+      __syncthreads();
+      bucket_sort = false;
     } else {
-      for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-            const int l = i | j;
-            const uint64_t a = keys[SEL_PHYS(i)], b = keys[SEL_PHYS(l)];
-            const bool desc = (i & k) == 0;
-            if (desc ? (a < b) : (a > b)) {
-              keys[SEL_PHYS(i)] = b;
-              keys[SEL_PHYS(l)] = a;
+      // ---- gather the chunk into LDS and pad to a power of two
+      if (tid == 0) sh->n_chunk = 0;
+      __syncthreads();
+      for (int i = tid; i < n_cand; i += SEL_THREADS) {
+        const unsigned long long key = cand[i];
+        if (key >= lo && key < hi && key > floor_key) {
+          const int p = atomicAdd(&sh->n_chunk, 1);
+          if (p < SEL_CHUNK) keys[SEL_PHYS(p)] = key;
+        }
+      }
+      __syncthreads();
+      n_chunk = min(sh->n_chunk, SEL_CHUNK);
+      int N = 1024;
+      while (N < n_chunk) N <<= 1;
+      for (int i = n_chunk + tid; i < N; i += SEL_THREADS) keys[SEL_PHYS(i)] = 0ull;
+      __syncthreads();
+      // ---- bitonic sort, descending.  With 2, 4 or 8 keys per thread (N = 2048 / 4096 / 8192) the network is
+      // register-blocked (sel_sort_blocked): ceil(m / log2(keys per thread)) LDS exchanges for the stage k = 2^m,
+      // e.g. 35 workgroup barriers for 8192 keys instead of 91 (one per sub-step).
+      if (N >= 2048) {
+        if (N == 8192) sel_sort_blocked<3>(keys, tid, 13);
+        else if (N == 4096) sel_sort_blocked<2>(keys, tid, 12);
+        else sel_sort_blocked<1>(keys, tid, 11);
+      } else {
+        for (int k = 2; k <= N; k <<= 1) {
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (N >> 1); t += SEL_THREADS) {
+              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const int l = i | j;
+              const uint64_t a = keys[SEL_PHYS(i)], b = keys[SEL_PHYS(l)];
+              const bool desc = (i & k) == 0;
+              if (desc ? (a < b) : (a > b)) {
+                keys[SEL_PHYS(i)] = b;
+                keys[SEL_PHYS(l)] = a;
+              }
             }
+            __syncthreads();
           }
-          __syncthreads();
         }
       }
     }
@@ -673,10 +761,11 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     VslStage st(ctx, VSL_STAGE_SELECT);
     if (grid_global)
       hipLaunchKernelGGL(select_kernel<true>, dim3(n), dim3(SEL_THREADS), 0, ctx->stream, f->cand, f->meta, f->kp_xy,
-                         f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, f->sel_grid);
+                         f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, f->sel_grid, ctx->select_bucket_cap);
     else
       hipLaunchKernelGGL(select_kernel<false>, dim3(n), dim3(SEL_THREADS), 0, ctx->stream, f->cand, f->meta, f->kp_xy,
-                         f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, (uint32_t*)nullptr);
+                         f->kp_count, w, h, f->cand_cap, f->F, first, num_features, 19, 0.01, (uint32_t*)nullptr,
+                         ctx->select_bucket_cap);
     VSL_CHECK_LAUNCH(ctx);
   }
   f->detect_meta_dirty = false;

@@ -50,6 +50,7 @@ struct vsl_ctx {
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
+  int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
   int k1_list_cap = 256;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
 
