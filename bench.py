@@ -60,8 +60,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="stereo frames per step per GPU")
+    ap.add_argument("--warmup", type=int, default=15)  # the chip's clock ramps for ~50 ms after idle: kernels of the first ~10 steps run up to 15 % slower
+    ap.add_argument("--batch", type=int, default=1024, help="stereo frames per step per GPU")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batch is split over (128 frames = 256 images per launch: one selection workgroup per CU)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs per rank")
