@@ -17,8 +17,12 @@
 
 #include "vsl_common.h"
 
-#define K1_ROWS 32
-#define K1_WLIST 256  // LDS candidate slots per wave (60 x 32 pixels); overflow goes straight to global memory
+// rows per wave strip; (K1_ROWS + 4) % 3 == 0 (the row loop is unrolled by three).  41 rows: 480 rows = 3 workgroups
+// of 4 x 41 with 2 % idle rows and 4 halo rows per 41 instead of per 32 (measured per 1024 images: 29 rows 0.771 ms,
+// 32: 0.740, 41: 0.712, 44: 0.716)
+#define K1_ROWS 41
+static_assert((K1_ROWS + 4) % 3 == 0, "row loop is unrolled by three");
+#define K1_WLIST 256  // LDS candidate slots per wave strip (60 x 41 pixels); overflow goes straight to global memory
 #define K1_COLS 60  // owned columns per wave: 64 lanes minus two halo lanes on each side
 
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -132,8 +136,8 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 }
 
 // K1 + K2a fused.  grid = (ceil(w/60), ceil(h/(4*K1_ROWS)), n_images), block = 256: wave v of a block owns the
-// K1_ROWS-row strip (blockIdx.y*4 + v) of the 60-column strip blockIdx.x (32 rows: every strip recomputes 4 halo
-// rows, so taller strips waste less -- 16 rows measured 0.280 ms, 24: 0.262, 32: 0.250, 48: 0.265 per 256 images).
+// K1_ROWS-row strip (blockIdx.y*4 + v) of the 60-column strip blockIdx.x (every strip recomputes 4 halo
+// rows, so taller strips waste less -- see K1_ROWS).
 // One image column per lane; rows
 // are walked top to bottom with the row-filter results, the fp64 row sums and three response rows held
 // in registers; column neighbours come from DPP lane shifts.  Nothing but the image is read and -- in
