@@ -135,7 +135,10 @@ __device__ __forceinline__ v4i_t expand16(uint32_t bits16) {
   return o;
 }
 
-__global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __restrict__ desc,
+#ifndef MM_WAVES
+#define MM_WAVES 8  // wavefronts (32 queries each) per workgroup; they share one expanded database tile (per 512 pairs: 4 waves 0.481 ms, 8: 0.450, 16: 0.467 on a slower box where 8 gave 0.470)
+#endif
+__global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint64_t* __restrict__ desc,
                                                            const int32_t* __restrict__ kp_count,
                                                            const int32_t* __restrict__ pair_slots,
                                                            uint32_t* __restrict__ best_key,
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
   const int slot_q = pair_slots[2 * pair + dir];      // queries (rows of the result)
   const int slot_d = pair_slots[2 * pair + 1 - dir];  // database (columns of the reference's loop)
   const int n_q = kp_count[slot_q], n_d = kp_count[slot_d];
-  const int q0 = blockIdx.x * 128;
+  const int q0 = blockIdx.x * (32 * MM_WAVES);
   if (q0 >= n_q) return;  // workgroup-uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -172,17 +175,22 @@ __global__ __launch_bounds__(256) void hamming_mfma_kernel(const uint64_t* __res
   }
 
   // tile fill: thread t expands words (t & 7) of database rows (t >> 3) and (t >> 3) + 32 of the super tile
+  // tile fill: the 64 rows x 8 words of a super tile are spread over the workgroup's threads (FILL_K words each)
+  constexpr int FILL_K = 64 * MM_WAVES >= 512 ? 1 : 512 / (64 * MM_WAVES);  // 2 with four waves, 1 with eight or more
+  const bool filler = tid < 512;  // sixteen waves: the first eight fill
+  constexpr int FILL_ROWS = 64 / FILL_K;         // rows covered per pass
   const int frow = tid >> 3, fword = tid & 7;
   auto load_words = [&](int st, uint32_t& w0, uint32_t& w1) {
-    const int r0 = st * 64 + frow, r1 = r0 + 32;
-    w0 = r0 < n_d ? dbase[(size_t)r0 * 8 + fword] : 0u;
-    w1 = r1 < n_d ? dbase[(size_t)r1 * 8 + fword] : 0u;
+    const int r0 = st * 64 + frow, r1 = r0 + FILL_ROWS;
+    w0 = (filler && r0 < n_d) ? dbase[(size_t)r0 * 8 + fword] : 0u;
+    w1 = (FILL_K > 1 && r1 < n_d) ? dbase[(size_t)r1 * 8 + fword] : 0u;
   };
   auto store_rows = [&](int buf, int st, uint32_t w0, uint32_t w1) {
+    if (!filler) return;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < FILL_K; k++) {
       const uint32_t wd = k ? w1 : w0;
-      const int lr = frow + 32 * k;
+      const int lr = frow + FILL_ROWS * k;
       unsigned char* dst = &tile[buf][lr * MM_ROW + fword * 32];
       *(v4i_t*)dst = expand16(wd & 0xFFFFu);
       *(v4i_t*)(dst + 16) = expand16(wd >> 16);
@@ -326,8 +334,8 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
       hipLaunchKernelGGL(hamming_best2_kernel<WAVES>, grid, dim3(64 * WAVES), 0, ctx->stream, f->kp_desc,
                          f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
     } else {
-      dim3 grid((f->F + 127) / 128, 2, n_pairs);
-      hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(256), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
+      dim3 grid((f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES), 2, n_pairs);
+      hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
                          f->best_key, f->second_key, f->F);
     }
     VSL_CHECK_LAUNCH(ctx);
