@@ -279,6 +279,45 @@ def test_full_batch_properties(ctx, orc, vsl, synth):
     fr.close()
 
 
+def test_bench_launch_size_and_ragged_ranges(ctx, orc, vsl, synth):
+    """The launch size bench.py uses (512 stereo frames = 1024 images per launch: 8-keypoint describe chunks, XCD-aware
+    grid, four selection rounds per CU) against oracle spot checks and twin slots, and sub-ranges whose start and
+    length are not multiples of eight (the describe grid deals images to the XCDs in octets)."""
+    B = 512
+    pairs_img = [synth.stereo_pair(500 + s) for s in range(8)]
+    batch = np.stack([pairs_img[(k // 2) % 8][k % 2] for k in range(2 * B)])
+    fr = vsl.Frames(ctx, 2 * B, 752, 480, 1500, max_pairs=B)
+    fr.upload(0, batch)
+    sp = np.array([[2 * k, 2 * k + 1] for k in range(B)], np.int32)
+    fr.detect_describe(0, 2 * B, 1500, True)
+    fr.resolve_ties()
+    fr.match(sp, 70, 1.2)
+    nk, nm = fr.counts(2 * B, B)
+    assert nk.min() > 500 and nm.min() > 50
+    ref = {}
+    for slot in (0, 9, 1023):
+        xy, ang, desc = fr.keypoints(slot)
+        oxy, oang, odesc = orc.detect_describe(batch[slot], 1500, True)
+        assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc) and np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
+        ref[slot % 16] = (xy, desc)
+    for slot in (16, 521, 1007):  # same image as slot % 16
+        xy, _, desc = fr.keypoints(slot)
+        if slot % 16 in ref:
+            assert np.array_equal(xy, ref[slot % 16][0]) and np.array_equal(desc, ref[slot % 16][1])
+    m = fr.matches(511)
+    d_l, d_r = fr.keypoints(1022)[2], fr.keypoints(1023)[2]
+    assert np.array_equal(m, orc.match_descriptors(d_l, d_r, 70, 1.2))
+    # ragged sub-range with a different feature count: slots 3 .. 11 (nine images), the rest must not change
+    before = fr.keypoints(12)[2].copy()
+    fr.detect_describe(3, 9, 400, True)
+    for slot in (3, 7, 10, 11):
+        xy, _, desc = fr.keypoints(slot)
+        oxy, _, odesc = orc.detect_describe(batch[slot], 400, True)
+        assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc), slot
+    assert np.array_equal(fr.keypoints(12)[2], before) and len(fr.keypoints(2)[0]) == nk[2]
+    fr.close()
+
+
 def test_randomized_differential(ctx, orc):
     """Seeded sweep over image content (smooth / blocky / noisy / saturated / low contrast), sizes and feature
     counts: the HIP path and the oracle must agree bit for bit on every case, including the matches between
