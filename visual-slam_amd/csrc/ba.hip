@@ -289,19 +289,21 @@ __global__ __launch_bounds__(256) void ba_lm_cols_kernel(BaDims D, const int* __
   }
 }
 
-// per-camera normal-equation block: H = sum F^T F (6x6) and g = sum F^T r over the camera's
-// observations (camera CSR), one workgroup per free camera, fixed-order tree reduction.
+// per-camera normal-equation block: H = sum F^T F (6x6) and g = sum F^T r over the camera's observations (camera
+// CSR).  grid = (free cameras, segments): a workgroup sums every `segments`-th 256-observation slice of its camera
+// (the local-BA window has ~11k observations per camera and only 12 free cameras: one workgroup per camera left
+// the chip idle for 128 us behind a serial chain of dependent loads), all 27 accumulators go through ONE LDS tree
+// (8 barriers, not 27 x 9), partials are summed per camera in segment order afterwards -- fixed order throughout.
 __global__ __launch_bounds__(256) void ba_cam_block_kernel(const int* __restrict__ free_cams,
                                                            const int* __restrict__ cam_start,
                                                            const int* __restrict__ cam_obs, const double* __restrict__ r,
-                                                           const double* __restrict__ F, double* __restrict__ H,
-                                                           double* __restrict__ g) {
-  __shared__ double sh[256];
-  const int fc = blockIdx.x;
+                                                           const double* __restrict__ F, double* __restrict__ part) {
+  __shared__ double sh[27][256];
+  const int fc = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y;
   const int cam = free_cams[fc];
   double acc[27];
   for (int k = 0; k < 27; k++) acc[k] = 0;
-  for (int q = cam_start[cam] + threadIdx.x; q < cam_start[cam + 1]; q += 256) {
+  for (int q = cam_start[cam] + seg * 256 + threadIdx.x; q < cam_start[cam + 1]; q += 256 * nseg) {
     const int i = cam_obs[q];
     const double* f = F + 12 * (size_t)i;
     const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
@@ -310,20 +312,37 @@ __global__ __launch_bounds__(256) void ba_cam_block_kernel(const int* __restrict
       for (int b = a; b < 6; b++) acc[k++] += f[a] * f[b] + f[6 + a] * f[6 + b];
     for (int a = 0; a < 6; a++) acc[21 + a] += f[a] * r0 + f[6 + a] * r1;
   }
-  double tot[27];
-  for (int k = 0; k < 27; k++) {
-    tot[k] = block_sum_256(acc[k], sh);
+#pragma unroll
+  for (int k = 0; k < 27; k++) sh[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int k = 0; k < 27; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+    }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    int k = 0;
-    for (int a = 0; a < 6; a++)
-      for (int b = a; b < 6; b++) {
-        H[36 * (size_t)fc + 6 * a + b] = tot[k];
-        H[36 * (size_t)fc + 6 * b + a] = tot[k];
-        k++;
-      }
-    for (int a = 0; a < 6; a++) g[6 * (size_t)fc + a] = tot[21 + a];
+  if (threadIdx.x < 27) part[((size_t)fc * nseg + seg) * 27 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ void ba_cam_block_finish_kernel(int nfree, int nseg, const double* __restrict__ part, double* __restrict__ H,
+                                           double* __restrict__ g) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nfree * 27) return;
+  const int fc = t / 27, k = t - fc * 27;
+  double v = 0;
+  for (int sgm = 0; sgm < nseg; sgm++) v += part[((size_t)fc * nseg + sgm) * 27 + k];
+  if (k >= 21) {
+    g[6 * (size_t)fc + (k - 21)] = v;
+  } else {
+    int a = 0, rem = k;  // k-th entry of the upper triangle, row-major
+    while (rem >= 6 - a) {
+      rem -= 6 - a;
+      a++;
+    }
+    const int bcol = a + rem;
+    H[36 * (size_t)fc + 6 * a + bcol] = v;
+    H[36 * (size_t)fc + 6 * bcol + a] = v;
   }
 }
 
@@ -545,24 +564,39 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
   if (tid < n) rhs_part[(size_t)blockIdx.x * n + tid] = racc;
 }
 
-// S = sum_g S_part[g] (fixed order) + blockdiag(H) + diag(D2_c);  rhs = sum_g rhs_part[g] + g_c
-__global__ void ba_schur_finish_kernel(int n, int G, const double* __restrict__ S_part, const double* __restrict__ rhs_part,
-                                       const double* __restrict__ H, const double* __restrict__ g_c,
-                                       const double* __restrict__ diag_c, double inv_radius, double* __restrict__ S,
-                                       double* __restrict__ rhs) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n * n) {
-    double v = 0;
-    for (int g = 0; g < G; g++) v += S_part[(size_t)g * n * n + idx];
-    const int i = idx / n, j = idx - i * n;
-    if (i / 6 == j / 6) v += H[36 * (size_t)(i / 6) + 6 * (i % 6) + (j % 6)];
-    if (i == j && diag_c) v += diag_c[i] * inv_radius;
-    S[idx] = v;
+// S = sum_g S_part[g] + blockdiag(H) + diag(D2_c);  rhs = sum_g rhs_part[g] + g_c.  A workgroup owns 16 consecutive
+// entries; 16 threads per entry each sum a sixteenth of the partials, the sixteen sub-sums are added in order (fixed
+// order, 16-deep dependent load chains instead of G-deep ones: 114 -> ~12 us for 256 partials of a 72 x 72 system).
+__global__ __launch_bounds__(256) void ba_schur_finish_kernel(int n, int G, const double* __restrict__ S_part,
+                                                              const double* __restrict__ rhs_part, const double* __restrict__ H,
+                                                              const double* __restrict__ g_c, const double* __restrict__ diag_c,
+                                                              double inv_radius, double* __restrict__ S, double* __restrict__ rhs) {
+  __shared__ double sh[16][17];
+  const int e = threadIdx.x & 15, c = threadIdx.x >> 4;
+  const int total = n * n + n;  // the n*n entries of S, then the n entries of rhs
+  const int idx = blockIdx.x * 16 + e;
+  const int per = (G + 15) / 16;
+  double v = 0;
+  if (idx < total) {
+    const bool is_rhs = idx >= n * n;
+    const double* src = is_rhs ? rhs_part + (idx - n * n) : S_part + idx;
+    const size_t stride = is_rhs ? (size_t)n : (size_t)n * n;
+    for (int g = c * per; g < min(G, (c + 1) * per); g++) v += src[(size_t)g * stride];
   }
-  if (idx < n) {
-    double v = 0;
-    for (int g = 0; g < G; g++) v += rhs_part[(size_t)g * n + idx];
-    rhs[idx] = v + g_c[idx];
+  sh[c][e] = v;
+  __syncthreads();
+  if (c == 0 && idx < total) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += sh[k][e];
+    if (idx < n * n) {
+      const int i = idx / n, j = idx - i * n;
+      if (i / 6 == j / 6) t += H[36 * (size_t)(i / 6) + 6 * (i % 6) + (j % 6)];
+      if (i == j && diag_c) t += diag_c[i] * inv_radius;
+      S[idx] = t;
+    } else {
+      rhs[idx - n * n] = t + g_c[idx - n * n];
+    }
   }
 }
 
@@ -912,11 +946,12 @@ struct DevBuf {
 struct BaState {
   BaDims D;
   int G = 1, lm_per_wg = 1, nb_obs = 1, nb_upd = 1;
+  int cb_seg = 1;  // workgroups per free camera in ba_cam_block_kernel
   bool small = true;
   std::vector<int> perm;  // sorted position -> caller observation index
   DevBuf poses, cand_poses, points, cand_points, intr, cam_intr, cam_free, free_cams, obs_cam, obs_lm, obs_uv, lm_start,
       cam_start, cam_obs, r, F, E, scale_c, scale_l, n2l, grad_l, H, g_c, diag_c, diag_l, gabs, S, rhs, S_part, rhs_part,
-      Pinv, bl, dc, dl, partials, scalars, flag;
+      Pinv, bl, dc, dl, partials, scalars, flag, cam_part;
 };
 
 #define BA_HIP(call)                                                                                   \
@@ -1027,6 +1062,9 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   BA_HIP(st.scale_l.alloc(8 * 3 * L));
   BA_HIP(st.n2l.alloc(8 * 3 * L));
   BA_HIP(st.grad_l.alloc(8 * 3 * L));
+  // enough workgroups per camera that a camera's observations are ~2 slices of 256 per workgroup (1 when cameras are many)
+  st.cb_seg = D.nfree > 0 ? std::max(1, std::min(32, (int)(D.O / std::max(1, D.nfree) / 512))) : 1;
+  BA_HIP(st.cam_part.alloc(8 * 27 * (size_t)std::max(1, D.nfree) * st.cb_seg));
   BA_HIP(st.H.alloc(8 * 36 * (size_t)D.nfree));
   BA_HIP(st.g_c.alloc(8 * n));
   BA_HIP(st.diag_c.alloc(8 * n));
@@ -1076,10 +1114,13 @@ int ba_columns(vsl_ctx* ctx, BaState& st) {
   VslStage s(ctx, VSL_STAGE_BA_LIN);
   hipLaunchKernelGGL(ba_lm_cols_kernel, dim3((D.L + 255) / 256), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                      st.r.as<double>(), st.E.as<double>(), st.n2l.as<double>(), st.grad_l.as<double>());
-  if (D.nfree > 0)
-    hipLaunchKernelGGL(ba_cam_block_kernel, dim3(D.nfree), dim3(256), 0, ctx->stream, st.free_cams.as<int>(),
+  if (D.nfree > 0) {
+    hipLaunchKernelGGL(ba_cam_block_kernel, dim3(D.nfree, st.cb_seg), dim3(256), 0, ctx->stream, st.free_cams.as<int>(),
                        st.cam_start.as<int>(), st.cam_obs.as<int>(), st.r.as<double>(), st.F.as<double>(),
-                       st.H.as<double>(), st.g_c.as<double>());
+                       st.cam_part.as<double>());
+    hipLaunchKernelGGL(ba_cam_block_finish_kernel, dim3((D.nfree * 27 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
+                       st.cb_seg, st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>());
+  }
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
@@ -1103,7 +1144,7 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
                          st.E.as<double>(), dgl, inv_radius, l0, lc, lpw, st.S_part.as<double>(),
                          st.rhs_part.as<double>(), Pinv, bl);
-    hipLaunchKernelGGL(ba_schur_finish_kernel, dim3((n * n + 255) / 256), dim3(256), 0, ctx->stream, n, G,
+    hipLaunchKernelGGL(ba_schur_finish_kernel, dim3((n * n + n + 15) / 16), dim3(256), 0, ctx->stream, n, G,
                        st.S_part.as<double>(), st.rhs_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), dgc,
                        inv_radius, st.S.as<double>(), st.rhs.as<double>());
   } else {
