@@ -718,51 +718,66 @@ __global__ void ba_add_cam_blocks_kernel(int nfree, const double* __restrict__ H
 // dense Cholesky solve in LDS, one workgroup; n <= 128.  dc = -(S^-1 rhs); flag = 0 on failure.
 __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double* __restrict__ S, const double* __restrict__ rhs,
                                                             double* __restrict__ dc, int* __restrict__ ok_flag) {
-  __shared__ double A[128 * 128 + 128];  // static: dynamic LDS above 64 KiB is refused by the runtime
-  double* bvec = A + n * n;
-  __shared__ int ok;
-  for (int i = threadIdx.x; i < n * n; i += 256) A[i] = S[i];
-  for (int i = threadIdx.x; i < n; i += 256) bvec[i] = rhs[i];
-  if (threadIdx.x == 0) ok = 1;
+  // Right-looking Cholesky in LDS, rows padded to an odd stride (column walks then spread over the banks).  Per
+  // column: every thread reads the (final) pivot itself, the column is scaled, one barrier, then thread pair
+  // (row, parity) updates its row's even / odd trailing entries, one barrier -- 2 barriers per column and no integer
+  // division (the first version spent 146 us on a 72 x 72 system: 3 barriers per column, t / m and t % m per
+  // updated entry, and 4 barriers per column in the substitutions, which one wavefront now does without any: 124 us.
+  // Batching the update's LDS reads eight entries ahead of the writes measured 156 us.  What remains is the
+  // latency of 72 pivot -> sqrt -> divide -> barrier rounds and 144 dependent substitution steps).
+  __shared__ double A[128 * 129 + 128];  // static: dynamic LDS above 64 KiB is refused by the runtime
+  const int ld = n | 1;
+  double* bvec = A + 128 * 129;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n * n; i += 256) {
+    const int r = i / n, c = i - r * n;
+    A[r * ld + c] = S[i];
+  }
+  for (int i = tid; i < n; i += 256) bvec[i] = rhs[i];
   __syncthreads();
+  bool good = true;
   for (int j = 0; j < n; j++) {
-    if (threadIdx.x == 0) {
-      const double d = A[j * n + j];
-      if (!(d > 0.0) || !isfinite(d)) ok = 0;
-      A[j * n + j] = sqrt(d);
+    const double d = A[j * ld + j];  // final since the previous column's last barrier; the same value in every thread
+    if (!(d > 0.0) || !isfinite(d)) {
+      good = false;
+      break;  // workgroup-uniform
     }
-    __syncthreads();
-    if (!ok) break;
-    const double djj = A[j * n + j];
-    for (int i = j + 1 + threadIdx.x; i < n; i += 256) A[i * n + j] /= djj;
-    __syncthreads();
-    // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i
-    const int m = n - j - 1;
-    for (int t = threadIdx.x; t < m * m; t += 256) {
-      const int i = j + 1 + t / m, k = j + 1 + t % m;
-      if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+    const double djj = sqrt(d);
+    for (int i = j + 1 + tid; i < n; i += 256) A[i * ld + j] /= djj;
+    __syncthreads();  // also orders everybody's read of the pivot before its overwrite below
+    if (tid == 0) A[j * ld + j] = djj;
+    // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i; thread pair (i, parity of k - j - 1)
+    const int i = j + 1 + (tid >> 1);
+    if (i < n) {
+      const double lij = A[i * ld + j];
+      for (int k = j + 1 + (tid & 1); k <= i; k += 2) A[i * ld + k] -= lij * A[k * ld + j];
     }
     __syncthreads();
   }
-  if (ok) {
-    // column-oriented substitutions: once x_j is final every later row subtracts its multiple in parallel
-    for (int j = 0; j < n; j++) {  // forward: L y = b
-      if (threadIdx.x == 0) bvec[j] /= A[j * n + j];
-      __syncthreads();
-      const double yj = bvec[j];
-      for (int i = j + 1 + threadIdx.x; i < n; i += 256) bvec[i] -= A[i * n + j] * yj;
-      __syncthreads();
+  if (good && tid < 64) {
+    // substitutions by one wavefront, two rows per lane, no workgroup barriers: L y = b, then L^T x = y
+    const int lane = tid, r0 = lane, r1 = lane + 64;
+    double b0 = r0 < n ? bvec[r0] : 0.0, b1 = r1 < n ? bvec[r1] : 0.0;
+    for (int j = 0; j < n; j++) {
+      const double yj = __shfl(j < 64 ? b0 : b1, j & 63) / A[j * ld + j];
+      if (lane == (j & 63)) {
+        if (j < 64) b0 = yj; else b1 = yj;
+      }
+      if (r0 > j && r0 < n) b0 -= A[r0 * ld + j] * yj;
+      if (r1 > j && r1 < n) b1 -= A[r1 * ld + j] * yj;
     }
-    for (int j = n - 1; j >= 0; j--) {  // backward: L^T x = y
-      if (threadIdx.x == 0) bvec[j] /= A[j * n + j];
-      __syncthreads();
-      const double xj = bvec[j];
-      for (int i = threadIdx.x; i < j; i += 256) bvec[i] -= A[j * n + i] * xj;
-      __syncthreads();
+    for (int j = n - 1; j >= 0; j--) {
+      const double xj = __shfl(j < 64 ? b0 : b1, j & 63) / A[j * ld + j];
+      if (lane == (j & 63)) {
+        if (j < 64) b0 = xj; else b1 = xj;
+      }
+      if (r0 < j) b0 -= A[j * ld + r0] * xj;
+      if (r1 < j) b1 -= A[j * ld + r1] * xj;
     }
-    for (int i = threadIdx.x; i < n; i += 256) dc[i] = -bvec[i];
+    if (r0 < n) dc[r0] = -b0;
+    if (r1 < n) dc[r1] = -b1;
   }
-  if (threadIdx.x == 0) *ok_flag = ok;
+  if (tid == 0) *ok_flag = good ? 1 : 0;
 }
 
 __global__ void ba_negate_kernel(int n, const double* __restrict__ y, double* __restrict__ dc) {
