@@ -403,7 +403,7 @@ inline __device__ bool inv3(const double* P, double* Pi) {
 
 // K7, small systems.  See the file header.  LB landmarks are staged per barrier pair.
 #define SCH_THREADS 1024
-#define SCH_LB 8
+#define SCH_LB 16
 #define SCH_KMAX 24   // observations of one landmark that hit FREE cameras (<= free cameras <= 21)
 #define SCH_EPT 16    // owned entries per thread: n <= 128
 #define SCH_CMAX 22   // free cameras
