@@ -279,13 +279,15 @@ def main():
 
             ba_dist.bundle_adjust_distributed(vsl, ctx, mk_g(), max_iters=1)   # warm-up: allocations, code objects
             times = {}
-            for iters in (3, 12):
+            for iters in (3, 12, 3, 12):  # best of two per length: the one-off set-up (~0.2 s) jitters by a few ms
                 a = mk_g()
                 ctx.synchronize()
                 t0 = time.perf_counter()
                 sg = ba_dist.bundle_adjust_distributed(vsl, ctx, a, max_iters=iters)
                 ctx.synchronize()
-                times[iters] = (time.perf_counter() - t0, sg.iterations)
+                dt = time.perf_counter() - t0
+                if iters not in times or dt < times[iters][0]:
+                    times[iters] = (dt, sg.iterations)
             (t3, i3), (t12, i12) = times[3], times[12]
             out["global_ba"] = {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d; "
                                             "session API, 1 rank" % (len(dg["poses"]), int(dg["cam_fixed"].sum()), len(dg["points"]),
