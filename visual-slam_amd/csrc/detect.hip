@@ -11,6 +11,8 @@
 //   R(x,y) = ((double)c(x-1,y) + c(x,y)) + c(x+1,y);  A = (R(x,y-1) + R(x,y)) + R(x,y+1)  (fp64)
 //   a = (float)A_xx*0.5f, b = (float)A_xy, c = (float)A_yy*0.5f
 //   response = (a + c) - sqrtf((a-c)*(a-c) + b*b)                                 (fp32)
+// (the kernel evaluates the last two lines as  t = fma(0.25, fl((X-Y)^2), fl(b*b)),  fma(0.5, fl(X+Y), -sqrt(t))  with
+// X = (float)A_xx, Y = (float)A_yy: halving is exact, so these two explicit FMAs round exactly the sums above)
 // BORDER_REFLECT_101 is applied to the image for the derivative and to the cov image for the box
 // sum (a lane or row outside the image evaluates the cov of its mirror position).
 #include <type_traits>
@@ -317,10 +319,11 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------------------ K2b
-// One 1024-thread workgroup per image.  The candidate keys are sorted (descending) in LDS in chunks
-// of at most SEL_CHUNK keys (a most-significant-digit radix select finds the chunk boundary when an
-// image has more candidates than that), and consumed in rank order, 1024 at a time, by an exact
-// parallel restatement of the reference's sequential greedy loop:
+// One 1024-thread workgroup per image.  The candidate keys above the quality threshold are sorted (descending) in
+// LDS -- a counting sort on the top response bits plus in-bin ranking for the usual case of at most SEL_CHUNK keys,
+// the bitonic network for chunks beyond that (a most-significant-digit radix select finds the chunk boundary) and
+// for over-full bins -- and consumed in rank order, 1024 at a time, by an exact parallel restatement of the
+// reference's sequential greedy loop:
 //   a candidate is dropped if an ALREADY ACCEPTED corner lies in the 3x3 neighbouring 8-px cells at
 //   squared distance < 64; among the survivors of one batch, a candidate waits for every
 //   higher-ranked survivor within that distance to be decided, is rejected if one of them was
