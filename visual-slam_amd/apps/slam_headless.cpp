@@ -103,14 +103,15 @@ int main(int argc, char** argv) {
   std::atomic<bool> go{false};
   auto run_stream = [&](Odometry& o, int* kf_count) {
     {  // per-thread warm-up outside the timed region: context creation, code objects of every kernel of a keyframe
-       // step and of a tracking step (a throw-away odometry object runs the first two frames), pinned buffers
+       // step and of a tracking step (a throw-away odometry object runs the first frames), pinned buffers
       KeypointsData kd;
       ImageRef l(left[0]);
       detectKeypointsAndDescriptors(l.img, kd, opt.num_features_per_image, opt.rotate_features);
       Odometry warm(calib, opt);
       warm.orb_voc = o.orb_voc;
-      warm.next_step(left[0], right[0], n_frames > 1 ? &left[1] : nullptr);
-      if (n_frames > 1) warm.next_step(left[1], right[1], nullptr);
+      // ... and enough frames (~50 ms of work) for the chip's clock to have ramped up from idle
+      const int n_warm = n_frames < 60 ? n_frames : 60;
+      for (int i = 0; i < n_warm; i++) warm.next_step(left[i], right[i], (lookahead && i + 1 < n_warm) ? &left[i + 1] : nullptr);
       warm.finish();
       warm.release_device();
     }
