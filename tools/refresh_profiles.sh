@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the measurements behind profiles/r01_*: run on the GPU box from the repo root
-# (gpurun -- 'bash tools/refresh_profiles.sh'), then copy gpurun_out/refresh/* into profiles/ as tools/README says.
+# (gpurun -- 'bash tools/refresh_profiles.sh'), then `bash tools/install_profiles.sh` here (tools/README.md).
 set -e
 R=$PWD
 mkdir -p gpurun_out/refresh
