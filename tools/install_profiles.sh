@@ -14,7 +14,7 @@ import csv, glob, statistics, re
 f = glob.glob('gpurun_out/refresh/kt1/runc/*_kernel_trace.csv')[0]
 print("rocprofv3 --kernel-trace of `python3 bench.py --batch 512 --streams 1 --cpu-frames 0 --no-ba --no-gba --no-e2e` (tools/refresh_profiles.sh):")
 print("per-launch kernel durations in microseconds, 512 stereo frames = 1024 images per launch")
-print("(15 warm-up + 20 timed + 5 profiled steps; the HIP events of bench.py cover the LAST 5).  After idle the chip's clock")
+print("(80 ms wake-up + 15 warm-up + 20 timed + 5 profiled steps; the HIP events of bench.py cover the LAST 5).  After idle the chip's clock")
 print("ramps for ~50 ms, so the all-launch average of the kernel_stats CSV is above the last-5 average.")
 d = {}
 for r in csv.DictReader(open(f)):
