@@ -1,0 +1,40 @@
+"""The committed bench line (profiles/r01_bench_line.json = the stdout of `python bench.py` on an MI355X) carries every
+key the benchmark contract names, with consistent values; and bench.py's command line still parses the driver's flags."""
+import json
+import pathlib
+import subprocess
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d = json.loads((ROOT / "profiles" / "r01_bench_line.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = frames of all ranks / time of the K timed steps
+    frames = d["n_gpus"] * d["config"]["stereo_frames_per_step_per_gpu"] * d["steps"]
+    assert abs(frames / (d["ms_per_step"] * 1e-3 * d["steps"]) - d["value"]) < 1e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-4
+    # achieved = algorithmic bytes per launch / average launch duration
+    assert abs(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 - r["achieved"]) < 1e-2 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == d["unit"]
+
+
+def test_bench_command_line_accepts_the_driver_flags():
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
