@@ -33,6 +33,16 @@ def test_committed_bench_line_has_the_contract_keys():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == d["unit"]
 
 
+def test_pmc_traffic_profile_matches_the_bench_launch_size():
+    # bench.py fills roofline.traffic from this file only when it was collected at the launch size it runs at
+    d = json.loads((ROOT / "profiles" / "r01_bench_line.json").read_text())
+    pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+    assert pm["batch_stereo_frames"] == d["config"]["stereo_frames_per_launch"]
+    k = pm["kernels"][d["roofline"]["kernel"]]
+    assert k["bytes_per_launch_uncorrected"] == (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024 or \
+        abs(k["bytes_per_launch_uncorrected"] - (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024) < 2048
+
+
 def test_bench_command_line_accepts_the_driver_flags():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
