@@ -110,7 +110,9 @@ __device__ __forceinline__ float fmax2(float a, float b) {  // no NaN canonicali
 // the neighbouring floats pick the correctly rounded one), minus that expansion's denormal pre-scaling
 // and inf/zero class test: t = 0 falls through both residual tests (NaN / zero compare false), and the
 // rare denormal-range t (rounding-noise gradients in an otherwise flat patch) takes the library path.
-__device__ __forceinline__ float sqrt_rn(float t) {
+// xmy = X - Y and bb = b * b are the operands t was formed from (t = fma(0.25, xmy * xmy, bb)): the rare path
+// re-forms t the unfused way.
+__device__ __forceinline__ float sqrt_rn(float t, float xmy, float bb) {
   float r = __builtin_amdgcn_sqrtf(t);
   const int rb = __builtin_bit_cast(int, r);
   const float rm = __builtin_bit_cast(float, rb - 1);
@@ -119,12 +121,21 @@ __device__ __forceinline__ float sqrt_rn(float t) {
   const float ep = __builtin_fmaf(-rp, r, t);
   r = (0.f >= em) ? rm : r;
   r = (0.f < ep) ? rp : r;
-  // 0 < sqrt(t) < 2^-47 (a superset of 0 < t < 2^-96, where the residuals lose bits), tested on the integer
-  // the correction computed anyway: one unsigned compare (r = 0 wraps to 0xffffffff and is not "tiny")
-  const bool tiny = (unsigned)(rb - 1) < 0x27FFFFFFu;
-  if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {  // wave-uniform branch: keeps the library expansion off the common path
+  // Rare path (wave-uniform branch), two reasons:
+  //  * 0 < sqrt(t) < 2^-47 (a superset of 0 < t < 2^-96, where the residuals lose bits), tested on the integer the
+  //    correction computed anyway: one unsigned compare (r = 0 wraps to 0xffffffff and is not "tiny");
+  //  * |X - Y| < 2^-62: ((X - Y)/2)^2 is then below FLT_MIN and rounds on the denormal grid, where
+  //    0.25 * fl((X - Y)^2) and fl(((X - Y)/2)^2) can differ by one denormal unit -- the only place where the fused
+  //    form of t is not the unfused sum bit for bit.  (Such X, Y are below 2e-12: flat, noise-level patches.)
+  const bool rare = (unsigned)(rb - 1) < 0x27FFFFFFu || __builtin_fabsf(xmy) < 0x1p-62f;
+  if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {  // keeps the library expansion off the common path
     asm volatile("" ::: "memory");  // not speculatable: stops the compiler from flattening the branch
-    if (tiny) r = sqrtf(t);
+    if (rare) {
+      const float d = 0.5f * xmy;
+      float t0 = d * d;
+      t0 = t0 + bb;
+      r = sqrtf(t0);
+    }
   }
   return r;
 }
@@ -239,12 +250,14 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const double Ayy = (pm2.yy + pm1.yy) + cur.yy;
       // lambda_min = (a + c) - sqrt((a - c)^2 + b^2) with a = X/2, c = Y/2.  Halving is exact, so it commutes
       // with every rounding: a - c = fl(X - Y)/2, fl((a - c)^2) = fl((X - Y)^2)/4, a + c = fl(X + Y)/2; the two
-      // fused multiply-adds below round exactly the sums the unfused sequence rounds (their products are exact).
+      // fused multiply-adds below round exactly the sums the unfused sequence rounds (their products are exact; the
+      // one exception, (X - Y)^2 / 4 in the denormal range, takes sqrt_rn's rare path).
       const float X = (float)Axx, b = (float)Axy, Y = (float)Ayy;
       const float xpy = X + Y, xmy = X - Y;
-      const float t = __builtin_fmaf(0.25f, xmy * xmy, b * b);
+      const float bb = b * b;
+      const float t = __builtin_fmaf(0.25f, xmy * xmy, bb);
       // sqrtf is correctly rounded under hipcc's default flags; __fsqrt_rn is the approximate native sqrt
-      const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t));
+      const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t, xmy, bb));
       if (own_col && y >= y0 && y < y_end) {
         if (STORE_RESPONSE) resp[y * w + x] = v_dn;
         vmax = fmax2(vmax, v_dn);
