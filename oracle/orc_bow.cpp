@@ -50,6 +50,45 @@ int forb_distance(const uint8_t* a, const uint8_t* b) {
   }
   return dist;
 }
+
+// BowVector::addWeight, BowVector.cpp:34-46
+void bow_add_weight(BowVector& bow, uint32_t id, double v) {
+  auto it = bow.lower_bound(id);
+  if (it != bow.end() && !(bow.key_comp()(id, it->first)))
+    it->second += v;
+  else
+    bow.insert(it, BowVector::value_type(id, v));
+}
+
+// BowVector::addIfNotExist, BowVector.cpp:50-58
+void bow_add_if_not_exist(BowVector& bow, uint32_t id, double v) {
+  auto it = bow.lower_bound(id);
+  if (it == bow.end() || bow.key_comp()(id, it->first)) bow.insert(it, BowVector::value_type(id, v));
+}
+
+// BowVector::normalize, BowVector.cpp:62-84 (norm_l 1 = L1, 2 = L2)
+void bow_normalize(BowVector& bow, int norm_l) {
+  double norm = 0.0;
+  if (norm_l == 1) {
+    for (auto& kv : bow) norm += fabs(kv.second);
+  } else {
+    for (auto& kv : bow) norm += kv.second * kv.second;
+    norm = sqrt(norm);
+  }
+  if (norm > 0.0)
+    for (auto& kv : bow) kv.second /= norm;
+}
+
+// FeatureVector::addFeature, FeatureVector.cpp:30-44
+void fv_add_feature(FeatureVector& fv, uint32_t id, uint32_t i_feature) {
+  auto it = fv.lower_bound(id);
+  if (it != fv.end() && it->first == id) {
+    it->second.push_back(i_feature);
+  } else {
+    it = fv.insert(it, FeatureVector::value_type(id, std::vector<uint32_t>()));
+    it->second.push_back(i_feature);
+  }
+}
 }  // namespace
 
 struct orc_voc {
@@ -170,38 +209,18 @@ void orc_bow_transform(const orc_voc* v, const uint8_t* desc32, int n, int level
     double w = 0;
     transform_one(v, desc32 + 32 * (size_t)i, id, w, &nid, levelsup);
     if (w > 0) {
-      if (tf) {
-        // BowVector::addWeight, BowVector.cpp:34-46
-        auto it = bow.lower_bound(id);
-        if (it != bow.end() && !(bow.key_comp()(id, it->first)))
-          it->second += w;
-        else
-          bow.insert(it, BowVector::value_type(id, w));
-      } else {
-        // BowVector::addIfNotExist, BowVector.cpp:50-58
-        auto it = bow.lower_bound(id);
-        if (it == bow.end() || bow.key_comp()(id, it->first)) bow.insert(it, BowVector::value_type(id, w));
-      }
-      // FeatureVector::addFeature, FeatureVector.cpp:30-44
-      fv[nid].push_back((uint32_t)i);
+      if (tf)
+        bow_add_weight(bow, id, w);
+      else
+        bow_add_if_not_exist(bow, id, w);
+      fv_add_feature(fv, nid, (uint32_t)i);
     }
   }
   if (tf && !bow.empty() && !must) {
     const double nd = (double)bow.size();
     for (auto& kv : bow) kv.second /= nd;
   }
-  if (must) {
-    // BowVector::normalize, BowVector.cpp:62-84
-    double norm = 0.0;
-    if (norm_l == 1) {
-      for (auto& kv : bow) norm += fabs(kv.second);
-    } else {
-      for (auto& kv : bow) norm += kv.second * kv.second;
-      norm = sqrt(norm);
-    }
-    if (norm > 0.0)
-      for (auto& kv : bow) kv.second /= norm;
-  }
+  if (must) bow_normalize(bow, norm_l);
   int j = 0;
   for (auto& kv : bow) {
     word_ids[j] = kv.first;
@@ -242,4 +261,39 @@ double orc_bow_score_l1(const uint32_t* ids1, const double* vals1, int n1, const
   }
   score = -score / 2.0;
   return score;
+}
+
+// Operation-stream replays of the container restatements above; oracle/ref_dbow2_driver.cpp replays the same
+// streams on the reference's own DBoW2::BowVector / FeatureVector objects (oracle/_ref/libdbow2_ref.so) and
+// tests/test_oracle_ref_pin.py asserts identical keys, value bit patterns and order.
+int orc_bowvec_stream(const uint32_t* ids, const double* vals, const uint8_t* ops, int n, int norm, uint32_t* out_ids,
+                      double* out_vals) {
+  BowVector bow;
+  for (int i = 0; i < n; i++) {
+    if (ops[i] == 0)
+      bow_add_weight(bow, ids[i], vals[i]);
+    else
+      bow_add_if_not_exist(bow, ids[i], vals[i]);
+  }
+  if (norm == 1 || norm == 2) bow_normalize(bow, norm);
+  int j = 0;
+  for (auto& kv : bow) {
+    out_ids[j] = kv.first;
+    out_vals[j] = kv.second;
+    j++;
+  }
+  return j;
+}
+
+int orc_featvec_stream(const uint32_t* nodes, const uint32_t* feats, int n, uint32_t* out_nodes, uint32_t* out_feats) {
+  FeatureVector fv;
+  for (int i = 0; i < n; i++) fv_add_feature(fv, nodes[i], feats[i]);
+  int j = 0;
+  for (auto& kv : fv)
+    for (uint32_t f : kv.second) {
+      out_nodes[j] = kv.first;
+      out_feats[j] = f;
+      j++;
+    }
+  return j;
 }

@@ -283,6 +283,71 @@ def bow_score_l1(ids1, v1, ids2, v2):
                                   ids2.ctypes.data_as(u32p), v2.ctypes.data_as(f64p), len(ids2))
 
 
+def _stream_args(ids, vals, ops):
+    ids = np.ascontiguousarray(ids, np.uint32)
+    vals = np.ascontiguousarray(vals, np.float64)
+    ops = np.ascontiguousarray(ops, np.uint8)
+    assert len(ids) == len(vals) == len(ops)
+    return ids, vals, ops
+
+
+def _bowvec_stream(fn, ids, vals, ops, norm):
+    ids, vals, ops = _stream_args(ids, vals, ops)
+    n = len(ids)
+    oi = np.zeros(max(n, 1), np.uint32)
+    ov = np.zeros(max(n, 1), np.float64)
+    fn.restype = C.c_int
+    m = fn(ids.ctypes.data_as(u32p), vals.ctypes.data_as(f64p), ops.ctypes.data_as(u8p), n, int(norm),
+           oi.ctypes.data_as(u32p), ov.ctypes.data_as(f64p))
+    return oi[:m].copy(), ov[:m].copy()
+
+
+def _featvec_stream(fn, nodes, feats):
+    nodes = np.ascontiguousarray(nodes, np.uint32)
+    feats = np.ascontiguousarray(feats, np.uint32)
+    n = len(nodes)
+    on = np.zeros(max(n, 1), np.uint32)
+    of = np.zeros(max(n, 1), np.uint32)
+    fn.restype = C.c_int
+    m = fn(nodes.ctypes.data_as(u32p), feats.ctypes.data_as(u32p), n, on.ctypes.data_as(u32p), of.ctypes.data_as(u32p))
+    return on[:m].copy(), of[:m].copy()
+
+
+def bowvec_stream(ids, vals, ops, norm):
+    """The restatement of BowVector::addWeight / addIfNotExist / normalize replayed on an operation stream."""
+    return _bowvec_stream(lib().orc_bowvec_stream, ids, vals, ops, norm)
+
+
+def featvec_stream(nodes, feats):
+    return _featvec_stream(lib().orc_featvec_stream, nodes, feats)
+
+
+_REF = None
+
+
+def ref_lib():
+    """oracle/_ref/libdbow2_ref.so: the REFERENCE's own BowVector.cpp / FeatureVector.cpp (compiled where they lie by
+    `make -C oracle ref`) behind oracle/ref_dbow2_driver.cpp.  Returns None when it is neither prebuilt nor buildable
+    (no /root/reference on this machine)."""
+    global _REF
+    if _REF is None:
+        so = _DIR / "_ref" / "libdbow2_ref.so"
+        if Path("/root/reference/thirdparty/DBoW2_ORBSLAM/DBoW2/BowVector.cpp").exists():
+            subprocess.run(["make", "-C", str(_DIR), "ref"], check=True, capture_output=True)
+        if not so.exists():
+            return None
+        _REF = C.CDLL(str(so))
+    return _REF
+
+
+def ref_bowvec_stream(ids, vals, ops, norm):
+    return _bowvec_stream(ref_lib().ref_bowvec_stream, ids, vals, ops, norm)
+
+
+def ref_featvec_stream(nodes, feats):
+    return _featvec_stream(ref_lib().ref_featvec_stream, nodes, feats)
+
+
 def project(model, intr8, p3):
     intr8 = np.ascontiguousarray(intr8, np.float64)
     p3 = np.ascontiguousarray(p3, np.float64)

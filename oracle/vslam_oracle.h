@@ -92,6 +92,12 @@ void orc_voc_info(const orc_voc*, int* k, int* L, int* n_nodes, int* n_words);
  * FeatureVector.cpp:30-44).  Capacities: n each. */
 void orc_bow_transform(const orc_voc*, const uint8_t* desc32, int n, int levelsup, uint32_t* word_ids,
                        double* word_vals, int* nnz, uint32_t* fv_node, uint32_t* fv_feat, int* fv_n);
+/* Operation-stream replays of the BowVector / FeatureVector restatements (ops: 0 addWeight, 1 addIfNotExist;
+ * norm: 0 none, 1 L1, 2 L2) -- REFERENCE-PINNED: compared bit for bit with the reference's own classes compiled
+ * into oracle/_ref/libdbow2_ref.so (BowVector.cpp:34-84, FeatureVector.cpp:30-44). */
+int orc_bowvec_stream(const uint32_t* ids, const double* vals, const uint8_t* ops, int n, int norm, uint32_t* out_ids,
+                      double* out_vals);
+int orc_featvec_stream(const uint32_t* nodes, const uint32_t* feats, int n, uint32_t* out_nodes, uint32_t* out_feats);
 /* ScoringObject.cpp:23-68 */
 double orc_bow_score_l1(const uint32_t* ids1, const double* v1, int n1, const uint32_t* ids2,
                         const double* v2, int n2);

@@ -165,7 +165,7 @@ def test_generic_describe_kernel_matches_fast_one(ctx, orc, images):
         ctx.set_diagnostic("no_such_knob", 1)
 
 
-@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("k", range(16))  # 16 real EuRoC pairs of the reference's data/euroc_V1 (tools/make_golden.py)
 def test_golden_euroc(ctx, k):
     g = np.load(GOLDEN / ("euroc_pair%d.npz" % k))
     for c in (0, 1):

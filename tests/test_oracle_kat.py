@@ -112,7 +112,7 @@ def test_good_features_semantics(orc):
     assert np.all(kp[:, 0] >= 19) and np.all(kp[:, 1] >= 19)
 
 
-@pytest.mark.parametrize("k", [0, 1])
+@pytest.mark.parametrize("k", range(16))  # 16 real EuRoC pairs of the reference's data/euroc_V1 (tools/make_golden.py)
 def test_oracle_reproduces_golden(orc, k):
     g = np.load(GOLDEN / ("euroc_pair%d.npz" % k))
     descs = []

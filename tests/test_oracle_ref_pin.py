@@ -1,0 +1,94 @@
+"""CPU: the ONE place the oracle is pinned by the reference's own code.
+
+`oracle/_ref/libdbow2_ref.so` is the reference's thirdparty/DBoW2_ORBSLAM/DBoW2/BowVector.cpp (addWeight :34-46,
+addIfNotExist :50-58, normalize :62-84) and FeatureVector.cpp (addFeature :30-44), compiled unmodified where they
+lie (`make -C oracle ref`).  The restatement in oracle/orc_bow.cpp must produce identical maps -- same keys, same
+order, same f64 bit patterns -- on the same operation streams:
+  * live, against the reference objects, wherever the library exists (this container; prebuilt on the GPU box);
+  * against tests/golden/dbow2_ref_streams.npz, outputs of the reference objects written by
+    tools/make_ref_bow_golden.py, everywhere.
+"""
+import importlib.util
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("make_ref_bow_golden", ROOT / "tools" / "make_ref_bow_golden.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _same_f64(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_restatement_matches_reference_golden(orc):
+    g = np.load(GOLDEN / "dbow2_ref_streams.npz")
+    gen = _gen()
+    for name, ids, vals, ops, norm in gen.streams():
+        # the committed inputs are the generator's streams (the fixture is self-describing)
+        assert np.array_equal(g[name + "_ids"], ids) and _same_f64(g[name + "_vals"], vals)
+        oi, ov = orc.bowvec_stream(g[name + "_ids"], g[name + "_vals"], g[name + "_ops"], int(g[name + "_norm"]))
+        assert np.array_equal(oi, g[name + "_out_ids"]), name
+        assert _same_f64(ov, g[name + "_out_vals"]), name
+    for name, nodes, feats in gen.fv_streams():
+        on, of = orc.featvec_stream(g[name + "_nodes"], g[name + "_feats"])
+        assert np.array_equal(on, g[name + "_out_nodes"]) and np.array_equal(of, g[name + "_out_feats"]), name
+
+
+def test_restatement_matches_reference_objects_live(orc):
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref/libdbow2_ref.so not built and /root/reference absent on this machine")
+    rng = np.random.default_rng(99)
+    for trial in range(60):
+        n = int(rng.integers(0, 3000))
+        n_ids = int(rng.choice([1, 7, 300, 5000, 2 ** 31]))
+        ids = rng.integers(0, n_ids, n, dtype=np.uint32)
+        vals = np.exp(rng.uniform(-20, 10, n)) * rng.choice([1.0, -1.0], n, p=[0.8, 0.2])
+        vals[rng.random(n) < 0.05] = 0.0
+        ops = (rng.random(n) < rng.choice([0.0, 0.3, 1.0])).astype(np.uint8)
+        norm = int(rng.integers(0, 3))
+        oi, ov = orc.bowvec_stream(ids, vals, ops, norm)
+        ri, rv = orc.ref_bowvec_stream(ids, vals, ops, norm)
+        assert np.array_equal(oi, ri), trial
+        assert _same_f64(ov, rv), trial
+        nodes = rng.integers(0, max(1, n_ids // 3), n, dtype=np.uint32)
+        feats = rng.integers(0, 2 ** 32, n, dtype=np.uint32)
+        on, of = orc.featvec_stream(nodes, feats)
+        rn, rf = orc.ref_featvec_stream(nodes, feats)
+        assert np.array_equal(on, rn) and np.array_equal(of, rf), trial
+
+
+def test_transform_tail_is_the_pinned_container_code(orc, synth, tmp_path):
+    """orc_bow_transform's container half (everything after the tree descent) equals the reference classes driven
+    with the per-descriptor (word, weight, node) triples: recover the triples by transforming one descriptor at a
+    time (un-normalised weight = the leaf weight), replay them on the reference objects, compare with the batch."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref/libdbow2_ref.so not built and /root/reference absent on this machine")
+    p = tmp_path / "voc.txt"
+    p.write_text(synth.vocabulary_text(3, k=10, L=3))
+    voc = orc.Vocabulary(p)
+    rng = np.random.default_rng(5)
+    f = rng.integers(0, 256, (600, 32), dtype=np.uint8)
+    ids, vals, fn, ff = voc.transform(f, levelsup=1)
+    words, nodes, feats = [], [], []
+    # leaf weights from the vocabulary text: line i+1 describes node i+1; word ids number the leaves in file order
+    lines = p.read_text().splitlines()[1:]
+    leaf_w = [float(ln.split()[-1]) for ln in lines if ln.split()[1] == "1"]
+    for i in range(len(f)):
+        wi, wv, ni, _ = voc.transform(f[i:i + 1], levelsup=1)
+        if len(wi):
+            words.append(int(wi[0]))
+            nodes.append(int(ni[0]))
+            feats.append(i)
+    w = np.array([leaf_w[k] for k in words])
+    ri, rv = orc.ref_bowvec_stream(np.array(words, np.uint32), w, np.zeros(len(words), np.uint8), 1)
+    rn, rf = orc.ref_featvec_stream(np.array(nodes, np.uint32), np.array(feats, np.uint32))
+    assert np.array_equal(ids, ri) and _same_f64(vals, rv)
+    assert np.array_equal(fn, rn) and np.array_equal(ff, rf)

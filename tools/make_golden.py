@@ -2,7 +2,10 @@
 """Generate tests/golden/*.npz -- run ONCE in the build container (needs /root/reference for the
 EuRoC-shaped input images; nothing under tests/ reads the reference at run time).
 
-Inputs : two stereo pairs of the reference's data/euroc_V1 (752x480 8-bit gray JPEG), decoded here
+Inputs : 16 stereo pairs of the reference's data/euroc_V1 (752x480 8-bit gray JPEG; the first two of the directory,
+         four spread over the 82 listed in its timestamps.txt, and the run of ten consecutive 20 Hz frames at its end
+         -- the only consecutive frames the reference ships, also the real-image sequence of the headless harness
+         test), decoded here
          with PIL and stored as raw pixels (JPEG decoders differ between versions, so the pixels --
          not the JPEGs -- are the fixture).
 Outputs: what the CPU oracle (oracle/, a restatement of include/visnav/keypoints.h) produces for
@@ -21,7 +24,15 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as entry  # noqa: E402
 
-PAIRS = ["1403715273262142976", "1403715308112143104"]
+def pick_pairs(ref):
+    stamps = sorted({f.name.split("_")[0] for f in (ref / "data/euroc_V1").glob("*_0.jpg")})
+    assert len(stamps) == 100
+    first = ["1403715273262142976", "1403715308112143104"]          # pair0 / pair1 of round 1 (kept)
+    spread = [stamps[i] for i in (10, 30, 50, 70)]
+    tail = stamps[-12:-2]                                            # ten frames 50 ms apart
+    out = first + [s for s in spread + tail if s not in first]
+    assert len(out) == 16
+    return out
 
 
 def main():
@@ -29,7 +40,7 @@ def main():
     orc = entry.load_oracle()
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
-    for k, stamp in enumerate(PAIRS):
+    for k, stamp in enumerate(pick_pairs(ref)):
         imgs = [np.array(Image.open(ref / "data/euroc_V1" / ("%s_%d.jpg" % (stamp, c)))) for c in (0, 1)]
         rec = {"stamp": np.array(stamp)}
         descs = []
