@@ -5,21 +5,26 @@ Metric (BASELINE.json): stereo frames/sec on synthetic 752x480 stereo, 1500 feat
 (configs[1]); one rank per GPU, every rank owns independent streams (configs[3]: weak scaling, no
 data-path collective).
 
-One STEP = one pass of the per-frame hot path over a batch of B stereo frames already resident in
-HBM:   detectKeypointsAndDescriptors on 2B images (K1 response, K2 selection, K3+K4 orientation +
-rBRIEF-256)  ->  exactness guard (vsl_frames_resolve_ties: one stream sync + 4-byte readback)  ->
-matchDescriptors(left, right, 70, 1.2) on B pairs (K5).  Outputs stay in HBM (the PCIe-inclusive
-host-buffer rate is reported in DESIGN.md, never as `value`).  The batch is split over S HIP streams
-(default 2 x 128 stereo frames): the selection kernel is one latency-bound workgroup per image and
-leaves most of each CU's issue slots free, so the other stream's response / describe kernels run
-underneath it.
+One PASS = the per-frame hot path over B distinct stereo frames already resident in HBM:
+detectKeypointsAndDescriptors on 2B images (K1 response, K2 selection, K3+K4 orientation + rBRIEF-256)
+->  exactness guard (vsl_frames_resolve_ties: one stream sync + 4-byte readback)  ->
+matchDescriptors(left, right, 70, 1.2) on B pairs (K5); outputs stay in HBM.  The batch is split over S HIP
+streams (default 2 x 512 stereo frames): the selection kernel is one latency-bound workgroup per image and leaves
+most of each CU's issue slots free, so the other stream's response / describe kernels run underneath it.
+One STEP = `--passes` passes (default 14, ~55 ms), so that the driver's 20 timed steps cover > 1 s of sustained
+clocks.  `value` = frames of all passes / time, inputs resident in HBM (the contract's definition).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+Next to it, at N = 1, the STREAMING mode measures the same hot path fed from the host (`value_incl_upload`):
+the B distinct stereo pairs sit in a pinned host ring, an upload context copies the next 512-frame batch into the
+idle one of two frame stores while the other one is being processed (vsl_event hand-offs, no host round trip),
+and the per-pair match counts are read back per batch.  It reports the PCIe rate achieved and which side bounds.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--passes P]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel stage, timed with HIP events on
-the stream the kernels run on; `cpu_baseline` is the CPU oracle (a port of the reference's path, the
-reference itself cannot be built offline) timed on this box's host cores on a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, timed with HIP events on the stream the
+kernels run on; `cpu_baseline` is the CPU oracle (a port of the reference's path, the reference itself cannot be
+built offline) timed on this box's host cores on a bounded sample of the same frames.
 """
 import argparse
 import importlib
@@ -36,39 +41,150 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as entry  # noqa: E402
 
 W, H, NUM_FEATURES = 752, 480, 1500
+SYNTH_MARGIN = 24  # synth.stereo_pair(margin=24): the 1500 strongest corners are interior, ~1500 keypoints survive the border filter
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achievable)
 I8_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2x the 2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, MFMA table)
 
 
 def stage_algorithmic_bytes(stage, n_img, n_pairs, kp_total, cand_total, match_total):
-    """Compulsory bytes of one launch of a stage over the whole batch (DESIGN.md 'Kernels')."""
+    """Compulsory bytes of one launch of a stage over the whole batch (DESIGN.md 'Kernels'):
+    one read of each input and one write of each OUTPUT of the path -- intermediates (provisional candidate keys,
+    best / second keys) are not counted."""
     px = W * H
-    if stage == "response":      # K1+K2a fused: image in, provisional candidate keys out (no response image)
-        return n_img * px + 8 * cand_total
+    if stage in ("response", "detect_describe"):
+        # 8(d) row "detect+angle+describe": image in, (xy 16 + angle 8 + descriptor 32) B per keypoint out; the
+        # response kernel is priced with the figure of the stage it dominates
+        return n_img * px + 56 * kp_total
     if stage == "select":        # K2b: candidate keys in, selected corners out
         return 8 * cand_total + 8 * kp_total
     if stage == "describe":      # K3+K4: 709-px disc + position in, moments/angle/descriptor out
         return kp_total * (709 + 8 + 8 + 8 + 32)
-    if stage == "match":         # K5: both descriptor sets in (per direction), best/second keys out
-        return 2 * kp_total * 32 + kp_total * 8
+    if stage == "match":         # 8(d) row "match": both descriptor sets in, match list out
+        return kp_total * 32 + match_total * 8
     if stage == "match_finalize":
         return kp_total * 8 + match_total * 8
     return 0
+
+
+def _gen_scene(job):
+    seed, n_variants = job
+    synth = importlib.import_module("visual_slam_amd.synth")
+    return synth.stereo_pair_variants(seed, n_variants, margin=SYNTH_MARGIN)
+
+
+def distinct_stereo_frames(seeds, n_variants, workers):
+    """(len(seeds) * n_variants, 2, H, W) uint8: every stereo pair distinct (scene x sensor-noise realisation).
+    Called BEFORE anything touches the GPU (worker processes are forked)."""
+    jobs = [(int(s), n_variants) for s in seeds]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.map(_gen_scene, jobs)
+    else:
+        parts = [_gen_scene(j) for j in jobs]
+    return np.concatenate(parts, axis=0)
+
+
+def streaming_measurement(vsl, units, ring, Bu, slot_pairs, seconds, device, expect_matches):
+    """Upload-inclusive throughput of the same hot path (N = 1).  `ring` = pinned host array (B, 2, H, W) of distinct
+    stereo pairs; the two frame stores of `units` are the double buffer: an upload context copies batch k+1 into the
+    idle store while batch k is processed (vsl_event hand-offs on the device), and batch k's per-pair match counts are
+    read back before batch k+1 is enqueued.  Mirrors the reference's order load -> detect x2 -> match
+    (src/slam.cpp:1122-1141)."""
+    n_img = 2 * Bu
+    chunks = [ring[c * Bu:(c + 1) * Bu].reshape(n_img, H, W) for c in range(len(ring) // Bu)]
+    bufs = [units[0], units[1]]
+    copy_ctx = vsl.Context(device)  # its own stream
+    uploaded = [vsl.Event(copy_ctx) for _ in range(2)]
+    computed = [vsl.Event(copy_ctx) for _ in range(2)]
+    batch_bytes = n_img * W * H
+
+    def enqueue_upload(k):
+        b = k % 2
+        copy_ctx.wait_event(computed[b])          # the store's previous batch has been consumed
+        bufs[b][2].upload_async(0, chunks[k % len(chunks)], ctx=copy_ctx)
+        uploaded[b].record(copy_ctx)
+
+    def compute(k):
+        b = k % 2
+        _, c, fr = bufs[b]
+        c.wait_event(uploaded[b])
+        fr.detect_describe(0, n_img, NUM_FEATURES, True)
+        fr.resolve_ties()
+        fr.match(slot_pairs, 70, 1.2)
+        computed[b].record(c)
+        return fr.counts(0, Bu)[1]                 # per-batch readback (host sync on this batch)
+
+    def run(min_seconds, check):
+        ok = True
+        for _, c, _ in bufs:
+            c.synchronize()
+        copy_ctx.synchronize()
+        t0 = time.perf_counter()
+        enqueue_upload(0)
+        k = 0
+        while True:
+            more = (time.perf_counter() - t0) < min_seconds
+            if more:
+                enqueue_upload(k + 1)
+            nm = compute(k)
+            if check:
+                ok = ok and np.array_equal(nm, expect_matches[k % len(chunks)])
+            k += 1
+            if not more:
+                break
+        copy_ctx.synchronize()
+        return k, time.perf_counter() - t0, ok
+
+    run(0.15, False)                                # warm-up (first-touch of the pinned pages by the DMA engine)
+    n_batches, dt, ok = run(seconds, True)
+    # copy alone (the PCIe ceiling as this process sees it) for the same batch size
+    copy_ctx.synchronize()
+    t0 = time.perf_counter()
+    n_copy = 0
+    while time.perf_counter() - t0 < 0.3:
+        for _ in range(4):
+            bufs[n_copy % 2][2].upload_async(0, chunks[n_copy % len(chunks)], ctx=copy_ctx)
+            n_copy += 1
+        copy_ctx.synchronize()
+    dt_copy = time.perf_counter() - t0
+    for e in uploaded + computed:
+        e.close()
+    copy_ctx.close()
+    fps = n_batches * Bu / dt
+    copy_only_fps = n_copy * Bu / dt_copy
+    return {"value_incl_upload": round(fps, 2),
+            "h2d_gbps": round(n_batches * batch_bytes / dt / 1e9, 2),
+            "streaming": {"what": "pinned host ring of %d distinct stereo pairs -> upload context (async H2D of %d-frame "
+                                  "batches into the idle one of two frame stores) -> detect+describe x2 + match -> per-pair "
+                                  "match counts read back per batch" % (len(ring), Bu),
+                          "stereo_frames": n_batches * Bu, "timed_region_s": round(dt, 3),
+                          "h2d_gbps_copy_alone": round(n_copy * batch_bytes / dt_copy / 1e9, 2),
+                          "frames_per_s_copy_alone": round(copy_only_fps, 1),
+                          "bound": "pcie (host->device copy)" if fps > 0.85 * copy_only_fps else "kernels",
+                          "outputs_equal_resident_run": bool(ok)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=15)  # the chip's clock ramps for ~50 ms after idle: kernels of the first ~10 steps run up to 15 % slower
-    ap.add_argument("--batch", type=int, default=1024, help="stereo frames per step per GPU")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="distinct stereo frames resident in HBM per GPU (one pass)")
+    ap.add_argument("--passes", type=int, default=14,
+                    help="passes over the resident batch per step (14 x 1024 frames ~ 55 ms: 20 steps > 1 s of sustained clocks)")
     ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the batch is split over (128 frames = 256 images per launch: one selection workgroup per CU)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs per rank")
-    ap.add_argument("--cpu-frames", type=int, default=200, help="stereo frames of the CPU-baseline sample (0 = skip)")
+                    help="HIP streams the batch is split over (512 frames = 1024 images per launch)")
+    ap.add_argument("--scenes", type=int, default=64,
+                    help="distinct synthetic scenes per rank; batch / scenes sensor-noise realisations of each, so every "
+                         "resident stereo pair is distinct")
+    ap.add_argument("--gen-workers", type=int, default=8, help="processes generating the synthetic frames (before GPU init)")
+    ap.add_argument("--cpu-frames", type=int, default=600, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--clock-ramp-ms", type=float, default=80.0,
-                    help="set-up: run the step for this long before the warm-up steps (the chip's clock ramps up from idle)")
+                    help="set-up: run passes for this long before the warm-up steps (the chip's clock ramps up from idle)")
+    ap.add_argument("--stream-seconds", type=float, default=1.5,
+                    help="N = 1: length of the upload-inclusive streaming measurement (0 = skip)")
     ap.add_argument("--no-ba", dest="ba", action="store_false", help="skip the local-BA ms/iter measurement")
     ap.add_argument("--no-gba", dest="gba", action="store_false",
                     help="skip the global-BA ms/iter measurement (BASELINE configs[4] scale, one rank)")
@@ -77,14 +193,29 @@ def main():
     ap.add_argument("--e2e-frames", type=int, default=90)
     args = ap.parse_args()
 
-    import torch
-
     vsl = entry.load_package()
     synth = importlib.import_module("visual_slam_amd.synth")
     vdist = importlib.import_module("visual_slam_amd.dist")
     rank, world, local_rank = vdist.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    B, S, P = args.batch, args.streams, max(1, args.passes)
+    if S < 1 or B % S:
+        raise SystemExit("--batch must be a multiple of --streams")
+    n_scenes = min(args.scenes, B)
+    if B % n_scenes:
+        raise SystemExit("--batch must be a multiple of --scenes")
+    Bu = B // S          # stereo frames per launch
+    n_img = 2 * Bu       # images per launch
+
+    # Synthetic input, generated before anything touches the GPU (forked workers): B distinct stereo pairs per rank
+    t_gen = time.perf_counter()
+    host_frames = distinct_stereo_frames(vdist.stream_seeds(rank, n_scenes), B // n_scenes, args.gen_workers)
+    # interleave the scenes so that every launch (and the CPU sample) sees all of them
+    host_frames = np.ascontiguousarray(host_frames.reshape(n_scenes, B // n_scenes, 2, H, W).transpose(1, 0, 2, 3, 4)).reshape(B, 2, H, W)
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # one rank per GPU; `% device_count` only matters when several ranks rehearse on a one-GPU box
@@ -92,40 +223,41 @@ def main():
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("VSL_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; "gloo" for rehearsals
     vdist.init(backend)  # a no-op at world size 1
-    B, S = args.batch, args.streams
-    if S < 1 or B % S:
-        raise SystemExit("--batch must be a multiple of --streams")
-    Bu = B // S          # stereo frames per launch
-    n_img = 2 * Bu       # images per launch
 
-    pairs_img = [synth.stereo_pair(seed) for seed in vdist.stream_seeds(rank, args.distinct)]
+    # the pinned host ring of the streaming mode doubles as the upload source of the resident batch
+    pinned = torch.empty((B, 2, H, W), dtype=torch.uint8).pin_memory()
+    ring = pinned.numpy()
+    ring[...] = host_frames
+    del host_frames
     slot_pairs = np.array([[2 * k, 2 * k + 1] for k in range(Bu)], np.int32)
     units = []  # one (stream, context, frame store) per HIP stream; inputs resident in HBM before the timed region
     for u in range(S):
         stream = torch.cuda.Stream()
         ctx = vsl.Context(local_rank, stream=stream.cuda_stream)
         frames = vsl.Frames(ctx, n_img, W, H, NUM_FEATURES, max_pairs=Bu)
-        batch = np.stack([pairs_img[(u * Bu + k // 2) % args.distinct][k % 2] for k in range(n_img)])
-        frames.upload(0, batch)
+        frames.upload(0, ring[u * Bu:(u + 1) * Bu].reshape(n_img, H, W))
         units.append((stream, ctx, frames))
 
-    def step():
+    def one_pass():
         for _, _, frames in units:
             frames.detect_describe(0, n_img, NUM_FEATURES, True)
         for _, _, frames in units:
             frames.resolve_ties()
             frames.match(slot_pairs, 70, 1.2)
 
+    def step():
+        for _ in range(P):
+            one_pass()
+
     def barrier():
         vdist.barrier()
         torch.cuda.synchronize()
 
     # Set-up, before the W warm-up steps: wake the device.  After idle the chip's clock ramps for ~50 ms and the
-    # kernels of that window run up to 15 % slower (profiles/r01_bench_kernel_trace_summary.txt); running the step for
-    # `--clock-ramp-ms` (default 80) here makes the measurement independent of how small W is.  Reported in `config`.
+    # kernels of that window run up to 15 % slower (profiles/r01_bench_kernel_trace_summary.txt).  Reported in `config`.
     t_ramp = time.perf_counter()
     while 1e3 * (time.perf_counter() - t_ramp) < args.clock_ramp_ms:
-        step()
+        one_pass()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -145,7 +277,7 @@ def main():
 
     out = None
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = world * B * P * args.steps / elapsed
         out = {
             "metric": "stereo frames/sec, detect+describe (1500 feats) + stereo match, 752x480",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -154,13 +286,25 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic 752x480 stereo, 1500 feats/frame (BASELINE configs[1]); "
                                    "independent streams per GPU (configs[3])",
-                       "stereo_frames_per_step_per_gpu": B, "hip_streams": S, "stereo_frames_per_launch": Bu,
+                       "value_is": "kernel pipeline: inputs resident in HBM when the timed region starts, outputs stay "
+                                   "in HBM (the upload-inclusive rate is value_incl_upload)",
+                       "inputs_resident_in_hbm": True, "h2d_in_timed_region": False,
+                       "distinct_stereo_pairs_per_gpu": B, "distinct_scenes_per_gpu": n_scenes,
+                       "stereo_frames_per_pass_per_gpu": B, "passes_per_step": P,
+                       "stereo_frames_per_step_per_gpu": B * P, "timed_region_s": round(elapsed, 3),
+                       "hip_streams": S, "stereo_frames_per_launch": Bu,
                        "clock_ramp_ms_before_warmup": args.clock_ramp_ms,
                        "num_features": NUM_FEATURES,
                        "match": "threshold 70, ratio 1.2, cross-check",
                        "mean_keypoints_per_image": round(float(nk.mean()), 1),
-                       "mean_matches_per_pair": round(float(nm.mean()), 1)},
+                       "mean_matches_per_pair": round(float(nm.mean()), 1),
+                       "synthetic_input_generation_s": round(t_gen, 2)},
         }
+
+        # ---- streaming mode (N = 1): the same hot path fed from the pinned host ring, upload inside the timed region
+        if args.stream_seconds > 0 and world == 1 and S >= 2:
+            out.update(streaming_measurement(vsl, units, ring, Bu, slot_pairs, args.stream_seconds, local_rank,
+                                             [c[1] for c in counts]))
 
         # ---- per-stage device time, HIP events around every stage on the stream each kernel is launched on.
         # Pass 1: one stream at a time (kernel durations in isolation -> roofline); pass 2: all streams active
@@ -188,7 +332,7 @@ def main():
                 c.synchronize()
 
         stages = staged(step_one_stream_at_a_time)
-        stages_overlapped = staged(step) if S > 1 else None
+        stages_overlapped = staged(one_pass) if S > 1 else None
         dom = max(stages, key=stages.get)
         # counts for the byte model: read back once (unit 0 = one launch)
         kp_total, match_total = int(counts[0][0].sum()), int(counts[0][1].sum())
@@ -196,19 +340,34 @@ def main():
         out["config"]["mean_candidates_per_image"] = round(cand_total / n_img, 1)
         ab = stage_algorithmic_bytes(dom, n_img, Bu, kp_total, cand_total, match_total)
         achieved = ab / (stages[dom] * 1e-3) / 1e9
-        # HBM traffic of that stage per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-        # uncorrected -- see profiles/r01_pmc_traffic.json); only valid for the batch size it was taken at
+        # HBM traffic of that kernel per launch from the newest committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes -- see the file's note); only
+        # valid for the launch size it was taken at
         traffic = None
         try:
-            pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            newest = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
+            pm = json.loads(newest.read_text())
             if pm.get("batch_stereo_frames") == Bu and dom in pm["kernels"]:
-                traffic = pm["kernels"][dom]["bytes_per_launch_uncorrected"]
+                traffic = pm["kernels"][dom].get("bytes_per_launch", pm["kernels"][dom].get("bytes_per_launch_uncorrected"))
         except Exception:
             traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "algorithmic_bytes_per_launch": int(ab),
+                           "algorithmic_bytes_are": "SURVEY 8(d) detect+angle+describe: image in + 56 B per keypoint out, "
+                                                    "x %d images per launch" % n_img,
                            "avg_launch_ms": round(stages[dom], 5)}
+        # the whole keypoint stage (K1 + selection + describe) and the whole pass against the same HBM peak
+        dd_ms = sum(stages.get(k, 0.0) for k in ("response", "select", "describe"))
+        if dd_ms > 0:
+            out["roofline_detect_describe_stage"] = {
+                "bound": "hbm", "achieved": round(ab / (dd_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ab / (dd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "sum_of_kernel_ms": round(dd_ms, 5)}
+        pass_bytes = B * (2 * W * H + 2 * 56 * NUM_FEATURES + 2 * 32 * NUM_FEATURES + 8 * NUM_FEATURES)  # 8(d): 997,920 B per stereo frame
+        out["roofline_whole_pass"] = {"bound": "hbm", "achieved": round(pass_bytes * P * args.steps / elapsed / 1e9, 2),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(pass_bytes * P * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                                      "algorithmic_bytes_per_stereo_frame": pass_bytes // B}
         # the matcher is the one matrix-core kernel: ALGORITHMIC int8 MACs (n_a x n_b distances of 256 bits, both
         # directions; the padding of the 256-query x 64-row tiles is not counted) against the dense int8 MFMA peak
         if "match" in stages:
@@ -225,13 +384,14 @@ def main():
         if stages_overlapped:
             out["stage_ms_per_launch_streams_overlapped"] = {k: round(v, 5) for k, v in stages_overlapped.items()}
 
-        # ---- CPU baseline: the oracle (port of the reference path), 1 core, bounded sample
+        # ---- CPU baseline: the oracle (port of the reference path), 1 core, bounded sample of the same frames,
+        # starting from host images like the reference does -- compared like for like with the upload-inclusive rate
         if args.cpu_frames > 0 and world == 1:   # the CPU baseline is an N = 1 measurement
             orc = entry.load_oracle()
             t0 = time.perf_counter()
             n_done = 0
             while n_done < args.cpu_frames:
-                left, right = pairs_img[n_done % args.distinct]
+                left, right = ring[n_done % B]
                 _, _, d1 = orc.detect_describe(left, NUM_FEATURES, True)
                 _, _, d2 = orc.detect_describe(right, NUM_FEATURES, True)
                 orc.match_descriptors(d1, d2, 70, 1.2)
@@ -239,10 +399,12 @@ def main():
             cpu_s = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": round(n_done / cpu_s, 3), "unit": "frames/s", "cores": 1,
                                    "kind": "port",
-                                   "sample": "%d synthetic stereo frames (same generator), oracle "
-                                             "detect+describe x2 + match, single thread (the reference's "
-                                             "keypoints.h path has no parallel loops)" % n_done}
-            out["speedup_vs_cpu_1core"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                                   "sample": "the first %d of the %d distinct synthetic stereo frames of the run, oracle "
+                                             "detect+describe x2 + match from host images, single thread (the "
+                                             "reference's keypoints.h path has no parallel loops), %.1f s"
+                                             % (n_done, B, cpu_s)}
+            if "value_incl_upload" in out:
+                out["speedup_vs_cpu_1core_incl_upload"] = round(out["value_incl_upload"] / out["cpu_baseline"]["value"], 1)
         # ---- second metric of BASELINE.json: ms per LM iteration of local bundle adjustment
         # (configs[2]: 7 keyframes = 14 cameras, ~20k landmarks), GPU next to the oracle on all host cores
         if args.ba and world == 1:

@@ -66,6 +66,15 @@ int vsl_ctx_destroy(vsl_ctx* ctx);
 int vsl_ctx_synchronize(vsl_ctx* ctx);
 /* The hipStream_t this context enqueues on. */
 void* vsl_ctx_stream(vsl_ctx* ctx);
+/* Device-side ordering between contexts of one device (no host round trip): vsl_event_record marks the work
+ * enqueued on `ctx` so far; work enqueued on a context after vsl_ctx_wait_event starts only after the marked
+ * work has completed (an event never recorded is not waited for).  The upload / compute hand-off of a streaming
+ * pipeline -- the reference's load -> detect order, src/slam.cpp:1122-1128. */
+typedef struct vsl_event vsl_event;
+int vsl_event_create(vsl_ctx* ctx, vsl_event** out);
+int vsl_event_destroy(vsl_event* e);
+int vsl_event_record(vsl_event* e, vsl_ctx* ctx);
+int vsl_ctx_wait_event(vsl_ctx* ctx, vsl_event* e);
 
 /* Per-stage device timing with hipEvents on the context's stream.  When
  * enabled, every kernel stage is bracketed by events; vsl_ctx_stage_ms returns
@@ -169,7 +178,11 @@ int vsl_frames_destroy(vsl_frames* f);
  * tensor); `_dev` marks the pointer as a device pointer. */
 void* vsl_frames_images_dev(vsl_frames* f);
 /* Copy n host images (row pitch `pitch`, image stride `img_stride` bytes) into
- * slots [first, first+n). */
+ * slots [first, first+n), enqueued on ctx's stream (any context of the device: a
+ * dedicated upload context overlaps the copy with another context's kernels).  A
+ * dense batch (pitch == w, img_stride == w*h) is ONE transfer; it is asynchronous
+ * when `imgs` is pinned host memory, and `imgs` must stay valid until the stream
+ * has passed the copy. */
 int vsl_frames_upload(vsl_ctx* ctx, vsl_frames* f, int first, int n, const uint8_t* imgs,
                       size_t pitch, size_t img_stride);
 /* detectKeypointsAndDescriptors over slots [first, first+n) (asynchronous). */
@@ -188,6 +201,8 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
+ *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
+ *                                   detected at the next synchronisation and the range is redone by the f64 kernel
  *   "select_bucket_cap" (default 128) fullest response bin the selection kernel's counting sort accepts; 0 = always
  *                                   the bitonic network */
 int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value);

@@ -138,6 +138,82 @@ def test_response_kernel_list_overflow_path(ctx, orc, images, cap):
     assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
 
 
+@pytest.mark.parametrize("cap", [0, 5])
+def test_exact_rounding_list_overflow_falls_back_to_f64_kernel(ctx, orc, vsl, images, synth, cap):
+    # shrink the per-image exact-rounding list of the fast describe kernel so that it overflows: the overflow flag
+    # rides the tie count, the host redoes the range with the generic f64 kernel -- same descriptors, and the
+    # context keeps working afterwards (no sticky error)
+    ctx.set_diagnostic("exact_list_cap", cap)
+    try:
+        for name in ("left", "right"):
+            xy, ang, desc = ctx.detect_describe(images[name], 1500, True)
+            oxy, oang, odesc = orc.detect_describe(images[name], 1500, True)
+            assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc) and np.array_equal(ang, oang)
+        # batched path: overflow in some slots, resolved at resolve_ties, before the match
+        imgs = np.stack([images["left"], images["right"], images["flat"], images["checker"]])
+        fr = vsl.Frames(ctx, 4, 752, 480, 1500, max_pairs=2)
+        fr.upload(0, imgs)
+        fr.detect_describe(0, 4, 1500, True)
+        fr.resolve_ties()
+        fr.match([[0, 1], [2, 3]], 70, 1.2)
+        d = []
+        for i in range(4):
+            _, _, desc = fr.keypoints(i)
+            assert np.array_equal(desc, orc.detect_describe(imgs[i], 1500, True)[2])
+            d.append(desc)
+        assert np.array_equal(fr.matches(0), orc.match_descriptors(d[0], d[1], 70, 1.2))
+        fr.close()
+    finally:
+        ctx.set_diagnostic("exact_list_cap", 16384)
+    xy, ang, desc = ctx.detect_describe(images["left"], 1500, True)
+    assert np.array_equal(desc, orc.detect_describe(images["left"], 1500, True)[2])
+
+
+def test_async_upload_and_event_handoff(ctx, orc, vsl, synth):
+    # the streaming primitives of bench.py: a second context uploads into the idle one of two frame stores while the
+    # first context computes on the other; vsl_event orders upload -> compute -> next upload on the device
+    import torch
+    pairs = [synth.stereo_pair(s) for s in (31, 32, 33, 34)]
+    host = torch.empty((4, 2, 480, 752), dtype=torch.uint8).pin_memory()
+    ring = host.numpy()
+    for k, (l, r) in enumerate(pairs):
+        ring[k, 0], ring[k, 1] = l, r
+    copy_ctx = vsl.Context(0)
+    stores = [vsl.Frames(ctx, 2, 752, 480, 1500, max_pairs=1) for _ in range(2)]
+    uploaded = [vsl.Event(ctx) for _ in range(2)]
+    computed = [vsl.Event(ctx) for _ in range(2)]
+    copy_ctx.wait_event(computed[0])   # never recorded: must not block
+
+    def up(k):
+        b = k % 2
+        copy_ctx.wait_event(computed[b])
+        stores[b].upload_async(0, ring[k], ctx=copy_ctx)
+        uploaded[b].record(copy_ctx)
+
+    got = []
+    up(0)
+    for k in range(4):
+        if k + 1 < 4:
+            up(k + 1)
+        b = k % 2
+        ctx.wait_event(uploaded[b])
+        stores[b].detect_describe(0, 2, 1500, True)
+        stores[b].resolve_ties()
+        stores[b].match([[0, 1]], 70, 1.2)
+        computed[b].record(ctx)
+        got.append(stores[b].matches(0))
+    copy_ctx.synchronize()
+    for k, (l, r) in enumerate(pairs):
+        d1 = orc.detect_describe(l, 1500, True)[2]
+        d2 = orc.detect_describe(r, 1500, True)[2]
+        assert np.array_equal(got[k], orc.match_descriptors(d1, d2, 70, 1.2)), k
+    for e in uploaded + computed:
+        e.close()
+    for s_ in stores:
+        s_.close()
+    copy_ctx.close()
+
+
 @pytest.mark.parametrize("cap", [0, 2, 100000])
 def test_selection_sort_paths_agree(ctx, orc, images, cap):
     # cap 0: always the bitonic network; 2: counting sort only when no response bin holds more than two keys

@@ -137,6 +137,10 @@ class Context:
     def stream(self):
         return self.L.vsl_ctx_stream(self.h)
 
+    def wait_event(self, ev):
+        """Device-side ordering: later work on this context starts after the work `ev` marked has completed."""
+        self._ck(self.L.vsl_ctx_wait_event(self.h, ev.h))
+
     def set_profiling(self, on):
         self._ck(self.L.vsl_ctx_set_profiling(self.h, int(on)))
 
@@ -472,6 +476,30 @@ class Vocabulary:
             pass
 
 
+class Event:
+    """vsl_event: marks a point in one context's stream for another context to wait on (device side)."""
+
+    def __init__(self, ctx):
+        self.L = ctx.L
+        h = C.c_void_p()
+        ctx._ck(self.L.vsl_event_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def record(self, ctx):
+        ctx._ck(self.L.vsl_event_record(self.h, ctx.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vsl_event_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Frames:
     """vsl_frames: device-resident batched frame store."""
 
@@ -508,6 +536,17 @@ class Frames:
                                                   imgs.ctypes.data_as(u8p), C.c_size_t(w),
                                                   C.c_size_t(w * h)))
         self.ctx.synchronize()
+
+    def upload_async(self, first, imgs, ctx=None):
+        """Enqueue the copy of a dense (n, h, w) uint8 batch -- pinned host memory for a truly asynchronous copy --
+        on `ctx` (default: the store's own context) and return without waiting; the caller keeps `imgs` alive and
+        unchanged until that stream has passed the copy."""
+        c = ctx or self.ctx
+        assert imgs.dtype == np.uint8 and imgs.ndim == 3 and imgs.flags["C_CONTIGUOUS"]
+        n, h, w = imgs.shape
+        assert (h, w) == (self.hgt, self.w)
+        c._ck(c.L.vsl_frames_upload(c.h, self.h, int(first), n, imgs.ctypes.data_as(u8p), C.c_size_t(w),
+                                    C.c_size_t(w * h)))
 
     def detect_describe(self, first, n, num_features=1500, rotate=True):
         self.ctx._ck(self.ctx.L.vsl_frames_detect_describe(self.ctx.h, self.h, int(first), int(n),

@@ -36,7 +36,20 @@ def _allreduce(t, op_name, group=None):
 
 def bundle_adjust_distributed(pkg, ctx, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0, group=None):
     """arr: flattened problem (same object as Context.bundle_adjust takes), identical on every rank.
-    Optimises arr.poses / arr.points in place on every rank; returns a summary namespace."""
+    Optimises arr.poses / arr.points in place on every rank; returns a summary namespace.
+
+    Stream contract: the session kernels run on ctx's stream, the buffer fills / element-wise math / collectives are
+    torch work.  The whole loop therefore runs with ctx's stream as torch's CURRENT stream (an ExternalStream view of
+    it), so that both kinds of work are ordered on one stream and an RCCL collective (which torch orders against the
+    current stream on both sides) can never overtake or be overtaken by a session kernel."""
+    import torch
+    handle = ctx.stream()  # None = the device's default (null) stream
+    stream = torch.cuda.ExternalStream(handle) if handle else torch.cuda.default_stream()
+    with torch.cuda.stream(stream):
+        return _bundle_adjust_distributed(pkg, ctx, arr, use_huber, huber, max_iters, verbosity, group)
+
+
+def _bundle_adjust_distributed(pkg, ctx, arr, use_huber, huber, max_iters, verbosity, group):
     import torch
     import torch.distributed as dist
     from . import dist as vdist

@@ -259,10 +259,68 @@ extern "C" int vsl_frames_upload(vsl_ctx* ctx, vsl_frames* f, int first, int n, 
                                  size_t img_stride) {
   if (!ctx || !f || !imgs || first < 0 || n < 0 || first + n > f->max_images || pitch < (size_t)f->w)
     return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_upload: bad arguments");
+  if (n == 0) return VSL_OK;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t img_bytes = (size_t)f->w * f->h;
+  if (pitch == (size_t)f->w && img_stride == img_bytes) {
+    // dense batch: ONE transfer (a 2-D copy per image costs ~5-10 us of submission each: 1024 images would be
+    // 5-10 ms of host time, more than the kernels that consume them); asynchronous when `imgs` is pinned
+    VSL_HIP(ctx, hipMemcpyAsync(f->images + (size_t)first * img_bytes, imgs, (size_t)n * img_bytes, hipMemcpyHostToDevice,
+                                ctx->stream));
+    return VSL_OK;
+  }
   for (int i = 0; i < n; i++) {
-    VSL_HIP(ctx, hipMemcpy2DAsync(f->images + (size_t)(first + i) * f->w * f->h, f->w, imgs + (size_t)i * img_stride,
+    VSL_HIP(ctx, hipMemcpy2DAsync(f->images + (size_t)(first + i) * img_bytes, f->w, imgs + (size_t)i * img_stride,
                                   pitch, f->w, f->h, hipMemcpyHostToDevice, ctx->stream));
   }
+  return VSL_OK;
+}
+
+// Cross-stream ordering without a host round trip (an upload context feeding a compute context, the compute context
+// handing the buffer back: bench.py's streaming mode; the reference's order is load -> detect, src/slam.cpp:1122-1128).
+struct vsl_event {
+  int device = 0;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;
+};
+
+extern "C" int vsl_event_create(vsl_ctx* ctx, vsl_event** out) {
+  if (!ctx || !out) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_event_create: null argument");
+  *out = nullptr;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  vsl_event* e = new (std::nothrow) vsl_event;
+  if (!e) return vsl_fail(ctx, VSL_ERR_NOMEM, "out of host memory");
+  e->device = ctx->device;
+  hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+  if (rc != hipSuccess) {
+    delete e;
+    return vsl_fail(ctx, VSL_ERR_HIP, "hipEventCreate -> %s", hipGetErrorString(rc));
+  }
+  *out = e;
+  return VSL_OK;
+}
+
+extern "C" int vsl_event_destroy(vsl_event* e) {
+  if (!e) return VSL_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipEventDestroy(e->ev);
+  delete e;
+  return VSL_OK;
+}
+
+extern "C" int vsl_event_record(vsl_event* e, vsl_ctx* ctx) {
+  if (!e || !ctx || e->device != ctx->device) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_event_record: bad arguments");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  VSL_HIP(ctx, hipEventRecord(e->ev, ctx->stream));
+  e->recorded = true;
+  return VSL_OK;
+}
+
+extern "C" int vsl_ctx_wait_event(vsl_ctx* ctx, vsl_event* e) {
+  if (!e || !ctx || e->device != ctx->device) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ctx_wait_event: bad arguments");
+  if (!e->recorded) return VSL_OK;  // nothing marked yet: nothing to wait for
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  VSL_HIP(ctx, hipStreamWaitEvent(ctx->stream, e->ev, 0));
   return VSL_OK;
 }
 
@@ -322,10 +380,7 @@ extern "C" int vsl_frames_download_keypoints(vsl_ctx* ctx, vsl_frames* f, int sl
   int32_t* hmom = hxy + 2 * F;
   uint64_t* hdesc = (uint64_t*)(hmom + 2 * F);
   const size_t base = (size_t)slot * F;
-  const bool ties = f->ties_pending && !f->exact_overflow_check;
-  if (f->ties_pending && !ties) {
-    if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;
-  }
+  const bool ties = f->ties_pending;
   hdr[0] = 0;
   if (ties) VSL_HIP(ctx, hipMemcpyAsync(&hdr[0], f->tie_count, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipMemcpyAsync(&hdr[1], f->kp_count + slot, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -16,6 +16,7 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   if (k == "match_use_valu") ctx->match_use_valu = value != 0;
   else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
+  else if (k == "exact_list_cap") ctx->exact_list_cap = value;
   else if (k == "select_bucket_cap") ctx->select_bucket_cap = value < 0 ? 0 : value;
   else return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ctx_set_diagnostic: unknown knob '%s'", name);
   return VSL_OK;

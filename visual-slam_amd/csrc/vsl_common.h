@@ -22,6 +22,7 @@
 #define VSL_META_NCAND_LAST 4
 #define VSL_META_NEXACT_LAST 5
 #define VSL_EXACT_CAP 16384 // capacity of that per-image list
+#define VSL_TIE_OVERFLOW_FLAG 0x40000000u  // set in tie_count by exact_bits_kernel when an image's list overflowed
 
 struct vsl_ctx {
   int device = 0;
@@ -51,6 +52,7 @@ struct vsl_ctx {
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
+  int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = 256;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
 
@@ -115,7 +117,8 @@ struct vsl_frames {
   bool ties_pending = false, ties_from_angles = false;
   bool detect_meta_dirty = true;    // MAX / NCAND not in their reset state (first use, or a failed launch)
   bool describe_meta_dirty = true;  // same for NEXACT
-  bool exact_overflow_check = false;  // diagnostic (tests): verify no exact-rounding list overflowed
+  int last_desc_first = 0, last_desc_n = 0, last_desc_rotate = 1;  // range of the last describe launch (overflow fallback)
+  int exact_fallbacks = 0;            // how often that fallback ran (diagnostic)
   bool store_response = false;  // K1 writes the fp32 response image only for the parity hook
   std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
 };

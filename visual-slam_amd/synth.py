@@ -32,8 +32,9 @@ def _blur3(img):
     return t[:-2] * k[0] + t[1:-1] * k[1] + t[2:] * k[2]
 
 
-def stereo_pair(seed, w=W, h=H, n_rects=2600, noise=2.0):
-    """Returns (left, right) uint8 images."""
+def stereo_scene(seed, w=W, h=H, n_rects=2600, margin=0):
+    """The noise-free float images (left, right) of one random-rectangle world.  `margin` > 0 keeps a band of
+    that many pixels along the image border free of rectangles (smooth background only)."""
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:h, 0:w]
     bg = 110 + 30 * np.sin(xx / 97.0 + rng.uniform(0, 6)) * np.cos(yy / 71.0 + rng.uniform(0, 6))
@@ -42,26 +43,52 @@ def stereo_pair(seed, w=W, h=H, n_rects=2600, noise=2.0):
     # painter's order: far first
     depth = np.sort(rng.uniform(2.0, 12.0, n_rects))[::-1]
     fb = DS_INTR[0, 0] * 0.55 * T_0_1[4]  # effective focal (ds model, centre) x baseline
+    lo_x, hi_x, lo_y, hi_y = margin, w - margin, margin, h - margin
     for z in depth:
         rw, rh = rng.integers(7, 30, 2)
         x0 = int(rng.integers(-10, w))
         y0 = int(rng.integers(-10, h))
         g = float(rng.choice([rng.uniform(20, 90), rng.uniform(150, 235)]))
         d = int(round(fb / z))
-        ya, yb = max(0, y0), min(h, y0 + rh)
+        ya, yb = max(lo_y, y0), min(hi_y, y0 + rh)
         if ya >= yb:
             continue
-        xa, xb = max(0, x0), min(w, x0 + rw)
+        xa, xb = max(lo_x, x0), min(hi_x, x0 + rw)
         if xa < xb:
             left[ya:yb, xa:xb] = g
-        xa, xb = max(0, x0 - d), min(w, x0 + rw - d)
+        xa, xb = max(lo_x, x0 - d), min(hi_x, x0 + rw - d)
         if xa < xb:
             right[ya:yb, xa:xb] = g
-    out = []
-    for k, im in enumerate((left, right)):
-        im = _blur3(im) + rng.normal(0, noise, im.shape)
-        out.append(np.clip(np.rint(im), 0, 255).astype(np.uint8))
-    return out[0], out[1]
+    return _blur3(left), _blur3(right), rng
+
+
+def _to_u8(im, rng, noise):
+    return np.clip(np.rint(im + rng.normal(0, noise, im.shape)), 0, 255).astype(np.uint8)
+
+
+def stereo_pair(seed, w=W, h=H, n_rects=2600, noise=2.0, margin=0):
+    """Returns (left, right) uint8 images.
+
+    margin = 0: corners everywhere, so goodFeaturesToTrack's 1500 strongest include ~12 % inside the 19-px border
+    that detectKeypoints then drops (keypoints.h:145-149): ~1320 keypoints per image.  margin = 24 (bench.py):
+    the border band holds no rectangle edges, the 1500 strongest corners are interior and ~1500 survive -- the
+    "1500 feats/frame" of BASELINE configs[1]."""
+    left, right, rng = stereo_scene(seed, w, h, n_rects, margin)
+    return _to_u8(left, rng, noise), _to_u8(right, rng, noise)
+
+
+def stereo_pair_variants(seed, n_variants, w=W, h=H, n_rects=2600, noise=2.0, margin=0):
+    """n_variants distinct stereo pairs of ONE scene: independent sensor-noise realisations (every pixel differs,
+    so do the corner responses, their order and the selected set).  Variant 0 == stereo_pair(seed, ...).
+    Returns uint8 array (n_variants, 2, h, w)."""
+    left, right, rng = stereo_scene(seed, w, h, n_rects, margin)
+    out = np.empty((n_variants, 2, h, w), np.uint8)
+    for v in range(n_variants):
+        if v:
+            rng = np.random.default_rng([seed, v])
+        out[v, 0] = _to_u8(left, rng, noise)
+        out[v, 1] = _to_u8(right, rng, noise)
+    return out
 
 
 def random_descriptors(rng, n):
