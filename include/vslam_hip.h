@@ -201,6 +201,7 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
+ *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
  *                                   detected at the next synchronisation and the range is redone by the f64 kernel
  *   "select_bucket_cap" (default 128) fullest response bin the selection kernel's counting sort accepts; 0 = always

@@ -55,6 +55,37 @@ def test_linearize_S_g_cost(ctx, orc, synth, huber):
     assert np.allclose(g, eg, rtol=0, atol=1e-9 * np.abs(eg).max())
 
 
+@pytest.mark.parametrize("n_kf,n_fixed_cams,n", [(7, 2, 72), (10, 2, 108), (11, 1, 126), (2, 3, 6), (4, 3, 30)])
+@pytest.mark.parametrize("entries", [0, 1])
+def test_schur_small_kernel_variants_at_local_ba_sizes(ctx, orc, synth, n_kf, n_fixed_cams, n, entries):
+    # reduced systems of 6C = 72 / 108 / 126 (the largest the small-system kernel takes: 21 free cameras, 903 of the
+    # 1024 threads own a 3 x 3 sub-block) and two tiny ones (most threads own nothing); 3 x 3 sub-block ownership
+    # (default) and single-entry ownership (diagnostic) against the oracle, both with landmark counts that leave the
+    # last 16-landmark stage of a workgroup ragged
+    d = synth.ba_problem(200 + n, n_kf=n_kf, n_lms=1237)
+    d["cam_fixed"][:] = 0
+    d["cam_fixed"][:n_fixed_cams] = 1
+    arr = _arr(orc, d)
+    assert 6 * arr.n_free == n
+    ctx.set_diagnostic("ba_schur_entries", entries)
+    try:
+        S, g, c = ctx.ba_linearize(arr)
+        a_gpu = _arr(orc, d)
+        s_gpu = ctx.bundle_adjust(a_gpu, max_iters=5)
+    finally:
+        ctx.set_diagnostic("ba_schur_entries", 0)
+    eS, eg, ec = orc.ba_linearize(arr)
+    assert c == pytest.approx(ec, rel=1e-12)
+    assert np.allclose(S, eS, rtol=0, atol=1e-9 * np.abs(eS).max())
+    assert np.allclose(g, eg, rtol=0, atol=1e-9 * np.abs(eg).max())
+    assert np.allclose(S, S.T, rtol=0, atol=1e-9 * np.abs(eS).max())
+    a_cpu = _arr(orc, d)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=5)
+    assert s_gpu.iterations == s_cpu.iterations
+    assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
+    assert np.allclose(a_gpu.poses, a_cpu.poses, rtol=0, atol=1e-6)
+
+
 def test_linearize_partition_is_additive(ctx, orc, synth):
     d = synth.ba_problem(22, n_kf=4, n_lms=900)
     arr = _arr(orc, d)

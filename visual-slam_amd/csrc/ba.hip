@@ -408,6 +408,15 @@ inline __device__ bool inv3(const double* P, double* Pi) {
 #define SCH_EPT 16    // owned entries per thread: n <= 128
 #define SCH_CMAX 22   // free cameras
 
+// BLOCK3 = false: every thread owns up to SCH_EPT single entries of the full n x n matrix (the first formulation;
+//   6 LDS doubles per 3 multiply-adds, LDS-bandwidth-bound; kept as the cross-check of the other one).
+// BLOCK3 = true (default): a thread owns ONE 3 x 3 sub-block (bi, bj), bi >= bj, of the LOWER block triangle --
+//   n = 6 * cameras is a multiple of 3, nb = n / 3 <= 42, nb (nb + 1) / 2 <= 903 <= SCH_THREADS sub-blocks, so threads
+//   beyond that count own nothing (own = false guards every use) -- 18 LDS doubles per 27 fused multiply-adds; the
+//   finish kernel mirrors the strictly-upper sub-blocks (S is symmetric).  A first attempt at this variant in round 1
+//   faulted on the GPU and was reverted uncommitted (its source is lost); this one was written against the extents
+//   listed in DESIGN.md "Schur kernel extents" and is tested at n = 72, 108 and 126.
+template <bool BLOCK3>
 __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
     BaDims D, const int* __restrict__ lm_start, const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
     const double* __restrict__ r, const double* __restrict__ F, const double* __restrict__ E,
@@ -425,17 +434,31 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
   const int n = D.n, tid = threadIdx.x;
   const int wl0 = l_first + blockIdx.x * lm_per_wg;
   const int wl1 = min(l_first + l_count, wl0 + lm_per_wg);
-  double acc[SCH_EPT];
-  int ei[SCH_EPT];  // packed (c1, x, c2, y) of the owned entries
+  double acc[BLOCK3 ? 9 : SCH_EPT];
+  int ei[BLOCK3 ? 1 : SCH_EPT];  // packed (c1, x, c2, y) of the owned entries
+  // BLOCK3: sub-block (bi, bj) of thread tid = bi (bi + 1) / 2 + bj, bj <= bi < nb
+  int bi = 0, bj = 0;
+  bool own = false;
+  if (BLOCK3) {
+    const int nb = n / 3;
+    bi = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+    while (bi * (bi + 1) / 2 > tid) bi--;
+    while ((bi + 1) * (bi + 2) / 2 <= tid) bi++;
+    bj = tid - bi * (bi + 1) / 2;
+    own = bi < nb;  // bj <= bi by construction
 #pragma unroll
-  for (int e = 0; e < SCH_EPT; e++) {
-    acc[e] = 0;
-    const int idx = tid + e * SCH_THREADS;
-    if (idx < n * n) {
-      const int i = idx / n, j = idx - i * n;
-      ei[e] = (i / 6) | ((i % 6) << 8) | ((j / 6) << 16) | ((j % 6) << 24);
-    } else {
-      ei[e] = -1;
+    for (int e = 0; e < 9; e++) acc[e] = 0;
+  } else {
+#pragma unroll
+    for (int e = 0; e < SCH_EPT; e++) {
+      acc[e] = 0;
+      const int idx = tid + e * SCH_THREADS;
+      if (idx < n * n) {
+        const int i = idx / n, j = idx - i * n;
+        ei[e] = (i / 6) | ((i % 6) << 8) | ((j / 6) << 16) | ((j % 6) << 24);
+      } else {
+        ei[e] = -1;
+      }
     }
   }
   double racc = 0;  // thread tid < n owns rhs[tid]
@@ -536,15 +559,37 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
     // phase C: owned entries
     for (int li = 0; li < nl; li++) {
       if (!ok_s[li]) continue;
+      if (BLOCK3) {
+        if (own) {
+          // cameras bi / 2 and bj / 2 (< nfree <= SCH_CMAX); rows 3 (bi % 2) .. +2 of Y = 9 contiguous doubles
+          const int q1 = slot[li][bi >> 1], q2 = slot[li][bj >> 1];
+          if (q1 >= 0 && q2 >= 0) {
+            const double* y1 = &Y[li][q1][9 * (bi & 1)];
+            const double* w2 = &W[li][q2][9 * (bj & 1)];
+            double yv[9], wv[9];
 #pragma unroll
-      for (int e = 0; e < SCH_EPT; e++) {
-        const int pk = ei[e];
-        if (pk < 0) continue;
-        const int q1 = slot[li][pk & 0xFF], q2 = slot[li][(pk >> 16) & 0xFF];
-        if (q1 < 0 || q2 < 0) continue;
-        const double* y1 = &Y[li][q1][3 * ((pk >> 8) & 0xFF)];
-        const double* w2 = &W[li][q2][3 * ((pk >> 24) & 0xFF)];
-        acc[e] -= y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2];
+            for (int t = 0; t < 9; t++) {
+              yv[t] = y1[t];
+              wv[t] = w2[t];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int b = 0; b < 3; b++)
+                acc[3 * a + b] = fma(-yv[3 * a + 2], wv[3 * b + 2], fma(-yv[3 * a + 1], wv[3 * b + 1], fma(-yv[3 * a], wv[3 * b], acc[3 * a + b])));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < SCH_EPT; e++) {
+          const int pk = ei[e];
+          if (pk < 0) continue;
+          const int q1 = slot[li][pk & 0xFF], q2 = slot[li][(pk >> 16) & 0xFF];
+          if (q1 < 0 || q2 < 0) continue;
+          const double* y1 = &Y[li][q1][3 * ((pk >> 8) & 0xFF)];
+          const double* w2 = &W[li][q2][3 * ((pk >> 24) & 0xFF)];
+          acc[e] -= y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2];
+        }
       }
       if (tid < n) {
         const int q1 = slot[li][tid / 6];
@@ -556,10 +601,19 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
     }
     __syncthreads();
   }
+  if (BLOCK3) {
+    if (own) {  // rows 3 bi .. 3 bi + 2 < n, columns 3 bj .. 3 bj + 2 < n
 #pragma unroll
-  for (int e = 0; e < SCH_EPT; e++) {
-    const int idx = tid + e * SCH_THREADS;
-    if (idx < n * n) S_part[(size_t)blockIdx.x * n * n + idx] = acc[e];
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) S_part[(size_t)blockIdx.x * n * n + (size_t)(3 * bi + a) * n + (3 * bj + b)] = acc[3 * a + b];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < SCH_EPT; e++) {
+      const int idx = tid + e * SCH_THREADS;
+      if (idx < n * n) S_part[(size_t)blockIdx.x * n * n + idx] = acc[e];
+    }
   }
   if (tid < n) rhs_part[(size_t)blockIdx.x * n + tid] = racc;
 }
@@ -570,7 +624,8 @@ __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
 __global__ __launch_bounds__(256) void ba_schur_finish_kernel(int n, int G, const double* __restrict__ S_part,
                                                               const double* __restrict__ rhs_part, const double* __restrict__ H,
                                                               const double* __restrict__ g_c, const double* __restrict__ diag_c,
-                                                              double inv_radius, double* __restrict__ S, double* __restrict__ rhs) {
+                                                              double inv_radius, double* __restrict__ S, double* __restrict__ rhs,
+                                                              int lower_blocks) {
   __shared__ double sh[16][17];
   const int e = threadIdx.x & 15, c = threadIdx.x >> 4;
   const int total = n * n + n;  // the n*n entries of S, then the n entries of rhs
@@ -579,7 +634,12 @@ __global__ __launch_bounds__(256) void ba_schur_finish_kernel(int n, int G, cons
   double v = 0;
   if (idx < total) {
     const bool is_rhs = idx >= n * n;
-    const double* src = is_rhs ? rhs_part + (idx - n * n) : S_part + idx;
+    int sidx = idx;
+    if (!is_rhs && lower_blocks) {  // the partials hold the lower triangle of 3 x 3 sub-blocks: mirror the rest
+      const int i = idx / n, j = idx - i * n;
+      if (i / 3 < j / 3) sidx = j * n + i;
+    }
+    const double* src = is_rhs ? rhs_part + (idx - n * n) : S_part + sidx;
     const size_t stride = is_rhs ? (size_t)n : (size_t)n * n;
     for (int g = c * per; g < min(G, (c + 1) * per); g++) v += src[(size_t)g * stride];
   }
@@ -715,51 +775,128 @@ __global__ void ba_add_cam_blocks_kernel(int nfree, const double* __restrict__ H
   if (t < n) rhs[t] += g_c[t];
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // `lane` wave-uniform (a constant after unrolling)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // dense Cholesky solve in LDS, one workgroup; n <= 128.  dc = -(S^-1 rhs); flag = 0 on failure.
+//
+// Blocked right-looking factorisation, 8-column panels, THREE workgroup barriers per panel (the first version ran one
+// pivot -> sqrt -> divide -> barrier round and a serial per-row trailing update per COLUMN: 124 us for 72 x 72):
+//   panel:    a thread owns a row of the panel (8 values in registers).  Each wavefront factors the 8 x 8 diagonal
+//             block redundantly in its lanes 0..7 (row per lane, column broadcasts by v_readlane: no LDS, no barrier),
+//             then every row is solved against that factor with readlane broadcasts of its entries;
+//   trailing: 4 x 4 register tiles of the lower triangle, 8-deep products from the panel rows in LDS.
+// Rows are padded to an odd stride (column walks spread over the banks).  The substitutions run in one wavefront, two
+// rows per lane, multiplying by the stored reciprocal pivots.
+#define CH_NB 8
 __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double* __restrict__ S, const double* __restrict__ rhs,
                                                             double* __restrict__ dc, int* __restrict__ ok_flag) {
-  // Right-looking Cholesky in LDS, rows padded to an odd stride (column walks then spread over the banks).  Per
-  // column: every thread reads the (final) pivot itself, the column is scaled, one barrier, then thread pair
-  // (row, parity) updates its row's even / odd trailing entries, one barrier -- 2 barriers per column and no integer
-  // division (the first version spent 146 us on a 72 x 72 system: 3 barriers per column, t / m and t % m per
-  // updated entry, and 4 barriers per column in the substitutions, which one wavefront now does without any: 124 us.
-  // Batching the update's LDS reads eight entries ahead of the writes measured 156 us.  What remains is the
-  // latency of 72 pivot -> sqrt -> divide -> barrier rounds and 144 dependent substitution steps).
-  __shared__ double A[128 * 129 + 128];  // static: dynamic LDS above 64 KiB is refused by the runtime
+  __shared__ double A[128 * 129 + 256];  // static: dynamic LDS above 64 KiB is refused by the runtime
+  __shared__ int fail_s;
   const int ld = n | 1;
   double* bvec = A + 128 * 129;
-  const int tid = threadIdx.x;
+  double* invd = bvec + 128;
+  const int tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < n * n; i += 256) {
     const int r = i / n, c = i - r * n;
     A[r * ld + c] = S[i];
   }
   for (int i = tid; i < n; i += 256) bvec[i] = rhs[i];
+  if (tid == 0) fail_s = 0;
   __syncthreads();
-  bool good = true;
-  for (int j = 0; j < n; j++) {
-    const double d = A[j * ld + j];  // final since the previous column's last barrier; the same value in every thread
-    if (!(d > 0.0) || !isfinite(d)) {
-      good = false;
-      break;  // workgroup-uniform
+  for (int j0 = 0; j0 < n; j0 += CH_NB) {
+    const int w = min(CH_NB, n - j0);  // a ragged last panel is completed with identity columns
+    const int row = j0 + tid;
+    const bool valid = tid < 128 && row < n;
+    double a[CH_NB], dr[CH_NB];
+    if (tid < 128) {
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) {
+        a[c] = (valid && c < w) ? A[row * ld + j0 + c] : 0.0;
+        dr[c] = (lane < w && c < w) ? A[(j0 + lane) * ld + j0 + c] : (lane == c ? 1.0 : 0.0);
+      }
     }
-    const double djj = sqrt(d);
-    for (int i = j + 1 + tid; i < n; i += 256) A[i * ld + j] /= djj;
-    __syncthreads();  // also orders everybody's read of the pivot before its overwrite below
-    if (tid == 0) A[j * ld + j] = djj;
-    // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i; thread pair (i, parity of k - j - 1)
-    const int i = j + 1 + (tid >> 1);
-    if (i < n) {
-      const double lij = A[i * ld + j];
-      for (int k = j + 1 + (tid & 1); k <= i; k += 2) A[i * ld + k] -= lij * A[k * ld + j];
+    __syncthreads();  // the second wavefront has read the diagonal block before the first one overwrites it with L
+    if (tid < 128) {
+      double inv[CH_NB], x[CH_NB];
+      bool good = true;
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) {
+        const double d = readlane_f64(dr[c], c);
+        if (!(d > 0.0) || !isfinite(d)) good = false;  // wave-uniform
+        const double sq = sqrt(d);
+        inv[c] = 1.0 / sq;
+        dr[c] = (lane == c) ? sq : dr[c] * inv[c];     // lanes > c: l(lane, c)
+#pragma unroll
+        for (int k = c + 1; k < CH_NB; k++) dr[k] -= dr[c] * readlane_f64(dr[c], k);  // meaningful for lanes >= k
+      }
+      // x L_d^T = a: the row of L in this panel (for a diagonal-block row this reproduces that row of L_d)
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) {
+        double t = a[c];
+#pragma unroll
+        for (int k = 0; k < c; k++) t -= x[k] * readlane_f64(dr[k], c);
+        x[c] = t * inv[c];
+      }
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++)
+          if (c < w && tid >= c) A[row * ld + j0 + c] = x[c];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++)
+          if (c < w) invd[j0 + c] = inv[c];
+        if (!good) fail_s = 1;
+      }
+    }
+    __syncthreads();
+    if (fail_s) break;  // workgroup-uniform
+    const int r0 = j0 + CH_NB, rem = n - r0;
+    if (rem > 0) {
+      const int T = (rem + 3) >> 2, ntiles = T * (T + 1) / 2;
+      for (int tile = tid; tile < ntiles; tile += 256) {
+        int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > tile) ti--;
+        while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+        const int tj = tile - ti * (ti + 1) / 2;
+        const int ib = r0 + 4 * ti, kb = r0 + 4 * tj;
+        double Li[4][CH_NB], Lk[4][CH_NB];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int ir = min(ib + q, n - 1), kr = min(kb + q, n - 1);
+#pragma unroll
+          for (int c = 0; c < CH_NB; c++) {
+            Li[q][c] = A[ir * ld + j0 + c];
+            Lk[q][c] = A[kr * ld + j0 + c];
+          }
+        }
+#pragma unroll
+        for (int qa = 0; qa < 4; qa++)
+#pragma unroll
+          for (int qb = 0; qb < 4; qb++) {
+            const int i = ib + qa, k = kb + qb;
+            if (i < n && k <= i) {
+              double acc = A[i * ld + k];
+#pragma unroll
+              for (int c = 0; c < CH_NB; c++) acc = fma(-Li[qa][c], Lk[qb][c], acc);
+              A[i * ld + k] = acc;
+            }
+          }
+      }
     }
     __syncthreads();
   }
+  const bool good = fail_s == 0;
   if (good && tid < 64) {
     // substitutions by one wavefront, two rows per lane, no workgroup barriers: L y = b, then L^T x = y
-    const int lane = tid, r0 = lane, r1 = lane + 64;
+    const int r0 = lane, r1 = lane + 64;
     double b0 = r0 < n ? bvec[r0] : 0.0, b1 = r1 < n ? bvec[r1] : 0.0;
     for (int j = 0; j < n; j++) {
-      const double yj = __shfl(j < 64 ? b0 : b1, j & 63) / A[j * ld + j];
+      const double yj = __shfl(j < 64 ? b0 : b1, j & 63) * invd[j];
       if (lane == (j & 63)) {
         if (j < 64) b0 = yj; else b1 = yj;
       }
@@ -767,7 +904,7 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
       if (r1 > j && r1 < n) b1 -= A[r1 * ld + j] * yj;
     }
     for (int j = n - 1; j >= 0; j--) {
-      const double xj = __shfl(j < 64 ? b0 : b1, j & 63) / A[j * ld + j];
+      const double xj = __shfl(j < 64 ? b0 : b1, j & 63) * invd[j];
       if (lane == (j & 63)) {
         if (j < 64) b0 = xj; else b1 = xj;
       }
@@ -923,6 +1060,33 @@ __global__ __launch_bounds__(256) void ba_update_kernel(BaDims D, const int* __r
   }
 }
 
+__global__ void ba_set_flags_kernel(int* __restrict__ flag) {
+  if (threadIdx.x < 2) flag[threadIdx.x] = 1;
+}
+
+// both step vectors in one launch
+__global__ void ba_all_finite2_kernel(int na, const double* __restrict__ a, int nb, const double* __restrict__ b,
+                                      int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i < na && !isfinite(a[i])) || (i < nb && !isfinite(b[i]))) *flag = 0;
+}
+
+// scalars[slot] and scalars[slot + 1] = sums of partials[0..n) and partials[n..2n): one launch, a workgroup each
+__global__ __launch_bounds__(256) void ba_reduce2_kernel(const double* __restrict__ partials, int n, double* __restrict__ scalars,
+                                                         int slot) {
+  __shared__ double sh[256];
+  const double* p = partials + (size_t)blockIdx.x * n;
+  double v = 0;
+  for (int i = threadIdx.x; i < n; i += 256) v += p[i];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scalars[slot + blockIdx.x] = sh[0];
+}
+
 __global__ void ba_all_finite_kernel(int n, const double* __restrict__ v, int* __restrict__ flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && !isfinite(v[i])) *flag = 0;
@@ -948,14 +1112,18 @@ __global__ void ba_raw_blocks_kernel(BaDims D, const double* __restrict__ poses,
 // ------------------------------------------------------------------------------- host-side state
 struct DevBuf {
   void* p = nullptr;
+  bool owned = false;  // arena-backed buffers (BaState) are not freed one by one
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
   }
   template <class T>
   T* as() {
     return (T*)p;
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes > 0 ? bytes : 8); }
+  hipError_t alloc(size_t bytes) {
+    owned = true;
+    return hipMalloc(&p, bytes > 0 ? bytes : 8);
+  }
 };
 
 struct BaState {
@@ -967,6 +1135,26 @@ struct BaState {
   DevBuf poses, cand_poses, points, cand_points, intr, cam_intr, cam_free, free_cams, obs_cam, obs_lm, obs_uv, lm_start,
       cam_start, cam_obs, r, F, E, scale_c, scale_l, n2l, grad_l, H, g_c, diag_c, diag_l, gabs, S, rhs, S_part, rhs_part,
       Pinv, bl, dc, dl, partials, scalars, flag, cam_part;
+  // second linearisation set (vsl_bundle_adjust linearises the CANDIDATE point speculatively, before the host has
+  // read the step's verdict; an accepted step swaps the sets, a rejected one leaves the current set untouched)
+  DevBuf r2, F2, E2, n2l2, grad_l2, H2, g_c2, diag_c2, diag_l2;
+  bool want_alt_set = false;
+  // ONE device allocation per solve, carved into the buffers above (40 hipMalloc calls cost more than 3 LM iterations);
+  // vsl_bundle_adjust lends the context's cached arena, a session owns its own
+  void* arena = nullptr;
+  size_t arena_cap = 0;
+  bool arena_owned = false;
+  vsl_ctx* arena_lender = nullptr;
+  ~BaState() {
+    if (arena && arena_owned) (void)hipFree(arena);
+    if (arena_lender) arena_lender->ba_arena_busy = false;
+  }
+  void swap_sets() {
+    std::swap(r.p, r2.p); std::swap(F.p, F2.p); std::swap(E.p, E2.p); std::swap(n2l.p, n2l2.p);
+    std::swap(grad_l.p, grad_l2.p); std::swap(H.p, H2.p); std::swap(g_c.p, g_c2.p); std::swap(diag_c.p, diag_c2.p);
+    std::swap(diag_l.p, diag_l2.p);
+    std::swap(poses.p, cand_poses.p); std::swap(points.p, cand_points.p);
+  }
 };
 
 #define BA_HIP(call)                                                                                   \
@@ -1054,50 +1242,72 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   st.lm_per_wg = ((D.L + st.G - 1) / st.G + SCH_LB - 1) / SCH_LB * SCH_LB;
   st.G = (D.L + st.lm_per_wg - 1) / st.lm_per_wg;
 
-  int rc;
-  if ((rc = upload(ctx, st.poses, p->poses, 7 * (size_t)D.C))) return rc;
-  if ((rc = upload(ctx, st.points, p->points, 3 * (size_t)D.L))) return rc;
-  if ((rc = upload(ctx, st.intr, p->intr, 16))) return rc;
-  if ((rc = upload(ctx, st.cam_intr, p->cam_intr, (size_t)D.C))) return rc;
-  if ((rc = upload(ctx, st.cam_free, cam_free.data(), (size_t)D.C))) return rc;
-  if ((rc = upload(ctx, st.free_cams, free_cams.data(), free_cams.size()))) return rc;
-  if ((rc = upload(ctx, st.obs_cam, s_cam.data(), (size_t)D.O))) return rc;
-  if ((rc = upload(ctx, st.obs_lm, s_lm.data(), (size_t)D.O))) return rc;
-  if ((rc = upload(ctx, st.obs_uv, s_uv.data(), 2 * (size_t)D.O))) return rc;
-  if ((rc = upload(ctx, st.lm_start, lm_start.data(), lm_start.size()))) return rc;
-  if ((rc = upload(ctx, st.cam_start, cam_start.data(), cam_start.size()))) return rc;
-  if ((rc = upload(ctx, st.cam_obs, cam_obs.data(), cam_obs.size()))) return rc;
-  const size_t n = (size_t)D.n, L = (size_t)D.L, O = (size_t)D.O;
-  BA_HIP(st.cand_poses.alloc(8 * 7 * (size_t)D.C));
-  BA_HIP(st.cand_points.alloc(8 * 3 * L));
-  BA_HIP(st.r.alloc(8 * 2 * O));
-  BA_HIP(st.F.alloc(8 * 12 * O));
-  BA_HIP(st.E.alloc(8 * 6 * O));
-  BA_HIP(st.scale_c.alloc(8 * n));
-  BA_HIP(st.scale_l.alloc(8 * 3 * L));
-  BA_HIP(st.n2l.alloc(8 * 3 * L));
-  BA_HIP(st.grad_l.alloc(8 * 3 * L));
+  const size_t n = (size_t)D.n, L = (size_t)D.L, O = (size_t)D.O, C = (size_t)D.C;
   // enough workgroups per camera that a camera's observations are ~2 slices of 256 per workgroup (1 when cameras are many)
   st.cb_seg = D.nfree > 0 ? std::max(1, std::min(32, (int)(D.O / std::max(1, D.nfree) / 512))) : 1;
-  BA_HIP(st.cam_part.alloc(8 * 27 * (size_t)std::max(1, D.nfree) * st.cb_seg));
-  BA_HIP(st.H.alloc(8 * 36 * (size_t)D.nfree));
-  BA_HIP(st.g_c.alloc(8 * n));
-  BA_HIP(st.diag_c.alloc(8 * n));
-  BA_HIP(st.diag_l.alloc(8 * 3 * L));
-  BA_HIP(st.gabs.alloc(8 * (n + 3 * L)));
-  BA_HIP(st.S.alloc(8 * n * n));
-  BA_HIP(st.rhs.alloc(8 * n));
+  struct Want { DevBuf* b; size_t bytes; };
+  std::vector<Want> want = {
+      {&st.poses, 8 * 7 * C}, {&st.points, 8 * 3 * L}, {&st.intr, 8 * 16}, {&st.cam_intr, 4 * C}, {&st.cam_free, 4 * C},
+      {&st.free_cams, 4 * free_cams.size()}, {&st.obs_cam, 4 * O}, {&st.obs_lm, 4 * O}, {&st.obs_uv, 16 * O},
+      {&st.lm_start, 4 * (L + 1)}, {&st.cam_start, 4 * (C + 1)}, {&st.cam_obs, 4 * O},
+      {&st.cand_poses, 8 * 7 * C}, {&st.cand_points, 8 * 3 * L}, {&st.r, 16 * O}, {&st.F, 96 * O}, {&st.E, 48 * O},
+      {&st.scale_c, 8 * n}, {&st.scale_l, 24 * L}, {&st.n2l, 24 * L}, {&st.grad_l, 24 * L},
+      {&st.cam_part, 8 * 27 * (size_t)std::max(1, D.nfree) * st.cb_seg}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
+      {&st.diag_c, 8 * n}, {&st.diag_l, 24 * L}, {&st.gabs, 8 * (n + 3 * L)}, {&st.S, 8 * n * n}, {&st.rhs, 8 * n},
+      {&st.Pinv, 72 * L}, {&st.bl, 24 * L}, {&st.dc, 8 * n}, {&st.dl, 24 * L},
+      {&st.partials, 8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)}, {&st.scalars, 8 * 16}, {&st.flag, sizeof(int) * 4}};
   if (st.small) {
-    BA_HIP(st.S_part.alloc(8 * n * n * st.G));
-    BA_HIP(st.rhs_part.alloc(8 * n * st.G));
+    want.push_back({&st.S_part, 8 * n * n * st.G});
+    want.push_back({&st.rhs_part, 8 * n * st.G});
   }
-  BA_HIP(st.Pinv.alloc(8 * 9 * L));
-  BA_HIP(st.bl.alloc(8 * 3 * L));
-  BA_HIP(st.dc.alloc(8 * n));
-  BA_HIP(st.dl.alloc(8 * 3 * L));
-  BA_HIP(st.partials.alloc(8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)));
-  BA_HIP(st.scalars.alloc(8 * 16));
-  BA_HIP(st.flag.alloc(sizeof(int) * 4));
+  if (st.want_alt_set) {
+    const Want alt[] = {{&st.r2, 16 * O}, {&st.F2, 96 * O}, {&st.E2, 48 * O}, {&st.n2l2, 24 * L}, {&st.grad_l2, 24 * L},
+                        {&st.H2, 8 * 36 * (size_t)D.nfree}, {&st.g_c2, 8 * n}, {&st.diag_c2, 8 * n}, {&st.diag_l2, 24 * L}};
+    want.insert(want.end(), std::begin(alt), std::end(alt));
+  }
+  size_t total = 0;
+  for (auto& wnt : want) total += (std::max<size_t>(wnt.bytes, 8) + 255) & ~(size_t)255;
+  if (ctx->ba_arena_busy || !st.want_alt_set) {   // sessions (and nested use) own their arena
+    BA_HIP(hipMalloc(&st.arena, total));
+    st.arena_cap = total;
+    st.arena_owned = true;
+  } else {
+    if (ctx->ba_arena_cap < total) {
+      BA_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
+      ctx->ba_arena = nullptr;
+      ctx->ba_arena_cap = 0;
+      const size_t cap = total + total / 4;
+      BA_HIP(hipMalloc(&ctx->ba_arena, cap));
+      ctx->ba_arena_cap = cap;
+    }
+    st.arena = ctx->ba_arena;
+    st.arena_cap = ctx->ba_arena_cap;
+    ctx->ba_arena_busy = true;
+    st.arena_lender = ctx;
+  }
+  {
+    size_t off = 0;
+    for (auto& wnt : want) {
+      wnt.b->p = (char*)st.arena + off;
+      off += (std::max<size_t>(wnt.bytes, 8) + 255) & ~(size_t)255;
+    }
+  }
+  auto up = [&](DevBuf& bf, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(bf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+  };
+  BA_HIP(up(st.poses, p->poses, 8 * 7 * C));
+  BA_HIP(up(st.points, p->points, 8 * 3 * L));
+  BA_HIP(up(st.intr, p->intr, 8 * 16));
+  BA_HIP(up(st.cam_intr, p->cam_intr, 4 * C));
+  BA_HIP(up(st.cam_free, cam_free.data(), 4 * C));
+  BA_HIP(up(st.free_cams, free_cams.data(), 4 * free_cams.size()));
+  BA_HIP(up(st.obs_cam, s_cam.data(), 4 * O));
+  BA_HIP(up(st.obs_lm, s_lm.data(), 4 * O));
+  BA_HIP(up(st.obs_uv, s_uv.data(), 16 * O));
+  BA_HIP(up(st.lm_start, lm_start.data(), 4 * (L + 1)));
+  BA_HIP(up(st.cam_start, cam_start.data(), 4 * (C + 1)));
+  BA_HIP(up(st.cam_obs, cam_obs.data(), 4 * O));
   BA_HIP(hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors that die here
   return VSL_OK;
 }
@@ -1108,7 +1318,7 @@ double now_ms() {
 
 // linearize at (poses, points): r, F, E (scaled when `scaled`), cost -> scalars[0]; per-landmark and
 // per-camera column statistics.
-int ba_linearize(vsl_ctx* ctx, BaState& st, bool scaled) {
+int ba_linearize(vsl_ctx* ctx, BaState& st, bool scaled, int cost_slot = 0) {
   const BaDims& D = st.D;
   {
     VslStage s(ctx, VSL_STAGE_BA_LIN);
@@ -1118,7 +1328,7 @@ int ba_linearize(vsl_ctx* ctx, BaState& st, bool scaled) {
                        scaled ? st.scale_c.as<double>() : nullptr, scaled ? st.scale_l.as<double>() : nullptr,
                        st.r.as<double>(), st.F.as<double>(), st.E.as<double>(), st.partials.as<double>(), 1);
     hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs,
-                       st.scalars.as<double>(), 0, 0);
+                       st.scalars.as<double>(), cost_slot, 0);
     VSL_CHECK_LAUNCH(ctx);
   }
   return VSL_OK;
@@ -1154,14 +1364,22 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
   if (st.small) {
     const int lpw = ((lc + st.G - 1) / st.G + SCH_LB - 1) / SCH_LB * SCH_LB;
     const int G = lpw > 0 ? (lc + lpw - 1) / lpw : 0;
-    if (G > 0)
-      hipLaunchKernelGGL(ba_schur_small_kernel, dim3(G), dim3(SCH_THREADS), 0, ctx->stream, D, st.lm_start.as<int>(),
-                         st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
-                         st.E.as<double>(), dgl, inv_radius, l0, lc, lpw, st.S_part.as<double>(),
-                         st.rhs_part.as<double>(), Pinv, bl);
+    const bool block3 = !ctx->ba_schur_entries;
+    if (G > 0) {
+      if (block3)
+        hipLaunchKernelGGL(ba_schur_small_kernel<true>, dim3(G), dim3(SCH_THREADS), 0, ctx->stream, D, st.lm_start.as<int>(),
+                           st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
+                           st.E.as<double>(), dgl, inv_radius, l0, lc, lpw, st.S_part.as<double>(),
+                           st.rhs_part.as<double>(), Pinv, bl);
+      else
+        hipLaunchKernelGGL(ba_schur_small_kernel<false>, dim3(G), dim3(SCH_THREADS), 0, ctx->stream, D, st.lm_start.as<int>(),
+                           st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
+                           st.E.as<double>(), dgl, inv_radius, l0, lc, lpw, st.S_part.as<double>(),
+                           st.rhs_part.as<double>(), Pinv, bl);
+    }
     hipLaunchKernelGGL(ba_schur_finish_kernel, dim3((n * n + n + 15) / 16), dim3(256), 0, ctx->stream, n, G,
                        st.S_part.as<double>(), st.rhs_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), dgc,
-                       inv_radius, st.S.as<double>(), st.rhs.as<double>());
+                       inv_radius, st.S.as<double>(), st.rhs.as<double>(), block3 ? 1 : 0);
   } else {
     VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * (size_t)n * n, ctx->stream));
     VSL_HIP(ctx, hipMemsetAsync(st.rhs.p, 0, sizeof(double) * n, ctx->stream));
@@ -1172,6 +1390,24 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
                          (lower_only && n > 128) ? 1 : 0);  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
     hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
                        st.H.as<double>(), st.g_c.as<double>(), dgc, inv_radius, st.S.as<double>(), st.rhs.as<double>());
+  }
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// dc = -(S^-1 rhs), enqueued only: flag[0] = 1 (the finite check clears it), flag[1] = Cholesky succeeded.
+int ba_solve_enqueue(vsl_ctx* ctx, BaState& st) {
+  const int n = st.D.n;
+  VslStage s(ctx, VSL_STAGE_BA_SOLVE);
+  hipLaunchKernelGGL(ba_set_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, st.flag.as<int>());
+  if (n == 0) return VSL_OK;
+  if (n <= 128) {
+    hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, ctx->stream, n, st.S.as<double>(), st.rhs.as<double>(),
+                       st.dc.as<double>(), st.flag.as<int>() + 1);
+  } else {
+    int rc = vsl_chol_solve_dev(ctx, st.S.as<double>(), st.rhs.as<double>(), n, st.flag.as<int>() + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
   }
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
@@ -1303,6 +1539,7 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   const double t_start = now_ms();
   BaState st;
+  st.want_alt_set = true;
   if ((rc = ba_setup(ctx, prob, opt, st))) return rc;
   const BaDims& D = st.D;
   const int nc = D.n, nl = 3 * D.L;
@@ -1326,16 +1563,16 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   VSL_CHECK_LAUNCH(ctx);
   if ((rc = ba_columns(ctx, st))) return rc;
 
-  auto diag_and_gmax = [&]() -> int {
+  auto diag_and_gmax = [&](int slot) -> int {
     hipLaunchKernelGGL(ba_diag_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, D.L, st.H.as<double>(),
                        st.n2l.as<double>(), st.g_c.as<double>(), st.grad_l.as<double>(), st.scale_c.as<double>(),
                        st.scale_l.as<double>(), st.diag_c.as<double>(), st.diag_l.as<double>(), st.gabs.as<double>());
     hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), nc + nl,
-                       st.scalars.as<double>(), 1, 1);
+                       st.scalars.as<double>(), slot, 1);
     VSL_CHECK_LAUNCH(ctx);
     return VSL_OK;
   };
-  if ((rc = diag_and_gmax())) return rc;
+  if ((rc = diag_and_gmax(1))) return rc;
   if ((rc = read_scalars(ctx, st, sc, 2))) return rc;
   double cost = sc[0], gmax = sc[1];
   sum.initial_cost = cost;
@@ -1345,24 +1582,34 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   sum.termination = 0;
   if (opt->verbosity >= 2)
     fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, cost);
+  // One host round trip per LM iteration: the whole iteration is enqueued without waiting -- Schur, Cholesky,
+  // back-substitution, model / step norms, candidate parameters AND the linearisation at the candidate (into the
+  // second set of blocks: its cost is the candidate's cost, and if the step is accepted it is the next iteration's
+  // linearisation already) -- then ONE copy brings back [Cholesky ok, finite] + 7 scalars and the host applies the
+  // [upstream] Ceres step policy.  A rejected or invalid step swaps the sets back; its speculative work (~60 us of
+  // device time) is the price.  (The first version synchronised three times per iteration: after the Cholesky, after
+  // the candidate cost, after the re-linearisation.)
+  int* hflag = nullptr;
+  {
+    void* hp = nullptr;
+    if ((rc = vsl_ctx_hpinned(ctx, 256, &hp))) return rc;
+    hflag = (int*)hp;
+  }
+  double* hsc = (double*)(hflag + 8);
   while (true) {
     if (iteration >= opt->max_num_iterations) { sum.termination = 0; break; }
     if (gmax <= 1e-10) { sum.termination = 2; break; }
     if (radius <= 1e-32) { sum.termination = 4; break; }
     iteration++;
     if ((rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true))) return rc;
-    bool ok = true;
-    if ((rc = ba_solve(ctx, st, ok))) return rc;
-    double model_change = 0, step_norm = 0, x_norm = 0;
-    if (ok) {
+    if ((rc = ba_solve_enqueue(ctx, st))) return rc;  // flag[1] = Cholesky ok
+    {
       VslStage s(ctx, VSL_STAGE_BA_SOLVE);
-      int one = 1;
-      VSL_HIP(ctx, hipMemcpyAsync(st.flag.p, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       hipLaunchKernelGGL(ba_backsub_kernel, dim3((D.L + 255) / 256), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.F.as<double>(), st.E.as<double>(),
                          st.Pinv.as<double>(), st.bl.as<double>(), st.dc.as<double>(), st.dl.as<double>());
-      if (nc > 0) hipLaunchKernelGGL(ba_all_finite_kernel, dim3((nc + 255) / 256), dim3(256), 0, ctx->stream, nc, st.dc.as<double>(), st.flag.as<int>());
-      hipLaunchKernelGGL(ba_all_finite_kernel, dim3((nl + 255) / 256), dim3(256), 0, ctx->stream, nl, st.dl.as<double>(), st.flag.as<int>());
+      hipLaunchKernelGGL(ba_all_finite2_kernel, dim3((std::max(nc, nl) + 255) / 256), dim3(256), 0, ctx->stream, nc,
+                         st.dc.as<double>(), nl, st.dl.as<double>(), st.flag.as<int>());
       hipLaunchKernelGGL(ba_model_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.obs_cam.as<int>(),
                          st.obs_lm.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(),
                          st.dc.as<double>(), st.dl.as<double>(), st.partials.as<double>());
@@ -1372,59 +1619,44 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
                          st.poses.as<double>(), st.points.as<double>(), st.dc.as<double>(), st.dl.as<double>(),
                          st.scale_c.as<double>(), st.scale_l.as<double>(), st.cand_poses.as<double>(),
                          st.cand_points.as<double>(), st.partials.as<double>(), st.nb_upd);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_upd,
-                         st.scalars.as<double>(), 3, 0);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>() + st.nb_upd, st.nb_upd,
-                         st.scalars.as<double>(), 4, 0);
+      hipLaunchKernelGGL(ba_reduce2_kernel, dim3(2), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_upd,
+                         st.scalars.as<double>(), 3);
       VSL_CHECK_LAUNCH(ctx);
     }
-    if (ok) {
-      VslStage s(ctx, VSL_STAGE_BA_LIN);
-      hipLaunchKernelGGL(ba_cost_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.cand_poses.as<double>(),
-                         st.cand_points.as<double>(), st.intr.as<double>(), st.cam_intr.as<int>(), st.obs_cam.as<int>(),
-                         st.obs_lm.as<int>(), st.obs_uv.as<double>(), 0, D.O, st.partials.as<double>());
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs,
-                         st.scalars.as<double>(), 5, 0);
-      VSL_CHECK_LAUNCH(ctx);
-    }
-    double cand_cost = 0;
-    if (ok) {
-      int flag = 1;
-      VSL_HIP(ctx, hipMemcpyAsync(&flag, st.flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      if ((rc = read_scalars(ctx, st, sc, 6))) return rc;
-      model_change = sc[2];
-      step_norm = sqrt(sc[3]);
-      x_norm = sqrt(sc[4]);
-      cand_cost = sc[5];
-      ok = flag != 0 && model_change > 0.0;
-    }
+    // speculative: the candidate becomes the current point, its linearisation goes to the other set;
+    // scalars[5] = cost there, scalars[6] = max |gradient| there (slots 0/1 keep the current point's values)
+    st.swap_sets();
+    if ((rc = ba_linearize(ctx, st, true, 5))) return rc;
+    if ((rc = ba_columns(ctx, st))) return rc;
+    if ((rc = diag_and_gmax(6))) return rc;
+    VSL_HIP(ctx, hipMemcpyAsync(hflag, st.flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipMemcpyAsync(hsc, st.scalars.p, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double model_change = hsc[2], step_norm = sqrt(hsc[3]), x_norm = sqrt(hsc[4]), cand_cost = hsc[5];
+    const bool ok = hflag[0] != 0 && hflag[1] != 0 && model_change > 0.0;
     if (!ok) {
+      st.swap_sets();
       if (++invalid >= 5) { sum.termination = 4; break; }
       radius *= 0.5;
       if (opt->verbosity >= 2) fprintf(stderr, "%4d  invalid step, radius %.3e\n", iteration, radius);
       continue;  // the LM diagonal is reused (the Jacobian is unchanged)
     }
     invalid = 0;
-    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 3; break; }
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { st.swap_sets(); sum.termination = 3; break; }
     const double cost_change = cost - cand_cost;
-    if (fabs(cost_change) <= 1e-6 * cost) { sum.termination = 1; break; }
+    if (fabs(cost_change) <= 1e-6 * cost) { st.swap_sets(); sum.termination = 1; break; }
     const double rel = cost_change / model_change;
     if (opt->verbosity >= 2)
       fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", iteration, cand_cost, cost_change, gmax, step_norm, rel, radius);
     if (rel > 1e-3) {
-      std::swap(st.poses.p, st.cand_poses.p);
-      std::swap(st.points.p, st.cand_points.p);
-      if ((rc = ba_linearize(ctx, st, true))) return rc;
-      if ((rc = ba_columns(ctx, st))) return rc;
-      if ((rc = diag_and_gmax())) return rc;
-      if ((rc = read_scalars(ctx, st, sc, 2))) return rc;
-      cost = sc[0];
-      gmax = sc[1];
+      cost = cand_cost;   // the sets stay swapped: the speculative linearisation is the current one
+      gmax = hsc[6];
       sum.successful_steps++;
       radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
       radius = std::min(1e16, radius);
       decrease_factor = 2.0;
     } else {
+      st.swap_sets();
       radius = radius / decrease_factor;
       decrease_factor *= 2.0;
     }

@@ -17,6 +17,7 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
   else if (k == "exact_list_cap") ctx->exact_list_cap = value;
+  else if (k == "ba_schur_entries") ctx->ba_schur_entries = value != 0;
   else if (k == "select_bucket_cap") ctx->select_bucket_cap = value < 0 ? 0 : value;
   else return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ctx_set_diagnostic: unknown knob '%s'", name);
   return VSL_OK;

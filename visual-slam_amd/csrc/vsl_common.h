@@ -47,11 +47,16 @@ struct vsl_ctx {
   size_t dscratch_cap = 0;
   void* hpinned = nullptr;
   size_t hpinned_cap = 0;
+  // device arena lent to vsl_bundle_adjust calls on this context (one allocation reused across solves)
+  void* ba_arena = nullptr;
+  size_t ba_arena_cap = 0;
+  bool ba_arena_busy = false;
   bool select_attr_set = false;
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
+  bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = 256;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
