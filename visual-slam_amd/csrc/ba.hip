@@ -377,16 +377,26 @@ __global__ void ba_diag_kernel(int nfree, int L, const double* __restrict__ H, c
                                const double* __restrict__ g_c, const double* __restrict__ grad_l,
                                const double* __restrict__ scale_c, const double* __restrict__ scale_l,
                                double* __restrict__ diag_c, double* __restrict__ diag_l, double* __restrict__ gabs) {
+  // gabs[blockIdx.x] = the workgroup's maximum (one 45k-entry max by a single workgroup afterwards cost ~40 us)
+  __shared__ double sh[256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nc = 6 * nfree, nl = 3 * L;
+  double m = 0;
   if (i < nc) {
     diag_c[i] = fmin(fmax(H[36 * (size_t)(i / 6) + 7 * (i % 6)], 1e-6), 1e32);
-    gabs[i] = fabs(g_c[i] / scale_c[i]);
+    m = fabs(g_c[i] / scale_c[i]);
   }
   if (i < nl) {
     diag_l[i] = fmin(fmax(n2l[i], 1e-6), 1e32);
-    gabs[nc + i] = fabs(grad_l[i] / scale_l[i]);
+    m = fmax(m, fabs(grad_l[i] / scale_l[i]));
   }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gabs[blockIdx.x] = sh[0];
 }
 
 inline __device__ bool inv3(const double* P, double* Pi) {
@@ -1255,7 +1265,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       {&st.cam_part, 8 * 27 * (size_t)std::max(1, D.nfree) * st.cb_seg}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
       {&st.diag_c, 8 * n}, {&st.diag_l, 24 * L}, {&st.gabs, 8 * (n + 3 * L)}, {&st.S, 8 * n * n}, {&st.rhs, 8 * n},
       {&st.Pinv, 72 * L}, {&st.bl, 24 * L}, {&st.dc, 8 * n}, {&st.dl, 24 * L},
-      {&st.partials, 8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)}, {&st.scalars, 8 * 16}, {&st.flag, sizeof(int) * 4}};
+      {&st.partials, 8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)}, {&st.scalars, 8 * 16 + sizeof(int) * 4}};
   if (st.small) {
     want.push_back({&st.S_part, 8 * n * n * st.G});
     want.push_back({&st.rhs_part, 8 * n * st.G});
@@ -1293,6 +1303,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       off += (std::max<size_t>(wnt.bytes, 8) + 255) & ~(size_t)255;
     }
   }
+  st.flag.p = (char*)st.scalars.p + 8 * 16;  // behind the 16 scalars: one copy brings both back
   auto up = [&](DevBuf& bf, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpyAsync(bf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
   };
@@ -1567,7 +1578,7 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
     hipLaunchKernelGGL(ba_diag_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, D.L, st.H.as<double>(),
                        st.n2l.as<double>(), st.g_c.as<double>(), st.grad_l.as<double>(), st.scale_c.as<double>(),
                        st.scale_l.as<double>(), st.diag_c.as<double>(), st.diag_l.as<double>(), st.gabs.as<double>());
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), nc + nl,
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), (nmax + 255) / 256,
                        st.scalars.as<double>(), slot, 1);
     VSL_CHECK_LAUNCH(ctx);
     return VSL_OK;
@@ -1589,13 +1600,13 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   // [upstream] Ceres step policy.  A rejected or invalid step swaps the sets back; its speculative work (~60 us of
   // device time) is the price.  (The first version synchronised three times per iteration: after the Cholesky, after
   // the candidate cost, after the re-linearisation.)
-  int* hflag = nullptr;
+  double* hsc = nullptr;
   {
     void* hp = nullptr;
     if ((rc = vsl_ctx_hpinned(ctx, 256, &hp))) return rc;
-    hflag = (int*)hp;
+    hsc = (double*)hp;
   }
-  double* hsc = (double*)(hflag + 8);
+  const int* hflag = (const int*)(hsc + 16);
   while (true) {
     if (iteration >= opt->max_num_iterations) { sum.termination = 0; break; }
     if (gmax <= 1e-10) { sum.termination = 2; break; }
@@ -1629,8 +1640,7 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
     if ((rc = ba_linearize(ctx, st, true, 5))) return rc;
     if ((rc = ba_columns(ctx, st))) return rc;
     if ((rc = diag_and_gmax(6))) return rc;
-    VSL_HIP(ctx, hipMemcpyAsync(hflag, st.flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    VSL_HIP(ctx, hipMemcpyAsync(hsc, st.scalars.p, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipMemcpyAsync(hsc, st.scalars.p, 16 * sizeof(double) + 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const double model_change = hsc[2], step_norm = sqrt(hsc[3]), x_norm = sqrt(hsc[4]), cand_cost = hsc[5];
     const bool ok = hflag[0] != 0 && hflag[1] != 0 && model_change > 0.0;
