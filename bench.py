@@ -43,7 +43,8 @@ import __graft_entry__ as entry  # noqa: E402
 W, H, NUM_FEATURES = 752, 480, 1500
 SYNTH_MARGIN = 24  # synth.stereo_pair(margin=24): the 1500 strongest corners are interior, ~1500 keypoints survive the border filter
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s achievable)
-I8_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2x the 2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, MFMA table)
+I8_PEAK_TOPS = 5000.0   # dense int8 MFMA = 2x the 2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, MFMA table)
+FP4_PEAK_TOPS = 10000.0  # dense block-scaled FP4 MFMA (same table): the instruction the matcher runs on for <= 2048 features
 
 
 def stage_algorithmic_bytes(stage, n_img, n_pairs, kp_total, cand_total, match_total):
@@ -368,8 +369,9 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(pass_bytes * P * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                                       "algorithmic_bytes_per_stereo_frame": pass_bytes // B}
-        # the matcher is the one matrix-core kernel: ALGORITHMIC int8 MACs (n_a x n_b distances of 256 bits, both
-        # directions; the padding of the 256-query x 64-row tiles is not counted) against the dense int8 MFMA peak
+        # the matcher is the one matrix-core kernel: ALGORITHMIC multiply-adds (n_a x n_b distances of 256 bits, both
+        # directions; the padding of the 256-query x 64-row tiles is not counted) against the dense peak of the
+        # instruction it runs on (block-scaled FP4, v_mfma_scale_f32_32x32x64_f8f6f4, for <= 2048 features per image)
         if "match" in stages:
             nk0 = counts[0][0].astype(np.int64)
             macs = 0
@@ -377,8 +379,9 @@ def main():
                 a, b = int(nk0[2 * k]), int(nk0[2 * k + 1])
                 macs += 2 * a * b * 256
             tops = 2.0 * macs / (stages["match"] * 1e-3) / 1e12
-            out["roofline_matcher"] = {"bound": "mfma", "kernel": "match", "achieved": round(tops, 1), "peak": I8_PEAK_TOPS,
-                                       "unit": "TOP/s", "frac": round(tops / I8_PEAK_TOPS, 4),
+            out["roofline_matcher"] = {"bound": "mfma", "kernel": "match", "instruction": "fp4 block-scaled MFMA (unit scales, exact on bits)",
+                                       "achieved": round(tops, 1), "peak": FP4_PEAK_TOPS, "unit": "TOP/s",
+                                       "frac": round(tops / FP4_PEAK_TOPS, 4), "frac_of_int8_peak": round(tops / I8_PEAK_TOPS, 4),
                                        "avg_launch_ms": round(stages["match"], 5)}
         out["stage_ms_per_launch"] = {k: round(v, 5) for k, v in stages.items()}
         if stages_overlapped:

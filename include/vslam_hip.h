@@ -199,6 +199,8 @@ int vsl_frames_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
 int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
 /* Diagnostic knobs for the parity tests (results never change, only which kernel path produces them):
  *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
+ *   "match_use_i8" (0/1)            int8 matrix-core matcher where the block-scaled FP4 one would run (<= 2048 features)
+ *   "match_no_stagger" (0/1)        matrix-core matcher with every wave of a workgroup in the same phase order
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
  *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks

@@ -46,7 +46,7 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
     d2[9] = np.uint64(0xFFFFFFFFFFFFFFFF)
     exp = orc.match_descriptors(d1, d2, 70, 1.2)
     assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
-    for knob in ("match_use_valu",):   # the popcount kernel
+    for knob in ("match_use_valu", "match_use_i8"):   # the popcount kernel; the int8 matrix-core kernel (default here: FP4)
         ctx.set_diagnostic(knob, 1)
         try:
             got = ctx.match_descriptors(d1, d2, 70, 1.2)
@@ -56,6 +56,23 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
     # thresholds / ratios that move the cutoff (including "everything passes" and ratio < 1)
     for thr, ratio in ((1, 1.2), (70, 1.0), (70, 0.5), (70, 3.0), (130, 1.2), (200, 1.5), (256, 1.2), (300, 2.0)):
         assert np.array_equal(ctx.match_descriptors(d1, d2, thr, ratio), orc.match_descriptors(d1, d2, thr, ratio)), (thr, ratio)
+
+
+@pytest.mark.parametrize("n1,n2", [(2048, 2048), (2047, 2049), (2049, 100), (100, 2049)])
+def test_match_fp4_int8_kernel_boundary(ctx, orc, synth, n1, n2):
+    # <= 2048 descriptors per set: block-scaled FP4 kernel (11 index bits in its f32 keys); above: the int8 kernel
+    d1, d2 = _planted(synth, n1 + 3 * n2, n1, n2, n_dup=90)
+    d2[n2 - 1] = d1[n1 - 1]                      # a best match at the last index of both sets
+    exp = orc.match_descriptors(d1, d2, 70, 1.2)
+    assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
+    ctx.set_diagnostic("match_use_i8", 1)
+    try:
+        for stagger_off in (0, 1):
+            ctx.set_diagnostic("match_no_stagger", stagger_off)
+            assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
+    finally:
+        ctx.set_diagnostic("match_use_i8", 0)
+        ctx.set_diagnostic("match_no_stagger", 0)
 
 
 def test_match_thresholds_and_ratios(ctx, orc, synth):

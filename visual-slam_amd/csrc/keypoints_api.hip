@@ -14,6 +14,8 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   if (!ctx || !name) return VSL_ERR_INVALID;
   const std::string k(name);
   if (k == "match_use_valu") ctx->match_use_valu = value != 0;
+  else if (k == "match_no_stagger") ctx->match_no_stagger = value != 0;
+  else if (k == "match_use_i8") ctx->match_use_i8 = value != 0;
   else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
   else if (k == "exact_list_cap") ctx->exact_list_cap = value;

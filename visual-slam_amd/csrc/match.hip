@@ -138,6 +138,14 @@ __device__ __forceinline__ v4i_t expand16(uint32_t bits16) {
 #ifndef MM_WAVES
 #define MM_WAVES 8  // wavefronts (32 queries each) per workgroup; they share one expanded database tile (per 512 pairs: 4 waves 0.481 ms, 8: 0.450, 16: 0.467 on a slower box where 8 gave 0.470)
 #endif
+// STAGGER: the second half of the workgroup's waves (wave >= MM_WAVES / 2: the SIMD partners of the first half --
+// a workgroup's waves go to SIMDs in cyclic order, so waves w and w + 4 share one) runs every block in the order
+// [key updates of the PREVIOUS super tile, matrix instructions of this one] while the first half runs [matrix
+// instructions, key updates].  Same work, same registers (the accumulators are consumed before they are overwritten),
+// bit-identical results; but the two waves of a SIMD are no longer in lockstep -- while one holds the matrix pipe
+// the other issues its v_lshl_add / v_med3 / v_min chain (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+// The row-key table is a ring of three (the deferred epilogue reads st - 1 while st + 1 is being written).
+template <bool STAGGER>
 __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint64_t* __restrict__ desc,
                                                            const int32_t* __restrict__ kp_count,
                                                            const int32_t* __restrict__ pair_slots,
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
                                                            uint32_t* __restrict__ second_key, int F) {
   // a "super tile" = 64 database descriptors = two MFMA tiles per workgroup barrier
   __shared__ __align__(16) unsigned char tile[2][64 * MM_ROW];
-  __shared__ __align__(16) uint32_t rowkey[2][64];  // (256 << KEY_SHIFT) | m, or MM_PAD_KEY past the end
+  __shared__ __align__(16) uint32_t rowkey[3][64];  // (256 << KEY_SHIFT) | m, or MM_PAD_KEY past the end; ring of 3
   const int pair = blockIdx.z, dir = blockIdx.y;
   const int slot_q = pair_slots[2 * pair + dir];      // queries (rows of the result)
   const int slot_d = pair_slots[2 * pair + 1 - dir];  // database (columns of the reference's loop)
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
       *(v4i_t*)dst = expand16(wd & 0xFFFFu);
       *(v4i_t*)(dst + 16) = expand16(wd >> 16);
       const int m = st * 64 + lr;
-      if (fword == 0) rowkey[buf][lr] = m < n_d ? ((256u << KEY_SHIFT) | (uint32_t)m) : MM_PAD_KEY;
+      if (fword == 0) rowkey[st % 3][lr] = m < n_d ? ((256u << KEY_SHIFT) | (uint32_t)m) : MM_PAD_KEY;
     }
   };
   const int n_st = (n_d + 63) / 64;
@@ -213,12 +221,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
     store_rows(0, 0, w0, w1);
     __syncthreads();
   }
-  for (int st = 0; st < n_st; st++) {
-    const int buf = st & 1;
-    uint32_t n0 = 0, n1 = 0;
-    if (st + 1 < n_st) load_words(st + 1, n0, n1);
-    v16i_t acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v16i_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v16i_t acc0, acc1;
+  auto mfma_phase = [&](int buf) {
+    acc0 = (v16i_t){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    acc1 = (v16i_t){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 8; s++) {
       const v4i_t a0 = *(const v4i_t*)&tile[buf][c * MM_ROW + s * 32 + h * 16];
@@ -226,12 +232,14 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
       acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[s], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, bq[s], acc1, 0, 0, 0);
     }
-    // accumulator register g*4+j of lane (c, h) belongs to database row 8g + 4h + j of its MFMA tile
+  };
+  // accumulator register g*4+j of lane (c, h) belongs to database row 8g + 4h + j of its MFMA tile
+  auto key_phase = [&](int rk_slot) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const uint4 rk = *(const uint4*)&rowkey[buf][32 * half + 8 * g + 4 * h];
+        const uint4 rk = *(const uint4*)&rowkey[rk_slot][32 * half + 8 * g + 4 * h];
         const uint32_t rks[4] = {rk.x, rk.y, rk.z, rk.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -247,9 +255,23 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
         }
       }
     }
+  };
+  const bool late = STAGGER && wave >= MM_WAVES / 2;  // wave-uniform
+  for (int st = 0; st < n_st; st++) {
+    const int buf = st & 1;
+    uint32_t n0 = 0, n1 = 0;
+    if (st + 1 < n_st) load_words(st + 1, n0, n1);
+    if (late) {
+      if (st > 0) key_phase((st - 1) % 3);
+      mfma_phase(buf);
+    } else {
+      mfma_phase(buf);
+      key_phase(st % 3);
+    }
     if (st + 1 < n_st) store_rows(buf ^ 1, st + 1, n0, n1);
     __syncthreads();
   }
+  if (late && n_st > 0) key_phase((n_st - 1) % 3);
   // merge the two trackers (disjoint database rows): second = min(max(b, bB), sk, skB)
   sk = min(umed3(b, bB, sk), skB);
   b = min(b, bB);
@@ -263,6 +285,142 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
     const size_t o = ((size_t)pair * 2 + dir) * F + qc;
     best_key[o] = (b >> KEY_SHIFT) >= 1023u ? KEY_INIT : b + fix;
     second_key[o] = (sk >> KEY_SHIFT) >= 1023u ? KEY_INIT : sk + fix;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-scaled FP4 variant (the default for database sets of <= 2048 descriptors).  Same identity, same tiling, but
+// the bits travel as FP4 (e2m1) elements through v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales:
+//   database bit 0 / 1 -> 0.0 / 1.0 (nibbles 0x0 / 0x2), query bit 0 / 1 -> +1.0 / -1.0 (0x2 / 0xA);
+//   the f32 accumulator |d| - 2<q, d> is an exact small integer.  One instruction covers K = 64 bits in the cycles
+//   the int8 form needs for K = 32 (tools/probes/fp4_mfma_probe.hip: exact on random data, 48 vs 52 ticks per
+//   dependent instruction), so the matrix-pipe time per tile halves, and so do the LDS bytes per expanded descriptor
+//   (128 B) and the registers of the query fragment.
+//   Keys stay lane-local: key = fma(acc, 2048, 256 * 2048 + m) is an exact non-negative f32 (< 2^21) whose bit pattern
+//   orders like the value, so best / second are v_min_u32 / v_med3_u32 on the bits; converted back to
+//   (distance << KEY_SHIFT) | m at the end.  m < 2048 is what limits this variant to 2048 database descriptors.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+#define MX_ROW 144          // LDS bytes per expanded descriptor: 128 + 16 pad
+#define MX_KEY_SCALE 2048.0f
+#define MX_PAD_KEY_F 4.0e6f  // rows past the end of the database: above every real key (max real key < 2^21)
+
+__global__ __launch_bounds__(64 * MM_WAVES) void hamming_mx_kernel(const uint64_t* __restrict__ desc,
+                                                                   const int32_t* __restrict__ kp_count,
+                                                                   const int32_t* __restrict__ pair_slots,
+                                                                   uint32_t* __restrict__ best_key,
+                                                                   uint32_t* __restrict__ second_key, int F) {
+  __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
+  __shared__ __align__(16) float rowkey[2][64];  // 256 * 2048 + m, or MX_PAD_KEY_F past the end
+  __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
+  const int pair = blockIdx.z, dir = blockIdx.y;
+  const int slot_q = pair_slots[2 * pair + dir];
+  const int slot_d = pair_slots[2 * pair + 1 - dir];
+  const int n_q = kp_count[slot_q], n_d = kp_count[slot_d];
+  const int q0 = blockIdx.x * (32 * MM_WAVES);
+  if (q0 >= n_q) return;  // workgroup-uniform
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int qc = q0 + wave * 32 + c;
+  const uint32_t* __restrict__ qd = (const uint32_t*)(desc + ((size_t)slot_q * F + (qc < n_q ? qc : 0)) * 4);
+  const uint32_t* __restrict__ dbase = (const uint32_t*)(desc + (size_t)slot_d * F * 4);
+  if (tid < 256) {
+    uint32_t x = (uint32_t)tid;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    lut[tid] = x << 1;
+  }
+  __syncthreads();
+  auto spread = [&](uint32_t w) -> v4i_t {
+    v4i_t o;
+    o.x = (int)lut[w & 255u];
+    o.y = (int)lut[(w >> 8) & 255u];
+    o.z = (int)lut[(w >> 16) & 255u];
+    o.w = (int)lut[w >> 24];
+    return o;
+  };
+  // query fragment of MFMA s (bits 64 s .. 64 s + 63): lane half h holds word 2 s + h; nibble 0x2 | (bit << 3)
+  v8i_t bq[4];
+  int pq = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const uint32_t w0 = qd[2 * s], w1 = qd[2 * s + 1];
+    pq += __builtin_popcount(w0) + __builtin_popcount(w1);
+    const v4i_t e = spread(h ? w1 : w0);
+    bq[s] = (v8i_t){(int)(((uint32_t)e.x << 2) | 0x22222222u), (int)(((uint32_t)e.y << 2) | 0x22222222u),
+                    (int)(((uint32_t)e.z << 2) | 0x22222222u), (int)(((uint32_t)e.w << 2) | 0x22222222u), 0, 0, 0, 0};
+  }
+  // tile fill: thread t expands word (t & 7) of database row (t >> 3) of the 64-row super tile
+  const bool filler = tid < 512;
+  const int frow = tid >> 3, fword = tid & 7;
+  auto load_word = [&](int st) -> uint32_t {
+    const int r0 = st * 64 + frow;
+    return (filler && r0 < n_d) ? dbase[(size_t)r0 * 8 + fword] : 0u;
+  };
+  auto store_row = [&](int buf, int st, uint32_t wd) {
+    if (!filler) return;
+    *(v4i_t*)&tile[buf][frow * MX_ROW + fword * 16] = spread(wd);
+    const int m = st * 64 + frow;
+    if (fword == 0) rowkey[buf][frow] = m < n_d ? (256.0f * MX_KEY_SCALE + (float)m) : MX_PAD_KEY_F;
+  };
+  const int n_st = (n_d + 63) / 64;
+  uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu, bB = 0xFFFFFFFFu, skB = 0xFFFFFFFFu;
+  store_row(0, 0, load_word(0));
+  __syncthreads();
+  for (int st = 0; st < n_st; st++) {
+    const int buf = st & 1;
+    uint32_t nw = 0;
+    if (st + 1 < n_st) nw = load_word(st + 1);
+    v16f_t acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    v16f_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const v4i_t t0 = *(const v4i_t*)&tile[buf][c * MX_ROW + s * 32 + h * 16];
+      const v4i_t t1 = *(const v4i_t*)&tile[buf][(c + 32) * MX_ROW + s * 32 + h * 16];
+      const v8i_t a0 = {t0.x, t0.y, t0.z, t0.w, 0, 0, 0, 0};
+      const v8i_t a1 = {t1.x, t1.y, t1.z, t1.w, 0, 0, 0, 0};
+      acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bq[s], acc0, 4, 4, 0, 127, 0, 127);
+      acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[s], acc1, 4, 4, 0, 127, 0, 127);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const float4 rk = *(const float4*)&rowkey[buf][32 * half + 8 * g + 4 * h];
+        const float rks[4] = {rk.x, rk.y, rk.z, rk.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float av = half ? acc1[4 * g + j] : acc0[4 * g + j];
+          const uint32_t key = __float_as_uint(__builtin_fmaf(av, MX_KEY_SCALE, rks[j]));
+          if (half) {
+            skB = umed3(bB, key, skB);
+            bB = min(bB, key);
+          } else {
+            sk = umed3(b, key, sk);
+            b = min(b, key);
+          }
+        }
+      }
+    }
+    if (st + 1 < n_st) store_row(buf ^ 1, st + 1, nw);
+    __syncthreads();
+  }
+  sk = min(umed3(b, bB, sk), skB);
+  b = min(b, bB);
+  const uint32_t b2 = (uint32_t)__shfl_xor((int)b, 32), s2 = (uint32_t)__shfl_xor((int)sk, 32);
+  sk = min(umed3(b, b2, sk), s2);
+  b = min(b, b2);
+  if (h == 0 && qc < n_q) {
+    // float key -> (distance << KEY_SHIFT) | m; anything that is not a real row becomes KEY_INIT
+    auto unpack = [&](uint32_t kb) -> uint32_t {
+      if (kb >= __float_as_uint(MX_PAD_KEY_F)) return KEY_INIT;  // padded row or untouched tracker
+      const int ki = (int)__uint_as_float(kb);                   // (acc + 256) * 2048 + m, exact
+      return ((uint32_t)((ki >> 11) + pq - 256) << KEY_SHIFT) | (uint32_t)(ki & 2047);
+    };
+    const size_t o = ((size_t)pair * 2 + dir) * F + qc;
+    best_key[o] = unpack(b);
+    second_key[o] = unpack(sk);
   }
 }
 
@@ -322,7 +480,8 @@ __global__ __launch_bounds__(1024) void match_finalize_kernel(
   if (threadIdx.x == 0) match_count[pair] = base_s;
 }
 
-int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best) {
+int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best, int db_bound) {
+  // db_bound: an upper bound of the descriptors per set in this launch (the FP4 kernel's keys hold 11 index bits)
   if (n_pairs <= 0) return VSL_OK;
   constexpr int WAVES = VSL_MATCH_WAVES;
   {
@@ -335,8 +494,15 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
                          f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
     } else {
       dim3 grid((f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES), 2, n_pairs);
-      hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
-                         f->best_key, f->second_key, f->F);
+      if (db_bound <= 2048 && !ctx->match_use_i8)
+        hipLaunchKernelGGL(hamming_mx_kernel, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
+                           f->best_key, f->second_key, f->F);
+      else if (ctx->match_no_stagger)
+        hipLaunchKernelGGL(hamming_mfma_kernel<false>, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
+                           f->pair_slots, f->best_key, f->second_key, f->F);
+      else
+        hipLaunchKernelGGL(hamming_mfma_kernel<true>, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
+                           f->pair_slots, f->best_key, f->second_key, f->F);
     }
     VSL_CHECK_LAUNCH(ctx);
   }
@@ -372,7 +538,7 @@ extern "C" int vsl_frames_match(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   int rc = vsl_set_pairs(ctx, f, slot_pairs, n_pairs);
   if (rc) return rc;
-  return vsl_launch_match(ctx, f, n_pairs, threshold, dist_2_best);
+  return vsl_launch_match(ctx, f, n_pairs, threshold, dist_2_best, f->F);
 }
 
 extern "C" int vsl_match_descriptors(vsl_ctx* ctx, const uint64_t* d1, int n1, const uint64_t* d2, int n2,
@@ -397,7 +563,7 @@ extern "C" int vsl_match_descriptors(vsl_ctx* ctx, const uint64_t* d1, int n1, c
   VSL_HIP(ctx, hipMemcpyAsync(f->kp_count, counts, sizeof(counts), hipMemcpyHostToDevice, ctx->stream));
   rc = vsl_set_pairs(ctx, f, slots, 1);
   if (rc) return rc;
-  rc = vsl_launch_match(ctx, f, 1, threshold, dist_2_best);
+  rc = vsl_launch_match(ctx, f, 1, threshold, dist_2_best, n1 > n2 ? n1 : n2);
   if (rc) return rc;
   return vsl_frames_download_matches(ctx, f, 0, n1 < n2 ? n1 : n2, pairs, n_out);
 }

@@ -53,6 +53,8 @@ struct vsl_ctx {
   bool ba_arena_busy = false;
   bool select_attr_set = false;
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
+  bool match_use_i8 = false;            // diagnostic: int8 matrix-core matcher even where the FP4 one applies (<= 2048 features)
+  bool match_no_stagger = false;        // diagnostic: all waves of a matcher workgroup in the same phase order (the pre-stagger kernel)
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
@@ -134,7 +136,7 @@ int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_
 int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features);
 int vsl_launch_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, int rotate_features,
                         int from_angles);
-int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best);
+int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, double dist_2_best, int db_bound);
 int vsl_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
 int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_pairs);
 
