@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const int yc = q - 2;
       if (yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1) {  // scalar
         const float colmax = fmax3(v_up, v_mid, v_dn);
-        float m8 = fmax3(from_lane_below(colmax), from_lane_above(colmax), __builtin_bit_cast(float, 1));
+        // the neighbours' column maxima folded into the maximum itself (v_max_f32 with a DPP source: one issue slot
+        // each instead of a DPP move plus its share of a v_max3); bound_ctrl:0 feeds 0.0 into lanes 0 / 63 (halo lanes)
+        float m8;
+        asm("v_max_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(m8) : "v"(colmax), "v"(__builtin_bit_cast(float, 1)));
+        asm("v_max_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(m8) : "v"(colmax), "v"(m8));
         m8 = fmax3(m8, v_up, v_dn);
         const bool ge = v_mid >= m8;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(ge) & cand_lanes;  // the compare's own lane mask
