@@ -203,6 +203,8 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "match_no_stagger" (0/1)        matrix-core matcher with every wave of a workgroup in the same phase order
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
+ *   "chol_no_fused" (0/1)           band Cholesky as one launch per panel step instead of the single-launch kernel
+ *   "ba_force_dense" (0/1)          large bundle adjustment with the dense reduced camera system (no band ordering)
  *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
  *                                   detected at the next synchronisation and the range is redone by the f64 kernel
@@ -354,6 +356,27 @@ int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_full_dev, dou
                             int refresh_diag, double* packC_dev);
 int vsl_ba_session_accept(vsl_ba_session* s);
 int vsl_ba_session_download(vsl_ba_session* s, double* poses, double* points_own);
+/* Layout of the reduced camera system inside packB: *s_elems doubles -- n * n when dense; in band form (cameras
+ * renumbered into a narrow band by reverse Cuthill-McKee on the covisibility graph of the FULL problem, identically
+ * on every rank) n * (bandwidth + 33) + 64 -- followed by rhs / diag H / g_c (n each), cost, 0.  Wherever this header
+ * says "n*n" for packB read *s_elems. */
+int vsl_ba_session_layout(const vsl_ba_session* s, int64_t* s_elems, int* banded, int* bandwidth);
+
+/* The whole Levenberg-Marquardt loop over a session, host code in C++.  Collectives go through ONE caller-supplied
+ * function: in-place all-reduce of `count` doubles at DEVICE pointer buf, op 0 = SUM, 1 = MAX, ordered on hip_stream
+ * (the context's stream: an RCCL caller enqueues ncclAllReduce on it and returns; a host-hopping caller synchronises
+ * it first); returns 0 on success.  world = 1: allreduce may be NULL.  poses_out [7 * n_cams] and points_all_out
+ * [3 * n_lms of the FULL problem] (host, nullable) receive the result on every rank. */
+typedef int (*vsl_allreduce_fn)(void* user, double* buf, int64_t count, int op, void* hip_stream);
+int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduce, void* user, int world, int max_iters,
+                         int verbosity, double* poses_out, double* points_all_out, vsl_ba_summary* summary);
+/* visnav::global_bundle_adjustment over `world` ranks (one process per GPU): landmark ranges balanced by observation
+ * count, rank `rank` owns one, prob->poses / prob->points updated in place on every rank. */
+int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
+                             vsl_allreduce_fn allreduce, void* user, int rank, int world, vsl_ba_summary* summary);
+/* Plain synchronous copy on the context's device (kind 0 host->device, 1 device->host, 2 device->device): for
+ * callers that hold device pointers handed out by this library (all-reduce callbacks). */
+int vsl_ctx_memcpy(vsl_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
 
 /* ------------------------------------------------------------ pose graph optimisation */
 /*

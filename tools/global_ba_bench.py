@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--lms", type=int, default=100000)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--radius", type=float, default=200.0)
+    ap.add_argument("--dense", action="store_true", help="force the dense reduced camera system (diagnostic)")
+    ap.add_argument("--single-call", action="store_true", help="vsl_bundle_adjust instead of the session path (one rank)")
     args = ap.parse_args()
     import torch
     vsl = entry.load_package()
@@ -44,13 +46,25 @@ def main():
     arr.obs_uv = np.ascontiguousarray(arr.obs_uv, np.float64)
     arr.cam_model = d["cam_model"]
     ctx = vsl.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    vdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    s = ba_dist.bundle_adjust_distributed(vsl, ctx, arr, max_iters=args.iters, verbosity=2)
-    torch.cuda.synchronize()
-    vdist.barrier()
-    dt = time.perf_counter() - t0
+    if args.dense:
+        ctx.set_diagnostic("ba_force_dense", 1)
+    import copy
+    run = (lambda a, it, v: ctx.bundle_adjust(a, max_iters=it, verbosity=v)) if args.single_call else \
+        (lambda a, it, v: ba_dist.bundle_adjust_distributed(vsl, ctx, a, max_iters=it, verbosity=v))
+    times = {}
+    for it in (1, 2, args.iters, 2, args.iters):      # first call = warm-up; marginal time per iteration from two lengths
+        a = copy.deepcopy(arr)
+        vdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s = run(a, it, 1 if it == args.iters else 0)
+        torch.cuda.synchronize()
+        vdist.barrier()
+        dt = time.perf_counter() - t0
+        times[it] = min(dt, times.get(it, (1e9,))[0]), s
+    dt, s = times[args.iters]
+    if rank == 0 and args.iters > 2:
+        print("marginal ms per LM iteration: %.2f" % (1e3 * (times[args.iters][0] - times[2][0]) / max(times[args.iters][1].iterations - times[2][1].iterations, 1)))
     if rank == 0:
         n = 6 * int((arr.cam_fixed == 0).sum())
         print("global BA: %d cameras (%d x %d reduced system), %d landmarks, %d observations, %d rank(s)" %

@@ -678,7 +678,9 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
                                                               const double* __restrict__ diag_l, double inv_radius,
                                                               int l_first, int l_count, double* __restrict__ S,
                                                               double* __restrict__ rhs, double* __restrict__ Pinv_out,
-                                                              double* __restrict__ bl_out, int lower_only) {
+                                                              double* __restrict__ bl_out, int lower_only, int ldS) {
+  // S is addressed as S[row * ldS + col]: ldS = n for the dense matrix; band storage (chol.hip "BAND FORM") passes
+  // storage + bws and ldS = bws together with lower_only = 2: only entries with col <= row exist there
   constexpr int KM = 64;
   __shared__ double Ws[4][KM][18];
   __shared__ double Ys[4][KM][18];
@@ -688,7 +690,6 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
   if (l >= l_first + l_count) return;
   const int a = lm_start[l], b = lm_start[l + 1];
   if (a == b) return;
-  const int n = D.n;
   // P and b: lanes stride the observations, xor-shuffle tree reduction (fixed order)
   double P[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};  // P upper: 00 01 02 11 12 22
   for (int i = a + lane; i < b; i += 64) {
@@ -751,10 +752,10 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
         const int c1 = cs[wave][q1], c2 = cam_free[obs_cam[qb + q2]];
         // lower_only: the Cholesky solve reads only the lower triangle -- blocks above the block diagonal
         // are not accumulated (half the atomics); the diagonal blocks stay complete
-        if (c1 < 0 || c2 < 0 || (lower_only && c1 < c2)) continue;
+        if (c1 < 0 || c2 < 0 || (lower_only && c1 < c2) || (lower_only == 2 && c1 == c2 && x < y)) continue;
         const double* y1 = &Ys[wave][q1][3 * x];
         const double* w2 = &Ws[wave][q2][3 * y];
-        unsafeAtomicAdd(&S[(size_t)(6 * c1 + x) * n + 6 * c2 + y], -(y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2]));
+        unsafeAtomicAdd(&S[(size_t)(6 * c1 + x) * ldS + 6 * c2 + y], -(y1[0] * w2[0] + y1[1] * w2[1] + y1[2] * w2[2]));
       }
       if (qb == a) {
         for (int item = lane; item < na * 6; item += 64) {
@@ -773,14 +774,14 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
 // S += blockdiag(H) + diag(D2); rhs += g_c   (large-system path, S pre-zeroed before the atomics)
 __global__ void ba_add_cam_blocks_kernel(int nfree, const double* __restrict__ H, const double* __restrict__ g_c,
                                          const double* __restrict__ diag_c, double inv_radius, double* __restrict__ S,
-                                         double* __restrict__ rhs) {
+                                         double* __restrict__ rhs, int ldS, int lower_elems) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = 6 * nfree;
   if (t < nfree * 36) {
     const int fc = t / 36, x = (t % 36) / 6, y = t % 6;
     double v = H[t];
     if (x == y && diag_c) v += diag_c[6 * fc + x] * inv_radius;
-    S[(size_t)(6 * fc + x) * n + 6 * fc + y] += v;
+    if (!(lower_elems && y > x)) S[(size_t)(6 * fc + x) * ldS + 6 * fc + y] += v;
   }
   if (t < n) rhs[t] += g_c[t];
 }
@@ -1149,6 +1150,14 @@ struct BaState {
   // read the step's verdict; an accepted step swaps the sets, a rejected one leaves the current set untouched)
   DevBuf r2, F2, E2, n2l2, grad_l2, H2, g_c2, diag_c2, diag_l2;
   bool want_alt_set = false;
+  // Layout of the reduced camera system S: dense (ldS = n, offset 0) or, for large systems whose cameras can be
+  // ordered into a narrow band (reverse Cuthill-McKee on the covisibility graph, ba_setup), LAPACK-style lower band
+  // storage -- row i keeps columns [i - bws, i], bws = bw + VSL_CHOL_NB, entry (i, j) at S[i * ldS + j + offS] with
+  // ldS = offS = bws (chol.hip "BAND FORM").  The free-camera numbering IS the band order.
+  bool banded = false;
+  int ldS = 0, offS = 0, bw = 0;
+  size_t s_elems = 0;  // doubles to allocate / clear / exchange for S
+  double* S_eff() { return (double*)S.p + offS; }
   // ONE device allocation per solve, carved into the buffers above (40 hipMalloc calls cost more than 3 LM iterations);
   // vsl_bundle_adjust lends the context's cached arena, a session owns its own
   void* arena = nullptr;
@@ -1196,7 +1205,83 @@ int upload(vsl_ctx* ctx, DevBuf& b, const T* src, size_t n) {
   return VSL_OK;
 }
 
-int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaState& st) {
+// Band order of the free cameras: reverse Cuthill-McKee on the covisibility graph (two free cameras are adjacent iff
+// some landmark is observed by both: exactly the non-zero 6 x 6 blocks of the reduced camera system).  gp = the
+// problem whose observations define the graph (a session passes the FULL problem so that every rank derives the same
+// order).  order[position] = free index in ascending-camera numbering; returns the block half-bandwidth (max
+// |position difference| over the edges).  A 500-keyframe loop comes out as a band of a few dozen cameras with no
+// corner blocks (the breadth-first levels run both ways round the loop).
+int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free0, int nfree, std::vector<int>& order) {
+  const size_t words = ((size_t)nfree + 63) / 64;
+  std::vector<uint64_t> adj((size_t)nfree * words, 0);
+  {
+    std::vector<int> start(gp->n_lms + 1, 0);
+    for (int i = 0; i < gp->n_obs; i++) start[gp->obs_lm[i] + 1]++;
+    for (int l = 0; l < gp->n_lms; l++) start[l + 1] += start[l];
+    std::vector<int> fill(start.begin(), start.end() - 1), cams(gp->n_obs);
+    for (int i = 0; i < gp->n_obs; i++) cams[fill[gp->obs_lm[i]]++] = cam_free0[gp->obs_cam[i]];
+    for (int l = 0; l < gp->n_lms; l++)
+      for (int a = start[l]; a < start[l + 1]; a++) {
+        const int ca = cams[a];
+        if (ca < 0) continue;
+        for (int b = a + 1; b < start[l + 1]; b++) {
+          const int cb = cams[b];
+          if (cb < 0 || cb == ca) continue;
+          adj[(size_t)ca * words + (cb >> 6)] |= 1ull << (cb & 63);
+          adj[(size_t)cb * words + (ca >> 6)] |= 1ull << (ca & 63);
+        }
+      }
+  }
+  std::vector<std::vector<int>> nb(nfree);
+  std::vector<int> deg(nfree, 0);
+  for (int c = 0; c < nfree; c++)
+    for (size_t w = 0; w < words; w++) {
+      uint64_t m = adj[(size_t)c * words + w];
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        nb[c].push_back((int)(w * 64) + b);
+      }
+    }
+  for (int c = 0; c < nfree; c++) deg[c] = (int)nb[c].size();
+  for (int c = 0; c < nfree; c++) std::sort(nb[c].begin(), nb[c].end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
+  std::vector<char> seen(nfree, 0);
+  order.clear();
+  order.reserve(nfree);
+  auto bfs = [&](int root, std::vector<int>& out) {  // Cuthill-McKee from root over the unseen part; returns the last level's first node
+    const size_t first = out.size();
+    out.push_back(root);
+    seen[root] = 1;
+    for (size_t h = first; h < out.size(); h++)
+      for (int v : nb[out[h]])
+        if (!seen[v]) {
+          seen[v] = 1;
+          out.push_back(v);
+        }
+    return out.back();
+  };
+  for (;;) {
+    int root = -1;
+    for (int c = 0; c < nfree; c++)
+      if (!seen[c] && (root < 0 || deg[c] < deg[root])) root = c;
+    if (root < 0) break;
+    // pseudo-peripheral start: two sweeps (the far end of a sweep from a minimum-degree node)
+    std::vector<int> probe;
+    const int far_end = bfs(root, probe);
+    for (int v : probe) seen[v] = 0;
+    bfs(far_end, order);
+  }
+  std::reverse(order.begin(), order.end());
+  std::vector<int> pos(nfree);
+  for (int k = 0; k < nfree; k++) pos[order[k]] = k;
+  int half = 0;
+  for (int c = 0; c < nfree; c++)
+    for (int v : nb[c]) half = std::max(half, std::abs(pos[c] - pos[v]));
+  return half;
+}
+
+int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaState& st, bool allow_band = false,
+             const vsl_ba_problem* graph_prob = nullptr) {
   BaDims& D = st.D;
   D.C = p->n_cams;
   D.L = p->n_lms;
@@ -1213,6 +1298,27 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     }
   D.nfree = (int)free_cams.size();
   D.n = 6 * D.nfree;
+  // layout of the reduced camera system (see BaState): dense unless the cameras order into a narrow band
+  st.banded = false;
+  st.ldS = D.n;
+  st.offS = 0;
+  st.bw = D.n;
+  st.s_elems = (size_t)D.n * D.n;
+  if (allow_band && D.n > 128 && !ctx->ba_force_dense) {
+    std::vector<int> order;
+    const int half = camera_band_order(graph_prob ? graph_prob : p, cam_free, D.nfree, order);
+    const int bw = 6 * half + 5, bws = bw + VSL_CHOL_NB;
+    if ((size_t)(bws + 1) * 2 < (size_t)D.n) {  // worth it: the band holds less than half of the matrix
+      std::vector<int> renum(D.nfree);
+      for (int k = 0; k < D.nfree; k++) renum[k] = free_cams[order[k]];
+      free_cams = renum;
+      for (int k = 0; k < D.nfree; k++) cam_free[free_cams[k]] = k;
+      st.banded = true;
+      st.bw = bw;
+      st.ldS = st.offS = bws;
+      st.s_elems = (size_t)D.n * (bws + 1) + 64;  // + slack: the diagonal kernels read (never use) a few entries past a row
+    }
+  }
   // sort observations by landmark (stable: keeps the caller's order inside a landmark)
   std::vector<int> lm_start(D.L + 1, 0);
   for (int i = 0; i < D.O; i++) lm_start[p->obs_lm[i] + 1]++;
@@ -1263,7 +1369,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       {&st.cand_poses, 8 * 7 * C}, {&st.cand_points, 8 * 3 * L}, {&st.r, 16 * O}, {&st.F, 96 * O}, {&st.E, 48 * O},
       {&st.scale_c, 8 * n}, {&st.scale_l, 24 * L}, {&st.n2l, 24 * L}, {&st.grad_l, 24 * L},
       {&st.cam_part, 8 * 27 * (size_t)std::max(1, D.nfree) * st.cb_seg}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
-      {&st.diag_c, 8 * n}, {&st.diag_l, 24 * L}, {&st.gabs, 8 * (n + 3 * L)}, {&st.S, 8 * n * n}, {&st.rhs, 8 * n},
+      {&st.diag_c, 8 * n}, {&st.diag_l, 24 * L}, {&st.gabs, 8 * (n + 3 * L)}, {&st.S, 8 * st.s_elems}, {&st.rhs, 8 * n},
       {&st.Pinv, 72 * L}, {&st.bl, 24 * L}, {&st.dc, 8 * n}, {&st.dl, 24 * L},
       {&st.partials, 8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)}, {&st.scalars, 8 * 16 + sizeof(int) * 4}};
   if (st.small) {
@@ -1392,15 +1498,17 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
                        st.S_part.as<double>(), st.rhs_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), dgc,
                        inv_radius, st.S.as<double>(), st.rhs.as<double>(), block3 ? 1 : 0);
   } else {
-    VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * (size_t)n * n, ctx->stream));
+    VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * st.s_elems, ctx->stream));
     VSL_HIP(ctx, hipMemsetAsync(st.rhs.p, 0, sizeof(double) * n, ctx->stream));
     if (lc > 0)
       hipLaunchKernelGGL(ba_schur_atomic_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
-                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S.as<double>(), st.rhs.as<double>(), Pinv, bl,
-                         (lower_only && n > 128) ? 1 : 0);  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
+                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S_eff(), st.rhs.as<double>(), Pinv, bl,
+                         st.banded ? 2 : ((lower_only && n > 128) ? 1 : 0),  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
+                         st.ldS);
     hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
-                       st.H.as<double>(), st.g_c.as<double>(), dgc, inv_radius, st.S.as<double>(), st.rhs.as<double>());
+                       st.H.as<double>(), st.g_c.as<double>(), dgc, inv_radius, st.S_eff(), st.rhs.as<double>(), st.ldS,
+                       st.banded ? 1 : 0);
   }
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
@@ -1416,7 +1524,7 @@ int ba_solve_enqueue(vsl_ctx* ctx, BaState& st) {
     hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, ctx->stream, n, st.S.as<double>(), st.rhs.as<double>(),
                        st.dc.as<double>(), st.flag.as<int>() + 1);
   } else {
-    int rc = vsl_chol_solve_dev(ctx, st.S.as<double>(), st.rhs.as<double>(), n, st.flag.as<int>() + 1);
+    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>() + 1);
     if (rc) return rc;
     hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
   }
@@ -1439,7 +1547,7 @@ int ba_solve(vsl_ctx* ctx, BaState& st, bool& ok) {
     VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
     // blocked right-looking Cholesky + substitutions (chol.hip); rhs <- S^-1 rhs
-    int rc = vsl_chol_solve_dev(ctx, st.S.as<double>(), st.rhs.as<double>(), n, st.flag.as<int>());
+    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>());
     if (rc) return rc;
     hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
     VSL_CHECK_LAUNCH(ctx);
@@ -1551,7 +1659,7 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   const double t_start = now_ms();
   BaState st;
   st.want_alt_set = true;
-  if ((rc = ba_setup(ctx, prob, opt, st))) return rc;
+  if ((rc = ba_setup(ctx, prob, opt, st, true))) return rc;
   const BaDims& D = st.D;
   const int nc = D.n, nl = 3 * D.L;
   vsl_ba_summary sum;
@@ -1707,7 +1815,7 @@ struct vsl_ba_session {
   vsl_ctx* ctx = nullptr;
   BaState st;
   vsl_ba_options opt;
-  int lm_first = 0, lm_count = 0;
+  int lm_first = 0, lm_count = 0, n_lms_total = 0;
   DevBuf diagc_keep;  // clamp(diag H_full): reused across rejected steps
 };
 
@@ -1754,24 +1862,21 @@ __global__ void sess_pack_b_kernel(int nfree, const double* __restrict__ rhs, co
   }
 }
 
-// S = S_full + diag(diag_c / radius); diag_c = clamp(diag H_full) when refresh, else kept; gabs_c
-__global__ void sess_damp_kernel(int n, const double* __restrict__ packB, double inv_radius, int refresh,
-                                 double* __restrict__ diag_keep, double* __restrict__ S, double* __restrict__ rhs) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n * n) {
-    double v = packB[idx];
-    const int i = idx / n, j = idx - i * n;
-    if (i == j) {
-      double d = diag_keep[i];
-      if (refresh) {
-        d = fmin(fmax(packB[(size_t)n * n + n + i], 1e-6), 1e32);
-        diag_keep[i] = d;
-      }
-      v += d * inv_radius;
+// S = S_full + diag(diag_c / radius); diag_c = clamp(diag H_full) when refresh, else kept.  S_full (the first
+// `elems` doubles of packB, dense or band layout) has been copied into S already; this adds the damping to the
+// diagonal (entry (i, i) at S_eff[i * ldS + i]) and unpacks rhs.
+__global__ void sess_damp_kernel(int n, size_t elems, const double* __restrict__ packB, double inv_radius, int refresh,
+                                 double* __restrict__ diag_keep, double* __restrict__ S_eff, int ldS, double* __restrict__ rhs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double d = diag_keep[i];
+    if (refresh) {
+      d = fmin(fmax(packB[elems + n + i], 1e-6), 1e32);
+      diag_keep[i] = d;
     }
-    S[idx] = v;
+    S_eff[(size_t)i * ldS + i] += d * inv_radius;
+    rhs[i] = packB[elems + i];
   }
-  if (idx < n) rhs[idx] = packB[(size_t)n * n + idx];
 }
 
 __global__ void sess_pack_c_kernel(const double* __restrict__ scalars, const int* __restrict__ flag, double* __restrict__ out) {
@@ -1847,7 +1952,8 @@ extern "C" int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, c
   s->opt = *opt;
   s->lm_first = lm_first;
   s->lm_count = lm_count;
-  if ((rc = ba_setup(ctx, &sub, opt, s->st))) {
+  s->n_lms_total = prob->n_lms;
+  if ((rc = ba_setup(ctx, &sub, opt, s->st, true, prob))) {  // band order from the FULL problem: identical on every rank
     delete s;
     return rc;
   }
@@ -1873,6 +1979,16 @@ extern "C" int vsl_ba_session_dims(const vsl_ba_session* s, int* n, int* n_lms_o
   if (n_lms_own) *n_lms_own = s->st.D.L;
   if (n_obs_own) *n_obs_own = s->st.D.O;
   if (n_cams) *n_cams = s->st.D.C;
+  return VSL_OK;
+}
+
+// Layout of the reduced camera system inside packB: *s_elems doubles (n * n dense; n * (ld + 1) + 64 in band form,
+// where the cameras were renumbered into band order -- identical on every rank), then rhs / diag H / g_c / cost.
+extern "C" int vsl_ba_session_layout(const vsl_ba_session* s, int64_t* s_elems, int* banded, int* bandwidth) {
+  if (!s) return VSL_ERR_INVALID;
+  if (s_elems) *s_elems = (int64_t)s->st.s_elems;
+  if (banded) *banded = s->st.banded ? 1 : 0;
+  if (bandwidth) *bandwidth = s->st.bw;
   return VSL_OK;
 }
 
@@ -1935,9 +2051,9 @@ extern "C" int vsl_ba_session_reduce_dev(vsl_ba_session* s, double radius, doubl
   int rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true);
   if (rc) return rc;
   if (n > 0) {
-    VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(sess_pack_b_kernel, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, D.nfree, st.rhs.as<double>(),
-                       st.H.as<double>(), st.g_c.as<double>(), st.scalars.as<double>(), packB_dev + (size_t)n * n);
+                       st.H.as<double>(), st.g_c.as<double>(), st.scalars.as<double>(), packB_dev + st.s_elems);
     VSL_CHECK_LAUNCH(ctx);
   }
   return VSL_OK;
@@ -1954,8 +2070,9 @@ extern "C" int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_fu
   const BaDims& D = st.D;
   const int n = D.n, nl = 3 * D.L;
   if (n > 0) {
-    hipLaunchKernelGGL(sess_damp_kernel, dim3((n * n + 255) / 256), dim3(256), 0, ctx->stream, n, packB_full_dev, 1.0 / radius,
-                       refresh_diag, s->diagc_keep.as<double>(), st.S.as<double>(), st.rhs.as<double>());
+    VSL_HIP(ctx, hipMemcpyAsync(st.S.p, packB_full_dev, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(sess_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.s_elems, packB_full_dev, 1.0 / radius,
+                       refresh_diag, s->diagc_keep.as<double>(), st.S_eff(), st.ldS, st.rhs.as<double>());
     VSL_CHECK_LAUNCH(ctx);
   }
   bool ok = true;
@@ -2006,6 +2123,186 @@ extern "C" int vsl_ba_session_download(vsl_ba_session* s, double* poses, double*
   vsl_ctx* ctx = s->ctx;
   if (poses) VSL_HIP(ctx, hipMemcpyAsync(poses, s->st.poses.p, sizeof(double) * 7 * (size_t)s->st.D.C, hipMemcpyDeviceToHost, ctx->stream));
   if (points_own) VSL_HIP(ctx, hipMemcpyAsync(points_own, s->st.points.p, sizeof(double) * 3 * (size_t)s->st.D.L, hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VSL_OK;
+}
+
+// =================================================================================================
+// The Levenberg-Marquardt loop over a session, in C++ (host code of the multi-GPU global bundle adjustment).
+// Collectives go through ONE caller-supplied function -- ncclAllReduce on the context's stream for RCCL
+// (include/visnav_amd/bundle_adjustment.h), a host hop for the gloo tests (visual-slam_amd/ba_dist.py) -- so the loop
+// itself does not depend on a communication library.  Policy = the [upstream] Ceres policy of vsl_bundle_adjust.
+// Per iteration: SUM of packB (the packed partial reduced camera system, band form when the cameras order into a band:
+// ~20 MB instead of 287 MB at 1000 cameras), MAX of one scalar after an accepted step, SUM of the 8 doubles of packC.
+namespace {
+__global__ __launch_bounds__(256) void sess_gmax_c_kernel(int n, const double* __restrict__ g_c, const double* __restrict__ scale_c,
+                                                          const double* __restrict__ cost_in, const double* __restrict__ gl,
+                                                          double* __restrict__ out) {
+  // out[0] = cost (copied), out[1] = max(max_i |g_c[i] / scale_c[i]|, gl[0])
+  __shared__ double sh[256];
+  double m = 0;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(g_c[i] / scale_c[i]));
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = cost_in[0];
+    out[1] = fmax(sh[0], gl[0]);
+  }
+}
+}  // namespace
+
+extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduce, void* user, int world, int max_iters,
+                                    int verbosity, double* poses_out, double* points_all_out, vsl_ba_summary* summary) {
+  if (!s || world < 1 || (world > 1 && !allreduce)) return VSL_ERR_INVALID;
+  vsl_ctx* ctx = s->ctx;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  BaState& st = s->st;
+  const int n = st.D.n;
+  const size_t elems = st.s_elems, nB = elems + 3 * (size_t)n + 2;
+  const double t_start = now_ms();
+  DevBuf bufA, packB, packC, gl, hostpack, gather;
+  if (bufA.alloc(8 * ((size_t)n + 1)) != hipSuccess || packB.alloc(8 * nB) != hipSuccess || packC.alloc(64) != hipSuccess ||
+      gl.alloc(8) != hipSuccess || hostpack.alloc(16) != hipSuccess)
+    return vsl_fail(ctx, VSL_ERR_NOMEM, "vsl_ba_session_solve: device allocation failed");
+  auto AR = [&](double* buf, size_t count, int op) -> int {
+    if (world == 1 || !allreduce) return VSL_OK;
+    const int rc = allreduce(user, buf, (int64_t)count, op, (void*)ctx->stream);
+    return rc ? vsl_fail(ctx, VSL_ERR_HIP, "all-reduce callback failed (%d)", rc) : VSL_OK;
+  };
+  auto D2H = [&](void* dst, const void* src, size_t bytes) -> int {
+    VSL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VSL_OK;
+  };
+  int rc;
+  vsl_ba_summary sum;
+  memset(&sum, 0, sizeof(sum));
+  VSL_HIP(ctx, hipMemsetAsync(gl.p, 0, 8, ctx->stream));
+  // iteration 0: cost, Jacobi scaling from the global column norms
+  if ((rc = vsl_ba_session_linearize(s, 0))) return rc;
+  if ((rc = vsl_ba_session_hdiag_cost_dev(s, bufA.as<double>()))) return rc;
+  if ((rc = AR(bufA.as<double>(), (size_t)n + 1, 0))) return rc;
+  if ((rc = vsl_ba_session_set_scale_dev(s, bufA.as<double>()))) return rc;
+  double h2[2];
+  if ((rc = D2H(h2, bufA.as<double>() + n, 8))) return rc;
+  sum.initial_cost = h2[0];
+  double radius = 1e4, decrease = 2.0, cost = sum.initial_cost, gmax = INFINITY;
+  int it = 0, invalid = 0, refresh = 1;
+  sum.termination = 0;
+  if (verbosity >= 2) fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, cost);
+  while (true) {
+    if ((rc = vsl_ba_session_reduce_dev(s, radius, packB.as<double>(), gl.as<double>()))) return rc;
+    if ((rc = AR(packB.as<double>(), nB, 0))) return rc;
+    if (refresh) {
+      if ((rc = AR(gl.as<double>(), 1, 1))) return rc;
+      hipLaunchKernelGGL(sess_gmax_c_kernel, dim3(1), dim3(256), 0, ctx->stream, n, packB.as<double>() + elems + 2 * (size_t)n,
+                         st.scale_c.as<double>(), packB.as<double>() + elems + 3 * (size_t)n, gl.as<double>(), hostpack.as<double>());
+      VSL_CHECK_LAUNCH(ctx);
+      if ((rc = D2H(h2, hostpack.p, 16))) return rc;
+      cost = h2[0];
+      gmax = h2[1];
+    }
+    if (it >= max_iters) { sum.termination = 0; break; }
+    if (gmax <= 1e-10) { sum.termination = 2; break; }
+    if (radius <= 1e-32) { sum.termination = 4; break; }
+    it++;
+    if ((rc = vsl_ba_session_step_dev(s, packB.as<double>(), radius, refresh, packC.as<double>()))) return rc;
+    if ((rc = AR(packC.as<double>(), 8, 0))) return rc;
+    double c[8];
+    if ((rc = D2H(c, packC.p, 64))) return rc;
+    const double cams_step2 = c[5] / world, cams_x2 = c[6] / world;
+    const bool ok = c[0] == 0.0 && c[1] > 0.0;
+    if (!ok) {
+      if (++invalid >= 5) { sum.termination = 4; break; }
+      radius *= 0.5;
+      refresh = 0;
+      continue;
+    }
+    invalid = 0;
+    const double step_norm = sqrt(std::max(c[2] - (world - 1) * cams_step2, 0.0));
+    const double x_norm = sqrt(std::max(c[3] - (world - 1) * cams_x2, 0.0));
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 3; break; }
+    const double cost_change = cost - c[4];
+    if (fabs(cost_change) <= 1e-6 * cost) { sum.termination = 1; break; }
+    const double rel = cost_change / c[1];
+    if (verbosity >= 2) fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", it, c[4], cost_change, gmax, step_norm, rel, radius);
+    if (rel > 1e-3) {
+      if ((rc = vsl_ba_session_accept(s))) return rc;
+      if ((rc = vsl_ba_session_linearize(s, 1))) return rc;
+      refresh = 1;
+      sum.successful_steps++;
+      radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
+      decrease = 2.0;
+    } else {
+      radius /= decrease;
+      decrease *= 2.0;
+      refresh = 0;
+    }
+  }
+  sum.iterations = it;
+  sum.final_cost = cost;
+  if (poses_out) {
+    VSL_HIP(ctx, hipMemcpyAsync(poses_out, st.poses.p, sizeof(double) * 7 * (size_t)st.D.C, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (points_all_out) {
+    // every rank's landmarks: a zero buffer with the own range filled in, summed over the ranks
+    const size_t total = 3 * (size_t)s->n_lms_total;
+    if (gather.alloc(8 * total) != hipSuccess) return vsl_fail(ctx, VSL_ERR_NOMEM, "vsl_ba_session_solve: device allocation failed");
+    VSL_HIP(ctx, hipMemsetAsync(gather.p, 0, 8 * total, ctx->stream));
+    VSL_HIP(ctx, hipMemcpyAsync(gather.as<double>() + 3 * (size_t)s->lm_first, st.points.p, sizeof(double) * 3 * (size_t)st.D.L,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = AR(gather.as<double>(), total, 0))) return rc;
+    VSL_HIP(ctx, hipMemcpyAsync(points_all_out, gather.p, 8 * total, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sum.total_ms = now_ms() - t_start;
+  if (verbosity >= 1)
+    fprintf(stderr, "vsl global BA (%d rank%s, %s system, bandwidth %d of %d): iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n",
+            world, world > 1 ? "s" : "", st.banded ? "band" : "dense", st.bw, n, sum.iterations, sum.initial_cost, sum.final_cost,
+            sum.termination, sum.total_ms);
+  if (summary) *summary = sum;
+  return VSL_OK;
+}
+
+// global_bundle_adjustment (include/visnav/loop_closure_utils.h:672-748) over `world` ranks: landmarks are split into
+// contiguous ranges balanced by observation count, rank `rank` owns one; poses / points of `prob` are updated in place
+// on every rank.  world = 1 (allreduce may be null) is the single-GPU session path.
+extern "C" int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_allreduce_fn allreduce,
+                                        void* user, int rank, int world, vsl_ba_summary* summary) {
+  int rc = ba_validate(ctx, prob);
+  if (rc) return rc;
+  if (!opt || world < 1 || rank < 0 || rank >= world) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_global_bundle_adjust: bad arguments");
+  // contiguous landmark ranges balanced by observation count (the same rule as visual-slam_amd/dist.py landmark_ranges)
+  std::vector<int64_t> csum(prob->n_lms + 1, 0);
+  for (int i = 0; i < prob->n_obs; i++) csum[prob->obs_lm[i] + 1]++;
+  for (int l = 0; l < prob->n_lms; l++) csum[l + 1] += csum[l];
+  std::vector<int> cuts(world + 1, 0);
+  for (int r = 1; r < world; r++) {
+    const double target = (double)csum[prob->n_lms] * r / world;
+    cuts[r] = (int)(std::lower_bound(csum.begin(), csum.end(), target, [](int64_t v, double t) { return (double)v < t; }) - csum.begin());
+    cuts[r] = std::min(std::max(cuts[r], cuts[r - 1]), prob->n_lms);
+  }
+  cuts[world] = prob->n_lms;
+  const int first = cuts[rank], count = cuts[rank + 1] - cuts[rank];
+  if (count < 1) return vsl_fail(ctx, VSL_ERR_INVALID, "rank %d owns no landmarks (%d landmarks over %d ranks)", rank, prob->n_lms, world);
+  vsl_ba_session* s = nullptr;
+  if ((rc = vsl_ba_session_create(ctx, prob, opt, first, count, &s))) return rc;
+  rc = vsl_ba_session_solve(s, allreduce, user, world, opt->max_num_iterations, opt->verbosity, prob->poses, prob->points, summary);
+  vsl_ba_session_destroy(s);
+  return rc;
+}
+
+// Plain copies for callers that hold device pointers of this library (the all-reduce callbacks of the tests):
+// kind 0 host->device, 1 device->host, 2 device->device; synchronous.
+extern "C" int vsl_ctx_memcpy(vsl_ctx* ctx, void* dst, const void* src, size_t bytes, int kind) {
+  if (!ctx || !dst || !src || kind < 0 || kind > 2) return VSL_ERR_INVALID;
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+  VSL_HIP(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VSL_OK;
 }

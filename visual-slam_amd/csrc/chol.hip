@@ -10,9 +10,21 @@
 //                                (3) rank-32 update of the trailing lower triangle, 64x64 tiles,
 //                                    4x4 register blocking, operands staged through LDS.
 // Forward / backward substitution reuse the panel structure and the inverted diagonal blocks: one launch
-// per panel and direction, no serial triangular solve.  Everything is deterministic
+// per panel and direction, no serial triangular solve.
+//
+// BAND FORM.  Every kernel addresses the matrix as A[i * ld + c] and visits only rows within `bw` of the panel, so
+// the same code factors a dense matrix (ld = n, bw = n) and a symmetric BAND matrix in LAPACK-style lower band
+// storage: row i keeps its entries c in [i - bws, i] contiguously, bws = bw + CH_NB, and the caller passes
+// A = storage + bws, ld = bws  (then A[i * ld + c] = storage[i * (bws + 1) + (c - i + bws)]).  The extra CH_NB
+// columns of explicit zeros are the ragged corner of a panel (rows up to k + nb + bw - 1 against columns from k), and
+// they stay zero: a Cholesky factor has no fill outside the band.  The reduced camera system of a 500-keyframe loop
+// is such a matrix once the cameras are ordered along the trajectory (ba.hip: reverse Cuthill-McKee on the
+// covisibility graph): ~n bw^2 instead of n^3 / 3 operations and n (bws + 1) instead of n^2 doubles.
+// Everything is deterministic
 // (no atomics).  Written here rather than calling rocSOLVER: librocsolver.so is a 0.9 GB load that
 // takes minutes to page in on a fresh machine.
+#include <algorithm>
+
 #include "vsl_common.h"
 
 #define CH_NB 32
@@ -29,14 +41,14 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, int n, int k, int nb, int* __restrict__ ok,
+__global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, int ld, int k, int nb, int* __restrict__ ok,
                                                        double* __restrict__ Linv) {
   if (!*ok) return;
   const int lane = threadIdx.x & 31;  // lanes 32..63 mirror 0..31 (their results are discarded)
   double r[CH_NB];
 #pragma unroll
   for (int c = 0; c < CH_NB; c++)
-    r[c] = (lane < nb && c < nb) ? A[(size_t)(k + lane) * n + k + c] : (lane == c ? 1.0 : 0.0);
+    r[c] = (lane < nb && c < nb && c <= lane) ? A[(size_t)(k + lane) * ld + k + c] : (lane == c ? 1.0 : 0.0);  // lower triangle only (band storage has no upper part)
   bool good = true;
   double dinv[CH_NB];  // 1 / L_jj, wave-uniform
 #pragma unroll
@@ -57,7 +69,7 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, i
   if (threadIdx.x < nb) {
 #pragma unroll
     for (int c = 0; c < CH_NB; c++)
-      if (c <= lane && c < nb) A[(size_t)(k + lane) * n + k + c] = r[c];
+      if (c <= lane && c < nb) A[(size_t)(k + lane) * ld + k + c] = r[c];
   }
   // column `lane` of the inverse: forward substitution of L x = e_lane; L_rp comes from lane r's registers
   double x[CH_NB];
@@ -77,8 +89,9 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(double* __restrict__ A, i
 
 // (2) rows i >= k+nb:  A[i, k:k+nb] <- A[i, k:k+nb] * L_kk^-T = sum_p A[i][p] Linv[c][p]
 // 256 threads = 8 rows x 32 columns per step, 64 rows per workgroup.
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int k, int nb, const int* __restrict__ ok,
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A, int n, int ld, int k, int nb, const int* __restrict__ ok,
                                                          const double* __restrict__ Linv) {
+  // n = one past the last row this panel reaches (min(matrix rows, k + nb + bw))
   __shared__ double Li[CH_NB][CH_NB + 1];
   __shared__ double R[64][CH_NB + 1];
   if (!*ok) return;
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
   for (int t = threadIdx.x; t < CH_NB * CH_NB; t += 256) Li[t / CH_NB][t % CH_NB] = Linv[t];
   for (int t = threadIdx.x; t < 64 * CH_NB; t += 256) {
     const int r = t / CH_NB, c = t % CH_NB;
-    R[r][c] = (i0 + r < n && c < nb) ? A[(size_t)(i0 + r) * n + k + c] : 0.0;
+    R[r][c] = (i0 + r < n && c < nb) ? A[(size_t)(i0 + r) * ld + k + c] : 0.0;
   }
   __syncthreads();
   const int c = threadIdx.x % CH_NB;
@@ -94,13 +107,13 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ A,
     double s = 0;
 #pragma unroll
     for (int p = 0; p < CH_NB; p++) s += R[r][p] * Li[c][p];  // Linv is zero above its diagonal
-    if (i0 + r < n && c < nb) A[(size_t)(i0 + r) * n + k + c] = s;
+    if (i0 + r < n && c < nb) A[(size_t)(i0 + r) * ld + k + c] = s;
   }
 }
 
 // (3) trailing update, lower triangle: C[i][j] -= sum_p P[i][p] P[j][p], i, j >= k+nb.
 // grid.x enumerates tile pairs (ti >= tj) of 64x64 tiles; 256 threads, 4x4 outputs each.
-__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, int n, int k, int nb, int T,
+__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A, int n, int ld, int k, int nb, int T,
                                                           const int* __restrict__ ok) {
   if (!*ok) return;
   // decode the (ti, tj) pair of this workgroup from its linear id over the lower triangle
@@ -115,8 +128,8 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
   __shared__ double Pj[64][CH_NB + 1];
   for (int t = threadIdx.x; t < 64 * CH_NB; t += 256) {
     const int r = t / CH_NB, c = t % CH_NB;
-    Pi[r][c] = (i0 + r < n && c < nb) ? A[(size_t)(i0 + r) * n + k + c] : 0.0;
-    Pj[r][c] = (j0 + r < n && c < nb) ? A[(size_t)(j0 + r) * n + k + c] : 0.0;
+    Pi[r][c] = (i0 + r < n && c < nb) ? A[(size_t)(i0 + r) * ld + k + c] : 0.0;
+    Pj[r][c] = (j0 + r < n && c < nb) ? A[(size_t)(j0 + r) * ld + k + c] : 0.0;
   }
   __syncthreads();
   const int tr = (threadIdx.x / 16) * 4, tc = (threadIdx.x % 16) * 4;
@@ -143,14 +156,14 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ A
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       const int i = i0 + tr + a, j = j0 + tc + b;
-      if (i < n && j < n && j <= i) A[(size_t)i * n + j] -= acc[a][b];
+      if (i < n && j < n && j <= i) A[(size_t)i * ld + j] -= acc[a][b];
     }
 }
 
 // forward, panel k:  y_k = Linv_kk b_k  (every workgroup computes it, workgroup 0 stores it in y), then
 // b[i] -= L[i, k:k+nb] . y_k for the rows i >= k+nb of this workgroup.  b_k itself is only read.
 __global__ __launch_bounds__(256) void chol_fwd_kernel(const double* __restrict__ A, double* __restrict__ b, double* __restrict__ y,
-                                                       const double* __restrict__ Linv, int n, int k, int nb) {
+                                                       const double* __restrict__ Linv, int n, int ld, int k, int nb) {
   __shared__ double bk[CH_NB], yk[CH_NB];
   if (threadIdx.x < CH_NB) bk[threadIdx.x] = threadIdx.x < nb ? b[k + threadIdx.x] : 0.0;
   __syncthreads();
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const double* __restrict_
   __syncthreads();
   const int i = k + nb + blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const double* row = A + (size_t)i * n + k;
+  const double* row = A + (size_t)i * ld + k;
   double s = 0;
   for (int p = 0; p < nb; p++) s += row[p] * yk[p];
   b[i] -= s;
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256) void chol_fwd_kernel(const double* __restrict_
 // backward, panel k:  x_k = Linv_kk^T y_k  (stored into b by workgroup 0), then y[c] -= sum_r L[k+r][c] x_k[r]
 // for the columns c < k of this workgroup.
 __global__ __launch_bounds__(256) void chol_bwd_kernel(const double* __restrict__ A, double* __restrict__ b, double* __restrict__ y,
-                                                       const double* __restrict__ Linv, int n, int k, int nb) {
+                                                       const double* __restrict__ Linv, int c_first, int ld, int k, int nb) {
   __shared__ double yk[CH_NB], xk[CH_NB];
   if (threadIdx.x < CH_NB) yk[threadIdx.x] = threadIdx.x < nb ? y[k + threadIdx.x] : 0.0;
   __syncthreads();
@@ -183,17 +196,284 @@ __global__ __launch_bounds__(256) void chol_bwd_kernel(const double* __restrict_
     if (blockIdx.x == 0 && threadIdx.x < nb) b[k + threadIdx.x] = s;
   }
   __syncthreads();
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = c_first + blockIdx.x * 256 + threadIdx.x;  // columns [c_first, k): the band reaches no further left
   if (c >= k) return;
   double s = 0;
-  for (int r = 0; r < nb; r++) s += A[(size_t)(k + r) * n + c] * xk[r];
+  for (int r = 0; r < nb; r++) s += A[(size_t)(k + r) * ld + c] * xk[r];
   y[c] -= s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow bands (bw <= CBF_MAXBW): the whole solve -- factorisation, forward substitution (the right-hand side rides
+// along as one more row of the matrix) and backward substitution -- in ONE launch of ONE workgroup.  A panel step
+// touches only the bw rows below the diagonal block, ~bw^2 / 2 x 32 multiply-adds (0.8 MFLOP at bw = 221): too little
+// to spread over the chip, and as separate launches the 188 panels of a 1000-camera system are 940 launches of 5-22 us
+// (measured ~10 ms of a 14.7 ms LM iteration).  One step here, on a window staged in LDS (rows k .. k + 32 + m of the
+// 32 panel columns, plus the right-hand side as the last row):
+//   * four sub-steps of 8 columns: every wavefront factors the 8 x 8 diagonal sub-block redundantly in its lanes 0..7
+//     (v_readlane column broadcasts), every thread solves ITS row against it and, after a barrier, subtracts its
+//     contribution from the remaining columns of its row -- the diagonal-block rows are rows like any other, there is no
+//     one-wavefront serial phase (a row-per-lane 32 x 32 factor on one wavefront measured 27k cycles per panel, the
+//     32-column row solve behind it 26k: 60 KB of unrolled code);
+//   * the m x m window update in 16 x 16 tiles of v_mfma_f64_16x16x4_f64 (faster here than register tiles on the
+//     vector ALU, see the loop); rows of the band are written back coalesced;
+// nothing to synchronise between workgroups, no flags, no spinning.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+#define CBF_THREADS 576  // 9 wavefronts: one thread per window row (32 + 512 + the right-hand side)
+#define CBF_MAXBW 512
+#define CBF_SUB 8
+#define CBF_TCH 6  // window tiles per wavefront whose old values are in flight together
+__global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __restrict__ A, int ld, int n, int bw,
+                                                                      double* __restrict__ b, double* __restrict__ y,
+                                                                      double* __restrict__ dinvg, int* __restrict__ ok) {
+  __shared__ double W[CH_NB + CBF_MAXBW + 1][CH_NB + 1];  // window rows x 32 panel columns (row stride 33: conflict-free)
+  __shared__ double red[CBF_THREADS / 32][CH_NB + 1];
+  __shared__ int fail_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
+  if (tid == 0) fail_s = 0;
+  __syncthreads();
+#ifdef CBF_TIMING
+  long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
+#define CBF_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); tph[q] += t2 - tt; tt = t2; }
+#else
+#define CBF_STAMP(q)
+#endif
+  for (int k = 0; k < n; k += CH_NB) {
+    const int nb = min(CH_NB, n - k);
+    const int m = min(n - k - nb, bw);
+    const int rows = CH_NB + m + 1;  // diagonal block, panel, right-hand side
+    const int base = k + nb;
+    // stage the window: 32 consecutive doubles per row (coalesced); the diagonal block is completed with the identity
+    // when nb < 32, its upper triangle is zero
+    for (int idx = tid; idx < rows * CH_NB; idx += CBF_THREADS) {
+      const int row = idx >> 5, c = idx & 31;
+      double v;
+      if (row < CH_NB)
+        v = (row < nb && c <= row) ? A[(size_t)(k + row) * ld + k + c] : (row == c ? 1.0 : 0.0);
+      else if (row < CH_NB + m)
+        v = c < nb ? A[(size_t)(k + nb + row - CH_NB) * ld + k + c] : 0.0;
+      else
+        v = c < nb ? b[k + c] : 0.0;
+      W[row][c] = v;
+    }
+    __syncthreads();
+    CBF_STAMP(0)
+    bool good = true;
+#pragma unroll 1
+    for (int j0 = 0; j0 < CH_NB; j0 += CBF_SUB) {
+      const bool act = tid < rows && tid >= j0;
+      double a[CBF_SUB], dr[CBF_SUB], inv[CBF_SUB], x[CBF_SUB];
+#pragma unroll
+      for (int c = 0; c < CBF_SUB; c++) {
+        a[c] = act ? W[tid][j0 + c] : 0.0;
+        dr[c] = lane < CBF_SUB ? W[j0 + lane][j0 + c] : (lane == c ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int c = 0; c < CBF_SUB; c++) {
+        const double d = lane_bcast(dr[c], c);
+        if (!(d > 0.0) || !isfinite(d)) good = false;  // wave-uniform
+        // 1 / sqrt(d) by the hardware estimate and two Newton steps, sqrt(d) = d / sqrt(d): the IEEE sqrt and divide
+        // expansions are ~100 dependent fp64 instructions (~1000 cycles) per pivot, and the 32 pivots of a panel are
+        // sequential -- measured 47k of the 100k cycles of a panel step
+        double iv = __builtin_amdgcn_rsq(d);
+        iv = iv * (1.5 - 0.5 * d * iv * iv);
+        iv = iv * (1.5 - 0.5 * d * iv * iv);
+        inv[c] = iv;
+        dr[c] = (lane == c) ? d * iv : dr[c] * iv;  // lanes > c: l(lane, c)
+#pragma unroll
+        for (int q = c + 1; q < CBF_SUB; q++) dr[q] -= dr[c] * lane_bcast(dr[c], q);  // meaningful for lanes >= q
+      }
+      CBF_STAMP(4)
+      // x L_d^T = a: this row's entries in the sub-panel (for a row of the diagonal sub-block: that row of L_d)
+#pragma unroll
+      for (int c = 0; c < CBF_SUB; c++) {
+        double t = a[c];
+#pragma unroll
+        for (int q = 0; q < c; q++) t -= x[q] * lane_bcast(dr[q], c);
+        x[c] = t * inv[c];
+      }
+      CBF_STAMP(5)
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < CBF_SUB; c++)
+          if (tid >= j0 + CBF_SUB || c <= tid - j0) W[tid][j0 + c] = x[c];
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < CBF_SUB; c++)
+          if (k + j0 + c < n) dinvg[k + j0 + c] = inv[c];
+      }
+      __syncthreads();
+      CBF_STAMP(6)
+      // the remaining panel columns of this row lose x . (row cc of the factor): W[cc][j0 .. j0 + 7], cc > j0 + 7
+      if (act && tid >= j0 + CBF_SUB) {
+        // four columns at a time (independent chains, LDS reads batched); a diagonal-block row stops at its diagonal
+        const int c_end = tid < CH_NB ? tid + 1 : CH_NB;
+        for (int cc = j0 + CBF_SUB; cc < c_end; cc += 4) {
+          double t[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) t[u] = W[tid][min(cc + u, CH_NB - 1)];
+#pragma unroll
+          for (int q = 0; q < CBF_SUB; q++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] -= x[q] * W[min(cc + u, CH_NB - 1)][j0 + q];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (cc + u < c_end) W[tid][cc + u] = t[u];
+        }
+      }
+      CBF_STAMP(7)
+      __syncthreads();
+      CBF_STAMP(8)
+    }
+    if (!good && lane == 0) fail_s = 1;
+    __syncthreads();
+    CBF_STAMP(1)
+    if (fail_s) break;  // workgroup-uniform
+    // write the factored rows back to the band (coalesced), y_k, and b of the window rows
+    for (int idx = tid; idx < (CH_NB + m) * CH_NB; idx += CBF_THREADS) {
+      const int row = idx >> 5, c = idx & 31;
+      if (row < CH_NB) {
+        if (row < nb && c <= row) A[(size_t)(k + row) * ld + k + c] = W[row][c];
+      } else if (c < nb) {
+        A[(size_t)(k + nb + row - CH_NB) * ld + k + c] = W[row][c];
+      }
+    }
+    if (tid < nb) y[k + tid] = W[rows - 1][tid];
+    if (tid < m) {
+      double dot = 0.0;
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) dot += W[CH_NB + tid][c] * W[rows - 1][c];
+      b[k + nb + tid] -= dot;
+    }
+    CBF_STAMP(9)
+    if (m > 0) {
+      // window update A[i][j] -= sum_c P[i][c] P[j][c], j <= i (P = the solved panel, W rows 32 ..): 16 x 16 tiles of
+      // the lower triangle, CBF_THREADS / 64 apart per wavefront, eight v_mfma_f64_16x16x4_f64 each in two chains (lane
+      // l feeds P[i0 + (l & 15)][c0 + (l >> 4)] and P[j0 + (l & 15)][c0 + (l >> 4)]; it receives rows (l >> 4) + 4 reg,
+      // column l & 15 of the tile, so a register is four 128-byte row segments of the band storage).  All old values
+      // of a chunk of tiles are requested before its matrix instructions.  Measured alternatives, cycles per panel
+      // step at bw = 221: 4 x 4 register tiles on the vector ALU with uncoalesced accesses 45k, the same with
+      // 512-byte row segments 90k (LDS-read bound), MFMA one chain 40k, two chains 35k.
+      const int T = (m + 15) >> 4, ntiles = T * (T + 1) / 2;
+      const int kq = lane >> 4, l16 = lane & 15;
+      int ti = 0, tj = wave;  // tile index -> (ti, tj) by integer stepping (an fp64 sqrt per tile costs more than the tile)
+      for (int tile0 = wave; tile0 < ntiles; tile0 += CBF_TCH * (CBF_THREADS / 64)) {
+        double old[CBF_TCH][4];
+        int tis[CBF_TCH], tjs[CBF_TCH];
+#pragma unroll
+        for (int u = 0; u < CBF_TCH; u++) {
+          while (tj > ti) {
+            tj -= ti + 1;
+            ti++;
+          }
+          tis[u] = ti;
+          tjs[u] = tj;
+          const bool have = tile0 + u * (CBF_THREADS / 64) < ntiles;
+          const int j = 16 * tj + l16;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int i = 16 * ti + kq + 4 * q;
+            old[u][q] = (have && i < m && j <= i) ? A[(size_t)(base + i) * ld + base + j] : 0.0;
+          }
+          tj += CBF_THREADS / 64;
+        }
+#pragma unroll
+        for (int u = 0; u < CBF_TCH; u++) {
+          const bool have = tile0 + u * (CBF_THREADS / 64) < ntiles;
+          const int j = 16 * tjs[u] + l16;
+          const int ra = CH_NB + min(16 * tis[u] + l16, m - 1), rb = CH_NB + min(j, m - 1);
+          v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int c0 = 0; c0 < CH_NB / 2; c0 += 4) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][c0 + kq], W[rb][c0 + kq], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][CH_NB / 2 + c0 + kq], W[rb][CH_NB / 2 + c0 + kq], acc2, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int i = 16 * tis[u] + kq + 4 * q;
+            if (have && i < m && j <= i) A[(size_t)(base + i) * ld + base + j] = old[u][q] - (acc[q] + acc2[q]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    CBF_STAMP(2)
+  }
+  if (fail_s) {
+    if (tid == 0) *ok = 0;
+    return;
+  }
+  // backward substitution L^T x = y, last panel first; x overwrites b
+  const int n_panels = (n + CH_NB - 1) / CH_NB;
+  for (int pi = n_panels - 1; pi >= 0; pi--) {
+    const int k = pi * CH_NB;
+    const int nb = min(CH_NB, n - k);
+    const int m = min(n - k - nb, bw);
+    {
+      const int c = tid & 31, part = tid >> 5;  // CBF_THREADS / 32 parts x 32 columns
+      double sum = 0.0;
+      if (c < nb) {
+        constexpr int NP = CBF_THREADS / 32;
+        for (int t0 = part; t0 < m; t0 += 8 * NP) {  // eight loads in flight per thread
+          double av[8], bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int t = t0 + u * NP;
+            av[u] = t < m ? A[(size_t)(k + nb + t) * ld + k + c] : 0.0;
+            bv[u] = t < m ? b[k + nb + t] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) sum += av[u] * bv[u];
+        }
+      }
+      red[part][c] = sum;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int part = 0; part < CBF_THREADS / 32; part++) sacc += red[part][l32];
+      double v = l32 < nb ? y[k + l32] - sacc : 0.0;
+      const double dv = l32 < nb ? dinvg[k + l32] : 1.0;
+      // column `l32` of the diagonal factor: rT[c] = L[c][l32], c >= l32
+      double rT[CH_NB];
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) rT[c] = (c < nb && l32 < nb && c >= l32) ? A[(size_t)(k + c) * ld + k + l32] : 0.0;
+      double xv = 0.0;
+#pragma unroll
+      for (int c = CH_NB - 1; c >= 0; c--) {
+        const double xc = lane_bcast(v, c) * lane_bcast(dv, c);
+        if (l32 == c) xv = xc;
+        if (l32 < c) v -= rT[c] * xc;
+      }
+      if (lane < nb) b[k + lane] = xv;
+    }
+    __syncthreads();
+  }
+  CBF_STAMP(3)
+#ifdef CBF_TIMING
+  if (tid == 0) printf("chol_band_fused ticks: stage %lld rest-of-factor %lld writeback+update %lld backward %lld | factor8 %lld solve %lld store+barrier %lld rowupdate %lld barrier %lld\n", tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[8]);
+  if (tid == 0) printf("   writeback+b %lld\n", tph[9]);
+#endif
+}
+
 // Solves S x = b in place (S destroyed, b <- x).  *ok_dev = 1 on success, 0 if S is not SPD.
-int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev) {
+// Dense: ld = n, bw = n.  Band: S = storage + bws, ld = bws = bw + CH_NB (see the file header); bw = the largest
+// i - c of a non-zero entry.
+int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
   const int one = 1;
   const int n_panels = (n + CH_NB - 1) / CH_NB;
+  if (ld != n && bw <= CBF_MAXBW && !ctx->chol_no_fused) {  // narrow band: one launch for the whole solve
+    void* ws = nullptr;
+    int rc = vsl_ctx_dscratch(ctx, sizeof(double) * (2 * (size_t)n + 16), &ws);
+    if (rc) return rc;
+    VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(chol_band_fused_kernel, dim3(1), dim3(CBF_THREADS), 0, ctx->stream, S, ld, n, bw, b, (double*)ws,
+                       (double*)ws + n, ok_dev);
+    VSL_CHECK_LAUNCH(ctx);
+    return VSL_OK;
+  }
   void* ws = nullptr;  // inverse diagonal blocks + the intermediate vector y
   int rc = vsl_ctx_dscratch(ctx, sizeof(double) * ((size_t)n_panels * CH_NB * CH_NB + (size_t)n + 8), &ws);
   if (rc) return rc;
@@ -203,28 +483,35 @@ int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev) {
   for (int k = 0, pi = 0; k < n; k += CH_NB, pi++) {
     const int nb = n - k < CH_NB ? n - k : CH_NB;
     double* Li = Linv + (size_t)pi * CH_NB * CH_NB;
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, ctx->stream, S, n, k, nb, ok_dev, Li);
-    const int m = n - k - nb;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(64), 0, ctx->stream, S, ld, k, nb, ok_dev, Li);
+    const int m = std::min(n - k - nb, bw);  // rows below the diagonal block that the band reaches
     if (m > 0) {
-      hipLaunchKernelGGL(chol_panel_kernel, dim3((m + 63) / 64), dim3(256), 0, ctx->stream, S, n, k, nb, ok_dev, Li);
+      const int n_end = k + nb + m;
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((m + 63) / 64), dim3(256), 0, ctx->stream, S, n_end, ld, k, nb, ok_dev, Li);
       const int T = (m + 63) / 64;
-      hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, S, n, k, nb, T, ok_dev);
+      hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, ctx->stream, S, n_end, ld, k, nb, T, ok_dev);
     }
   }
   VSL_CHECK_LAUNCH(ctx);
   // (a failed factorisation leaves Linv / y undefined; the caller looks at *ok_dev before using b)
   for (int k = 0, pi = 0; k < n; k += CH_NB, pi++) {
     const int nb = n - k < CH_NB ? n - k : CH_NB;
-    const int m = n - k - nb;
+    const int m = std::min(n - k - nb, bw);
     hipLaunchKernelGGL(chol_fwd_kernel, dim3(m > 0 ? (m + 255) / 256 : 1), dim3(256), 0, ctx->stream, S, b, y,
-                       Linv + (size_t)pi * CH_NB * CH_NB, n, k, nb);
+                       Linv + (size_t)pi * CH_NB * CH_NB, k + nb + std::max(m, 0), ld, k, nb);
   }
   for (int pi = n_panels - 1; pi >= 0; pi--) {
     const int k = pi * CH_NB;
     const int nb = n - k < CH_NB ? n - k : CH_NB;
-    hipLaunchKernelGGL(chol_bwd_kernel, dim3(k > 0 ? (k + 255) / 256 : 1), dim3(256), 0, ctx->stream, S, b, y,
-                       Linv + (size_t)pi * CH_NB * CH_NB, n, k, nb);
+    const int c_first = std::max(0, k + nb - 1 - (bw + CH_NB - 1));  // row k + nb - 1 reaches back to column (k + nb - 1) - bw at most
+    const int cols = k - c_first;
+    hipLaunchKernelGGL(chol_bwd_kernel, dim3(cols > 0 ? (cols + 255) / 256 : 1), dim3(256), 0, ctx->stream, S, b, y,
+                       Linv + (size_t)pi * CH_NB * CH_NB, c_first, ld, k, nb);
   }
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
+}
+
+int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev) {
+  return vsl_chol_solve_band_dev(ctx, S, b, n, n, n, ok_dev);
 }

@@ -58,6 +58,8 @@ struct vsl_ctx {
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
+  bool chol_no_fused = false;           // diagnostic: band Cholesky as one launch per panel step instead of the fused single-launch kernel
+  bool ba_force_dense = false;          // diagnostic: dense reduced camera system even where the band form applies
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = 256;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
@@ -142,6 +144,9 @@ int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_
 
 // dense fp64 Cholesky solve on the device (chol.hip): S x = b in place, *ok_dev = 0 if not SPD
 int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev);
+// the same on LAPACK-style lower band storage (chol.hip, "BAND FORM"): S = storage + bws, ld = bws = bw + VSL_CHOL_NB
+#define VSL_CHOL_NB 32
+int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev);
 
 // scratch store of the host-buffer API
 int vsl_ctx_scratch_frames(vsl_ctx* ctx, int w, int h, int feat, vsl_frames** out);
