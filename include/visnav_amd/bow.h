@@ -10,15 +10,8 @@
 #include <string>
 #include <vector>
 
+#include "dbow2_types.h"
 #include "keypoints.h"
-
-namespace DBoW2 {
-typedef unsigned int WordId;
-typedef unsigned int NodeId;
-typedef double WordValue;
-class BowVector : public std::map<WordId, WordValue> {};
-class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
-}  // namespace DBoW2
 
 namespace visnav {
 

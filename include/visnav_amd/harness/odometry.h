@@ -1,6 +1,8 @@
 // harness/odometry.h -- headless restatement of the reference's per-frame pipeline, i.e. the call order
-// of next_step() (src/slam.cpp:1087-1458) with the GUI, relocalisation and loop-closure branches left
-// out (enable_relocalization = enable_loop_closure = false), written against the SAME operator names the
+// of next_step() (src/slam.cpp:1087-1458) without the GUI.  The relocalisation branch (track_camera /
+// relocalize_camera, src/slam.cpp:1167-1191) and the loop-closure branch (detect_loop_closure -> compute_sim3 ->
+// loop_closure -> global_ba, :1219-1258, :1287) are options like the reference's GUI switches (default off here: they
+// need a vocabulary; the reference's defaults are on).  Written against the SAME operator names the
 // reference calls: detectKeypointsAndDescriptors, matchDescriptors, project_landmarks,
 // find_matches_landmarks, bundle_adjustment -- here the MI355X drop-ins of include/visnav_amd/ -- plus the
 // host-side pieces the reference takes from OpenGV (harness/pnp.h) and its own small helpers:
@@ -26,12 +28,15 @@
 #include "../bow.h"
 #include "../bundle_adjustment.h"
 #include "../keypoints.h"
+#include "../loop_closure.h"
 #include "../vo_utils.h"
 #include "ate.h"
 #include "camera.h"
 #include "geometry.h"
 #include "io.h"
 #include "pnp.h"
+#include "sim3.h"
+#include "tracking.h"
 
 namespace visnav {
 namespace harness {
@@ -56,6 +61,24 @@ struct OdometryOptions {  // defaults = the pangolin::Var defaults of src/slam.c
   // descriptors are copied device-to-device into the map's pool.  Same kernels, same matches, same
   // trajectory as the operator-by-operator sequence (tests/test_headless_gpu.py); fewer PCIe round trips.
   bool fused_tracking = false;
+  // src/slam.cpp:244-247, :274-294 (the reference's defaults are true / true / true; they need --voc-path)
+  bool enable_relocalization = false;
+  bool enable_loop_closure = false;
+  bool enable_global_ba_after_loop_closure = true;
+  double motion_threshold = 0.5;
+  int num_cov_threshold = 10;
+  int num_ess_threshold = 30;
+  int num_consistency = 3;
+  int loop_closing_time_threshold = 500;  // frames between a keyframe and a loop candidate
+  bool use_sim3 = true;
+  bool fixed_current_kf = true;
+  int gba_max_iterations = 20;
+  // TEST HOOK (-1 = off): from keyframe frame id `force_loop_from` on, keyframe `force_loop_candidate` is handed to
+  // the loop-closing stage as a consistent candidate once, whatever detect_loop_closure says -- the rendered box room
+  // is not distinctive enough for the BoW consistency test to fire (every keyframe pair scores 0.27-0.38 with a random
+  // vocabulary), so the stages behind detection (compute_sim3, loop_closure, pose graph, global BA) are exercised this way;
+  // detection itself is tested on constructed vectors (tests/cpp/loop_closure_test.cpp)
+  int force_loop_from = -1, force_loop_candidate = 0;
 };
 
 struct StageClock {
@@ -238,16 +261,59 @@ class Odometry {
   std::map<FrameCamId, DBoW2::FeatureVector> feature_vectors;
   StageClock clock;
   int last_inliers = 0, last_matches = 0;
+  // relocalisation / loop closure state, with the names of src/slam.cpp:127-190
+  Sophus::SE3d vel, last_pose;
+  bool tracking_successful = true;
+  CovisibilityGraph graph;
+  DBoWInvertedFile orb_db;  // resized to the vocabulary size (src/slam.cpp:380)
+  ConsistentGroups consistent_groups;
+  std::vector<FrameCamId> enough_consistent_candidates;
+  std::vector<std::pair<FrameCamId, FrameCamId>> loop_edges;
+  bool pose_graph_opt_done = false;
+  int n_tracking_lost = 0, n_relocalized = 0, n_loops_closed = 0, n_global_ba = 0;
+  double loop_ms = 0, gba_ms = 0;
 
   // One step of the pipeline on the stereo pair of frame `current_frame` (the right image is only
   // looked at on keyframes).
   // `next_left` (fused mode only, may be null): the left image of the FOLLOWING frame.  Its upload and
   // detect / describe kernels are enqueued as soon as this frame's device results are on the host, so
   // they run on the GPU while the host does P3P-RANSAC, triangulation and map bookkeeping for this frame.
+  // src/slam.cpp:1099-1114: with relocalisation on, the guided search projects with the constant-motion prediction
+  Sophus::SE3d projection_pose() const {
+    return (opt.enable_relocalization && tracking_successful) ? se3_mul(current_pose, vel) : current_pose;
+  }
+  // src/slam.cpp:1167-1191 / :1348-1372
+  void localize(const FrameCamId& fcidl, const GreyImage& img_left, const KeypointsData& kdl, LandmarkMatchData& md) {
+    if (!opt.enable_relocalization) {
+      localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md, rng);
+      current_pose = md.T_w_c;
+      return;
+    }
+    tracking_successful = track_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks,
+                                       opt.reprojection_error_pnp_inlier_threshold_pixel, md, vel, opt.motion_threshold,
+                                       tracking_successful, rng);
+    if (tracking_successful) {
+      current_pose = md.T_w_c;
+      return;
+    }
+    n_tracking_lost++;
+    const Sophus::SE3d tracking_result = md.T_w_c;
+    ImageRef l(img_left);
+    if (orb_voc && relocalize_camera(fcidl, l.img, calib_cam, graph, orb_voc, orb_db, cameras, vel, current_pose, feature_corners,
+                                     landmarks, opt.motion_threshold, opt.reprojection_error_pnp_inlier_threshold_pixel, md, rng)) {
+      current_pose = md.T_w_c;
+      tracking_successful = true;
+      n_relocalized++;
+    } else {
+      current_pose = tracking_result;
+    }
+  }
+
   void next_step(const GreyImage& img_left, const GreyImage& img_right, const GreyImage* next_left = nullptr) {
     typedef std::chrono::steady_clock Clk;
     auto ms = [](Clk::time_point a, Clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const FrameCamId fcidl(current_frame, 0), fcidr(current_frame, 1);
+    if (orb_voc && orb_db.empty()) orb_db.resize(orb_voc->size());
     std::vector<Eigen::Vector2d, Eigen::aligned_allocator<Eigen::Vector2d>> projected_points;
     std::vector<TrackId> projected_track_ids;
     LandmarkMatchData md;
@@ -255,7 +321,7 @@ class Odometry {
       take_keyframe = false;
       auto t0 = Clk::now();
       if (!opt.fused_tracking)
-        project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
+        project_landmarks(projection_pose(), calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
                           projected_track_ids);
       auto t1 = Clk::now();
       MatchData md_stereo;
@@ -286,29 +352,68 @@ class Odometry {
         find_matches_landmarks(kdl, landmarks, feature_corners, projected_points, projected_track_ids, opt.match_max_dist_2d,
                                opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
       auto t4 = Clk::now();
-      localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md,
-                      rng);
-      current_pose = md.T_w_c;
+      localize(fcidl, img_left, kdl, md);
       auto t5 = Clk::now();
       add_new_landmarks(fcidl, fcidr, kdl, kdr, calib_cam, md_stereo, md, landmarks, next_landmark_id);
       Camera cam_left, cam_right;
       cam_left.T_w_c = current_pose;
+      const bool graph_needed = opt.enable_relocalization || opt.enable_loop_closure;
+      if (graph_needed) construct_visibility_graph(fcidl, cameras, landmarks, cam_left, graph, opt.num_cov_threshold);  // :1198
       cam_left.active = true;
       cam_left.last_fcid = last_kf_fcid;
+      if (orb_voc) {  // src/slam.cpp:1205-1208
+        auto tb = Clk::now();
+        ImageRef l(img_left);
+        compute_bow_vector(l.img, opt.num_features_per_image, orb_voc, cam_left.bow_vector, cam_left.feature_vector);
+        bow_vectors[fcidl] = cam_left.bow_vector;
+        feature_vectors[fcidl] = cam_left.feature_vector;
+        clock.bow_ms += ms(tb, Clk::now());
+      }
       cam_right.T_w_c = to_se3(to_pose(current_pose) * T_0_1);
       cam_right.active = true;
+      if (opt.enable_loop_closure && orb_voc) {  // src/slam.cpp:1219-1258
+        auto tl = Clk::now();
+        bool loop_detected = detect_loop_closure(fcidl, cam_left, cameras, orb_db, orb_voc, graph, consistent_groups,
+                                                 enough_consistent_candidates, opt.num_cov_threshold * 2, opt.num_consistency);
+        if (opt.force_loop_from >= 0 && fcidl.frame_id >= opt.force_loop_from && n_loops_closed == 0 &&
+            cameras.count(FrameCamId(opt.force_loop_candidate, 0))) {
+          enough_consistent_candidates.assign(1, FrameCamId(opt.force_loop_candidate, 0));
+          loop_detected = true;
+        }
+        if (loop_detected) {
+          for (size_t i = 0; i < enough_consistent_candidates.size(); i++) {
+            const FrameCamId cand = enough_consistent_candidates[i];
+            if (fcidl.frame_id - cand.frame_id <= opt.loop_closing_time_threshold) continue;
+            Sophus::SE3d sim3;
+            if (!compute_sim3(calib_cam, fcidl, cand, feature_corners, cameras, landmarks, graph,
+                              opt.reprojection_error_pnp_inlier_threshold_pixel, sim3, rng))
+              continue;
+            loop_edges.emplace_back(fcidl, cand);
+            if (!opt.use_sim3) sim3 = Sophus::SE3d();
+            LoopClosureOptions lco;
+            lco.verbosity_level = opt.ba_verbose;
+            lco.set_current_kf_fixed = opt.fixed_current_kf;
+            loop_closure(fcidl, cam_left, cand, to_se3(T_0_1), sim3, cameras, landmarks, opt.num_ess_threshold, lco);
+            n_loops_closed++;
+            map_dirty = true;
+            if (opt.enable_global_ba_after_loop_closure) pose_graph_opt_done = true;
+          }
+        }
+        loop_ms += ms(tl, Clk::now());
+      } else if (orb_voc && graph_needed) {
+        insert_new_kf_to_db(fcidl, cam_left, orb_db);  // relocalisation alone still needs the inverted file
+      }
       cameras[fcidl] = cam_left;
       cameras[fcidr] = cam_right;
       remove_old_keyframes(fcidl, opt.max_num_kfs, cameras, landmarks, kf_frames);
       if (opt.fused_tracking) fused_register_observations(fcidl, fcidr);
-      if (orb_voc) {  // src/slam.cpp:1206-1208
-        auto tb = Clk::now();
-        ImageRef l(img_left);
-        compute_bow_vector(l.img, opt.num_features_per_image, orb_voc, bow_vectors[fcidl], feature_vectors[fcidl]);
-        clock.bow_ms += ms(tb, Clk::now());
-      }
       auto t6 = Clk::now();
       optimize();
+      if (pose_graph_opt_done) {  // src/slam.cpp:1285-1288
+        auto tg = Clk::now();
+        global_ba();
+        gba_ms += ms(tg, Clk::now());
+      }
       auto t7 = Clk::now();
       current_pose = cameras[fcidl].T_w_c;
       last_kf_fcid = fcidl;
@@ -321,7 +426,7 @@ class Odometry {
     } else {
       auto t0 = Clk::now();
       if (!opt.fused_tracking)
-        project_landmarks(current_pose, calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
+        project_landmarks(projection_pose(), calib_cam.intrinsics[0], landmarks, opt.cam_z_threshold, projected_points,
                           projected_track_ids);
       auto t1 = Clk::now();
       KeypointsData kdl;
@@ -343,9 +448,7 @@ class Odometry {
                                opt.feature_match_max_dist, opt.feature_match_test_next_best, md);
       }
       auto t3 = Clk::now();
-      localize_camera(current_pose, calib_cam.intrinsics[0], kdl, landmarks, opt.reprojection_error_pnp_inlier_threshold_pixel, md,
-                      rng);
-      current_pose = md.T_w_c;
+      localize(fcidl, img_left, kdl, md);
       auto t4 = Clk::now();
       if ((int)md.inliers.size() < opt.new_kf_min_inliers && !opt_running && !opt_finished) take_keyframe = true;
       if (!opt_running && opt_finished) merge_optimized();
@@ -359,6 +462,8 @@ class Odometry {
     last_matches = (int)md.matches.size();
     frame_poses.push_back(current_pose);
     current_frame++;
+    vel = se3_mul(se3_inv(last_pose), current_pose);  // src/slam.cpp:1300-1301, :1454-1455
+    last_pose = current_pose;
   }
 
   // Wait for a running optimisation and merge it (end of sequence).
@@ -492,6 +597,43 @@ class Odometry {
     map_dirty = true;  // landmark positions moved
   }
 
+  // src/slam.cpp:1741-1788 + the merge-back of :1410-1447.  The reference runs it in global_ba_thread and merges at a
+  // later non-keyframe step, skipping what the local BA modified meanwhile; here it runs synchronously (reproducible
+  // runs), so nothing is modified in between and every landmark / camera is taken over.
+  void global_ba() {
+    pose_graph_opt_done = false;
+    Cameras cameras_gba = cameras;
+    Landmarks landmarks_gba = landmarks;
+    Calibration calib_cam_gba = calib_cam;
+    Corners corners_gba;
+    for (const auto& kv : cameras_gba) {
+      KeypointsData kd;
+      kd.corners = feature_corners.at(kv.first).corners;
+      corners_gba[kv.first] = kd;
+    }
+    GlobalBundleAdjustmentOptions ba_options;
+    ba_options.use_huber = true;
+    ba_options.huber_parameter = opt.reprojection_error_huber_pixel;
+    ba_options.max_num_iterations = opt.gba_max_iterations;
+    ba_options.verbosity_level = opt.ba_verbose;
+    const std::set<FrameCamId> fixed_cameras = {FrameCamId(0, 0), FrameCamId(0, 1)};
+    global_bundle_adjustment(corners_gba, ba_options, fixed_cameras, calib_cam_gba, cameras_gba, landmarks_gba);
+    n_global_ba++;
+    for (const auto& kv : landmarks_gba) {
+      Landmark& lm = landmarks.at(kv.first);
+      lm.p = kv.second.p;
+      lm.p_c = to_eigen(inverse(to_pose(cameras_gba.at(lm.from_fcid).T_w_c)) * to_vec3(lm.p));
+    }
+    for (const auto& kv : cameras_gba) {
+      Camera& cam = cameras.at(kv.first);
+      cam.T_w_c = kv.second.T_w_c;
+      std::map<FrameCamId, Sophus::SE3d> rel;
+      for (const auto& fr : cam.covisible_rel_poses) rel.emplace(fr.first, se3_mul(se3_inv(cam.T_w_c), cameras_gba.at(fr.first).T_w_c));
+      cam.covisible_rel_poses = rel;
+    }
+    map_dirty = true;
+  }
+
   // ---- fused device path (OdometryOptions::fused_tracking)
   vsl_frames* dev_frames = nullptr;  // slots cur_base / cur_base + 1 = left / right image of the current frame,
                                      // the other pair receives the look-ahead frame
@@ -570,12 +712,18 @@ class Odometry {
   }
 
   void fused_download_corners(int slot, KeypointsData& kd) {
+    // relocalisation / loop closure match keyframe descriptors on demand (tracking.h:283, sim3.h:252): then the
+    // descriptors come along; otherwise only the positions leave the device
+    const bool with_desc = opt.enable_relocalization || opt.enable_loop_closure;
     std::vector<double> xy(2 * (size_t)opt.num_features_per_image);
+    if (with_desc) kd.corner_descriptors.resize((size_t)opt.num_features_per_image);
     int n = 0;
-    amd::check(vsl_frames_download_keypoints(amd::ctx(), dev_frames, slot, opt.num_features_per_image, xy.data(), nullptr, nullptr, &n),
+    amd::check(vsl_frames_download_keypoints(amd::ctx(), dev_frames, slot, opt.num_features_per_image, xy.data(), nullptr,
+                                             with_desc ? reinterpret_cast<uint64_t*>(kd.corner_descriptors.data()) : nullptr, &n),
                "vsl_frames_download_keypoints");
     kd.corners.clear();
     for (int i = 0; i < n; i++) kd.corners.emplace_back(xy[2 * i], xy[2 * i + 1]);
+    if (with_desc) kd.corner_descriptors.resize((size_t)n);
   }
 
   void fused_stereo(KeypointsData& kdl, KeypointsData& kdr, MatchData& md_stereo) {

@@ -6,12 +6,20 @@
 //                                          edges above the essential threshold, the loop constraint), the
 //                                          optimisation itself runs on the MI355X (vsl_pose_graph_optimize)
 // Same names, arguments and in-place update convention as the reference.
+// Round 2 adds the loop DETECTION half (host graph / inverted-file bookkeeping restated; the BoW scores of the
+// surviving candidates go to the GPU in one batched launch, ORBVocabularyAmd::score_batch):
+//   compute_min_connected_covisible (:109-126), detect_loop_candidates (:141-263), insert_new_kf_to_db (:269-276),
+//   detect_loop_closure (:294-388), loop_align (:398-416), update_stereo_pair (:593-601),
+//   update_landmark_position (:607-621), loop_closure (:633-648)
 #pragma once
 #include <cmath>
 #include <map>
 #include <set>
 #include <vector>
 
+#include <unordered_map>
+
+#include "bow.h"
 #include "bundle_adjustment.h"
 
 namespace visnav {
@@ -181,6 +189,204 @@ inline void pose_graph_optimization(const FrameCamId& cur_kf_fcid, Camera& cur_k
   if (options.verbosity_level >= 1)  // stands in for summary.BriefReport() (:585)
     std::printf("vslam_hip PGO: %d nodes, %d edges, iterations %d, initial cost %.6e, final cost %.6e, termination %d\n", N,
                 prob.n_edges, sum.iterations, sum.initial_cost, sum.final_cost, sum.termination);
+}
+
+
+// loop_closure_utils.h:109-126
+inline double compute_min_connected_covisible(const Camera& new_kf, const Cameras& keyframes, const ORBVocabularyAmd* voc, int threshold) {
+  std::vector<const DBoW2::BowVector*> bows;
+  for (const auto& kv : new_kf.covisible_weights)
+    if (kv.second > threshold) bows.push_back(&keyframes.at(kv.first).bow_vector);
+  double min_score = 1;
+  for (double s : voc->score_batch(new_kf.bow_vector, bows))
+    if (s < min_score) min_score = s;
+  return min_score;
+}
+
+// loop_closure_utils.h:141-263.  The reference walks unordered_maps; here candidates are visited in the order their
+// first shared word was met (deterministic), everything else -- the counting quirk (a keyframe's first shared word counts
+// 0), the 0.8 / 0.75 fractions, the accumulation over graph neighbours -- is the reference's.
+inline std::vector<FrameCamId> detect_loop_candidates(const FrameCamId& new_kf_fcid, const Camera& new_kf, const Cameras& keyframes,
+                                                      const CovisibilityGraph& graph, double min_score,
+                                                      DBoWInvertedFile& recognition_database, const ORBVocabularyAmd* voc) {
+  const std::set<FrameCamId>& connected_frames = graph.at(new_kf_fcid);
+  std::unordered_map<FrameCamId, int, FrameCamIdHash> num_sharing_words;
+  std::vector<FrameCamId> first_seen;
+  bool has_any_sharing_words = false;
+  auto bump = [&](const FrameCamId& f) {
+    auto it = num_sharing_words.find(f);
+    if (it != num_sharing_words.end()) {
+      it->second += 1;
+    } else {
+      num_sharing_words[f] = 0;
+      first_seen.push_back(f);
+    }
+  };
+  for (const auto& wv : new_kf.bow_vector) {
+    if (wv.first >= recognition_database.size()) continue;
+    has_any_sharing_words = true;
+    for (const auto& lkf : recognition_database[wv.first]) {
+      if (!connected_frames.count(lkf)) {
+        bump(lkf);
+      } else if (new_kf.covisible_weights.at(lkf) < 30) {
+        bump(lkf);
+      }
+    }
+  }
+  if (!has_any_sharing_words || num_sharing_words.empty()) return {};
+  int max_num_sharing_words = 0;
+  for (const auto& kv : num_sharing_words) max_num_sharing_words = std::max(max_num_sharing_words, kv.second);
+  const int sharing_words_threshold = (int)(max_num_sharing_words * 0.8f);
+  std::vector<FrameCamId> scored;
+  std::vector<const DBoW2::BowVector*> bows;
+  for (const auto& f : first_seen)
+    if (num_sharing_words.at(f) > sharing_words_threshold) {
+      scored.push_back(f);
+      bows.push_back(&keyframes.at(f).bow_vector);
+    }
+  const std::vector<double> scores = voc->score_batch(new_kf.bow_vector, bows);  // ONE launch for all candidates
+  if (std::getenv("VISNAV_AMD_TRACE")) {
+    std::fprintf(stderr, "  loop candidates of %lld: %zu keyframes share words (max %d), %zu above 0.8 max:", (long long)new_kf_fcid.frame_id,
+                 num_sharing_words.size(), max_num_sharing_words, scored.size());
+    for (size_t i = 0; i < scored.size(); i++) std::fprintf(stderr, " %lld=%.3f", (long long)scored[i].frame_id, scores[i]);
+    std::fprintf(stderr, " | connected: %zu, bow nnz %zu\n", connected_frames.size(), new_kf.bow_vector.size());
+  }
+  std::vector<std::pair<double, FrameCamId>> loop_score_and_match;
+  std::unordered_map<FrameCamId, double, FrameCamIdHash> loop_score;
+  for (size_t i = 0; i < scored.size(); i++) {
+    loop_score[scored[i]] = scores[i];
+    if (scores[i] >= min_score) loop_score_and_match.emplace_back(scores[i], scored[i]);
+  }
+  if (loop_score_and_match.empty()) return {};
+  double best_acc_score = min_score;
+  for (const auto& score_fcid : loop_score_and_match) {
+    double acc_score = score_fcid.first;
+    for (const auto& nb : graph.at(score_fcid.second)) {
+      auto it = num_sharing_words.find(nb);
+      if (it != num_sharing_words.end() && it->second > sharing_words_threshold) acc_score += loop_score.at(nb);
+    }
+    if (acc_score > best_acc_score) best_acc_score = acc_score;
+  }
+  const double min_score_to_retain = 0.75f * best_acc_score;
+  std::set<FrameCamId> already_added_kf;
+  std::vector<FrameCamId> loop_candidates;
+  for (const auto& score_fcid : loop_score_and_match)
+    if (score_fcid.first > min_score_to_retain && !already_added_kf.count(score_fcid.second)) {
+      loop_candidates.push_back(score_fcid.second);
+      already_added_kf.insert(score_fcid.second);
+    }
+  return loop_candidates;
+}
+
+// loop_closure_utils.h:269-276
+inline void insert_new_kf_to_db(const FrameCamId& new_kf_fcid, const Camera& new_kf, DBoWInvertedFile& recognition_database) {
+  for (const auto& wv : new_kf.bow_vector)
+    if (wv.first < recognition_database.size()) recognition_database[wv.first].push_back(new_kf_fcid);
+}
+
+// loop_closure_utils.h:294-388
+inline bool detect_loop_closure(const FrameCamId& new_kf_fcid, const Camera& new_kf, const Cameras& keyframes,
+                                DBoWInvertedFile& recognition_database, const ORBVocabularyAmd* voc, const CovisibilityGraph& graph,
+                                ConsistentGroups& consistent_groups, std::vector<FrameCamId>& enough_consistent_candidates, int threshold,
+                                int num_consistency_threshold) {
+  const double min_score = compute_min_connected_covisible(new_kf, keyframes, voc, threshold);
+  const std::vector<FrameCamId> loop_candidates =
+      detect_loop_candidates(new_kf_fcid, new_kf, keyframes, graph, min_score, recognition_database, voc);
+  if (std::getenv("VISNAV_AMD_TRACE")) {
+    std::fprintf(stderr, "loop detection keyframe %lld: min covisible score %.4f, %zu candidates:", (long long)new_kf_fcid.frame_id, min_score, loop_candidates.size());
+    for (const auto& c : loop_candidates) std::fprintf(stderr, " %lld", (long long)c.frame_id);
+    std::fprintf(stderr, " (groups %zu)\n", consistent_groups.size());
+  }
+  if (loop_candidates.empty()) {
+    consistent_groups.clear();
+    if (new_kf_fcid.cam_id == 0) insert_new_kf_to_db(new_kf_fcid, new_kf, recognition_database);
+    return false;
+  }
+  enough_consistent_candidates.clear();
+  ConsistentGroups current_consistent_groups;
+  std::vector<bool> is_old_groups_consistent(consistent_groups.size(), false);
+  for (const FrameCamId& candidate_fcid : loop_candidates) {
+    std::set<FrameCamId> candidate_group = graph.at(candidate_fcid);
+    candidate_group.insert(candidate_fcid);
+    bool enough_consistent = false, consistent_in_some_groups = false;
+    int idx = 0;
+    for (auto& g : consistent_groups) {
+      bool is_consistent = false;
+      for (const auto& f : candidate_group)
+        if (g.first.count(f)) {
+          is_consistent = true;
+          consistent_in_some_groups = true;
+          break;
+        }
+      if (is_consistent) {
+        const int num_curr_consistency = g.second + 1;
+        if (!is_old_groups_consistent[(size_t)idx]) {
+          current_consistent_groups.emplace_back(candidate_group, num_curr_consistency);
+          is_old_groups_consistent[(size_t)idx] = true;
+        }
+        if (num_curr_consistency >= num_consistency_threshold && !enough_consistent) {
+          enough_consistent_candidates.push_back(candidate_fcid);
+          enough_consistent = true;
+        }
+      }
+      idx++;
+    }
+    if (!consistent_in_some_groups) current_consistent_groups.emplace_back(candidate_group, 0);
+  }
+  consistent_groups = current_consistent_groups;
+  if (new_kf_fcid.cam_id == 0) insert_new_kf_to_db(new_kf_fcid, new_kf, recognition_database);
+  return !enough_consistent_candidates.empty();
+}
+
+// loop_closure_utils.h:398-416
+inline void loop_align(const FrameCamId& cur_kf_fcid, Camera cur_kf, const FrameCamId& loop_candidate_fcid, const Sophus::SE3d& T_0_1,
+                       const Sophus::SE3d& sim3, Cameras& keyframes, Landmarks& landmarks) {
+  (void)cur_kf_fcid;
+  (void)landmarks;
+  const amd::Rt cur = amd::rt_of(cur_kf.T_w_c);
+  // cur_kf.T_w_c * (cur_kf.T_w_c^-1 * T_w_candidate * sim3) = T_w_candidate * sim3
+  const amd::Rt aligned = amd::rt_mul(cur, amd::rt_mul(amd::rt_mul(amd::rt_inv(cur), amd::rt_of(keyframes.at(loop_candidate_fcid).T_w_c)), amd::rt_of(sim3)));
+  for (const auto& kv : cur_kf.covisible_rel_poses) {
+    keyframes.at(kv.first).T_w_c = amd::se3_of(amd::rt_mul(aligned, amd::rt_of(kv.second)));
+    keyframes.at(FrameCamId(kv.first.frame_id, 1)).T_w_c = amd::se3_of(amd::rt_mul(amd::rt_of(keyframes.at(kv.first).T_w_c), amd::rt_of(T_0_1)));
+  }
+}
+
+// loop_closure_utils.h:593-601
+inline void update_stereo_pair(const FrameCamId& cur_kf_fcid, Camera cur_kf, const Sophus::SE3d T_0_1, Cameras& keyframes) {
+  (void)cur_kf_fcid;
+  (void)cur_kf;
+  for (auto& kv : keyframes)
+    if (kv.first.cam_id == 1)
+      kv.second.T_w_c = amd::se3_of(amd::rt_mul(amd::rt_of(keyframes.at(FrameCamId(kv.first.frame_id, 0)).T_w_c), amd::rt_of(T_0_1)));
+}
+
+// loop_closure_utils.h:607-621
+inline void update_landmark_position(const FrameCamId& cur_kf_fcid, const Camera& cur_kf, const Cameras& keyframes, Landmarks& landmarks) {
+  for (auto& kv : landmarks) {
+    const Camera* from = nullptr;
+    auto it = keyframes.find(kv.second.from_fcid);
+    if (it != keyframes.end())
+      from = &it->second;
+    else if (cur_kf_fcid == kv.second.from_fcid)
+      from = &cur_kf;
+    if (!from) continue;
+    const amd::Rt T = amd::rt_of(from->T_w_c);
+    double o[3];
+    amd::qrot(T.q, kv.second.p_c.data(), o);
+    for (int i = 0; i < 3; i++) kv.second.p.data()[i] = o[i] + T.t[i];
+  }
+}
+
+// loop_closure_utils.h:633-648.  cur_kf is taken BY VALUE like the reference does: the optimised pose of the current
+// keyframe is dropped (with set_current_kf_fixed it does not move anyway) and the caller inserts its own copy afterwards.
+inline void loop_closure(const FrameCamId& cur_kf_fcid, Camera cur_kf, const FrameCamId& loop_candidate_fcid, const Sophus::SE3d T_0_1,
+                         const Sophus::SE3d& sim3, Cameras& keyframes, Landmarks& landmarks, int essential_threshold,
+                         const LoopClosureOptions& options) {
+  loop_align(cur_kf_fcid, cur_kf, loop_candidate_fcid, T_0_1, sim3, keyframes, landmarks);
+  pose_graph_optimization(cur_kf_fcid, cur_kf, loop_candidate_fcid, sim3, keyframes, essential_threshold, options);
+  update_stereo_pair(cur_kf_fcid, cur_kf, T_0_1, keyframes);
+  update_landmark_position(cur_kf_fcid, cur_kf, keyframes, landmarks);
 }
 
 }  // namespace visnav

@@ -21,6 +21,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include "dbow2_types.h"
+
 namespace Eigen {
 template <int N>
 struct VectorNd {
@@ -89,18 +91,25 @@ struct KeypointsData {
 using Corners = std::unordered_map<FrameCamId, KeypointsData, FrameCamIdHash>;  // tbb::concurrent_unordered_map upstream
 using FeatureTrack = std::map<FrameCamId, FeatureId>;
 
-// include/visnav/common_types.h:204-222 (graph / BoW members omitted: host bookkeeping outside the path)
+// include/visnav/common_types.h:202
+using DBoWInvertedFile = std::vector<std::vector<FrameCamId>>;
+// include/visnav/common_types.h:204-222
 struct Camera {
   Sophus::SE3d T_w_c;
   bool active = true;
   std::map<FrameCamId, int> covisible_weights;
   std::map<FrameCamId, Sophus::SE3d> covisible_rel_poses;
   FrameCamId last_fcid = FrameCamId(-1, 0);  // parent on the spanning tree; frame_id -1 = none (loop_closure_utils.h:522)
+  DBoW2::BowVector bow_vector;
+  DBoW2::FeatureVector feature_vector;
   std::map<TrackId, FeatureId> map_points;
   std::string img_path;
   bool modified = false;
 };
 using CovisibilityGraph = std::unordered_map<FrameCamId, std::set<FrameCamId>, FrameCamIdHash>;
+// include/visnav/common_types.h:225-226
+using ConsistentGroup = std::pair<std::set<FrameCamId>, int>;
+using ConsistentGroups = std::vector<ConsistentGroup>;
 // include/visnav/common_types.h:228-252
 struct Landmark {
   Eigen::Vector3d p;

@@ -83,3 +83,46 @@ def test_headless_pipeline_computes_bow_vectors_per_keyframe(sequence, tmp_path,
     b = _run(seq_dir, "--kf-min-inliers", "500", "--fused", "--voc-path", str(voc))
     assert b["bow_vectors"] == b["keyframes"] == a["keyframes"] and a["bow_vectors"] == 0
     assert b["ate_rmse_m"] == a["ate_rmse_m"]
+
+
+@pytest.fixture(scope="module")
+def loop_sequence(tmp_path_factory, vsl, synth):
+    # a full lap and a bit: 230 frames on a circle of 168 frames
+    import sys
+    d = tmp_path_factory.mktemp("loopseq")
+    code = ("import sys, importlib; sys.path.insert(0, %r); import __graft_entry__ as e; e.load_package(); "
+            "sq = importlib.import_module('visual_slam_amd.synth_sequence'); "
+            "sq.render_sequence(%r, n_frames=230, seed=1, step_m=0.045, radius=1.2, workers=12)" % (str(ROOT), str(d)))
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=600)   # a fresh process: forked render workers, no GPU
+    (d / "voc.txt").write_text(synth.vocabulary_text(3, 10, 4))
+    return d
+
+
+def test_relocalization_branch(loop_sequence):
+    # src/slam.cpp:1167-1191 with enable_relocalization: track_camera replaces localize_camera (same trajectory quality),
+    # and the relocalisation operator itself (tracking.h:241-419: BoW candidates through the inverted file, descriptor
+    # matching against the candidate and its covisible neighbours, PnP) recovers a frame from a pose prior 0.2 m off
+    d = loop_sequence
+    out = _run(d, "--frames", "120", "--kf-min-inliers", "400", "--voc-path", str(d / "voc.txt"), "--relocalization", "--reloc-check", "70")
+    assert out["ate_rmse_m"] < 0.015, out
+    assert out["reloc_check_ok"] == 1 and out["reloc_check_err_m"] < 0.03, out
+    assert out["bow_vectors"] == out["keyframes"]
+
+
+def test_loop_closing_stages_and_global_ba(loop_sequence):
+    # the stages behind loop detection (src/slam.cpp:1225-1258, :1287): compute_sim3 against an old keyframe, loop_align +
+    # pose_graph_optimization + landmark update, then global_bundle_adjustment.  A displaced pose estimate at frame 100
+    # stands in for drift (the second half of the lap is mapped 1.1 m off), `--force-loop` hands keyframe 0 to the
+    # loop-closing stage once the lap is complete (the box room is not distinctive enough for the BoW consistency test;
+    # detection is covered by tests/test_loop_closure_gpu.py).  The loop must close, the global BA must run, the
+    # trajectory error must drop, and the device-resident path must agree with the operator path.
+    d = loop_sequence
+    common = ["--kf-min-inliers", "400", "--voc-path", str(d / "voc.txt"), "--loop-closure", "--loop-time", "30",
+              "--inject-drift", "100:1.0,0,0.5"]
+    open_loop = _run(d, *common)
+    closed = _run(d, *common, "--force-loop", "170:0")
+    assert open_loop["loops_closed"] == 0 and open_loop["global_ba_runs"] == 0
+    assert closed["loops_closed"] == 1 and closed["global_ba_runs"] == 1
+    assert closed["ate_rmse_m"] < 0.85 * open_loop["ate_rmse_m"], (closed["ate_rmse_m"], open_loop["ate_rmse_m"])
+    fused = _run(d, *common, "--force-loop", "170:0", "--fused")
+    assert fused["ate_rmse_m"] == closed["ate_rmse_m"] and fused["keyframes"] == closed["keyframes"]

@@ -129,3 +129,30 @@ def test_loop_closure_dropins(tmp_path, orc, synth):
     assert seen == exp and len(exp) >= 3
     mp, ne, back = struct.unpack_from("iii", buf, off)
     assert mp == n_map_points and ne == len(exp) and back == len(exp)
+
+
+@pytest.mark.gpu
+def test_detect_loop_closure_on_a_constructed_revisit(tmp_path):
+    # the detection half of the loop-closure branch (loop_closure_utils.h:109-388 restated in
+    # include/visnav_amd/loop_closure.h) on place-specific BoW vectors: nothing fires on the first pass, the revisit of
+    # places 3..6 is consistent with itself and reaches num_consistency = 3 at its fourth keyframe with the matching
+    # old keyframe as the candidate, a new place clears the consistency groups
+    exe = tmp_path / "loop_detect_test"
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "tests/cpp/loop_detect_test.cpp"),
+           "-o", str(exe), "-L", str(ROOT / "visual-slam_amd"), "-lvslam_hip", "-Wl,-rpath," + str(ROOT / "visual-slam_amd")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rows = [list(map(int, ln.split())) for ln in r.stdout.splitlines() if ln and ln[0].isdigit()]
+    by_frame = {row[0]: row[1:] for row in rows}
+    for f in range(10):
+        assert by_frame[f][0] == 0 and by_frame[f][1] == 0, (f, by_frame[f])      # first pass: no loop
+    assert by_frame[20][:2] == [0, 0] and by_frame[20][3] == 1 and by_frame[20][4] == 0   # one group, consistency 0
+    assert by_frame[21][:2] == [0, 0] and by_frame[21][4] == 1
+    assert by_frame[22][:2] == [0, 0] and by_frame[22][4] == 2
+    assert by_frame[23][:3] == [1, 1, 6] and by_frame[23][4] == 3                  # loop: current keyframe 23 <-> old keyframe 6
+    # new place: no loop, groups cleared (the candidate list is left stale like in the reference: only read on `true`)
+    assert by_frame[24][0] == 0 and by_frame[24][3] == 0
+    db = [ln for ln in r.stdout.splitlines() if ln.startswith("db")][0].split()
+    assert int(db[2]) == sum(70 for _ in range(15))                                # 15 keyframes x 70 words in the inverted file

@@ -13,6 +13,8 @@
 #include <string>
 #include <thread>
 
+#include <algorithm>
+#include <cmath>
 #include <memory>
 
 #include "visnav_amd/harness/odometry.h"
@@ -25,6 +27,12 @@ int main(int argc, char** argv) {
   int max_frames = -1;
   bool lookahead = true;  // fused mode: detect of frame t+1 enqueued under the host work of frame t
   int replicas = 1;       // BASELINE configs[3] on one GPU: that many independent streams, one host thread each
+  std::string drop_spec;  // "a-b": frames a..b are replaced by a blank image (forces tracking loss -> relocalisation)
+  bool trace = false;      // one stderr line per frame (matches, inliers, tracking state)
+  int reloc_check = -1;    // >= 0: after the run, relocalise frame F from scratch (relocalize_camera with a displaced pose
+                           // prior) against the finished map and report how far the result is from the tracked pose
+  std::string drift_spec;  // "F:dx,dy,dz": before frame F the pose estimate is displaced by (dx, dy, dz) metres -- a test hook
+                           // that stands in for accumulated drift (the rendered room is too small to drift by itself)
   OdometryOptions opt;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -48,6 +56,20 @@ int main(int argc, char** argv) {
     else if (a == "--max-kfs") opt.max_num_kfs = std::atoi(need("--max-kfs").c_str());
     else if (a == "--num-features") opt.num_features_per_image = std::atoi(need("--num-features").c_str());
     else if (a == "--ba-verbose") opt.ba_verbose = 1;
+    else if (a == "--relocalization") opt.enable_relocalization = true;   // the reference's ui.relocalization (default on there)
+    else if (a == "--loop-closure") opt.enable_loop_closure = true;       // ui.loop_closure
+    else if (a == "--no-gba-after-loop") opt.enable_global_ba_after_loop_closure = false;
+    else if (a == "--loop-time") opt.loop_closing_time_threshold = std::atoi(need("--loop-time").c_str());
+    else if (a == "--num-consistency") opt.num_consistency = std::atoi(need("--num-consistency").c_str());
+    else if (a == "--motion-threshold") opt.motion_threshold = std::atof(need("--motion-threshold").c_str());
+    else if (a == "--drop-frames") drop_spec = need("--drop-frames");
+    else if (a == "--inject-drift") drift_spec = need("--inject-drift");
+    else if (a == "--trace") trace = true;
+    else if (a == "--reloc-check") reloc_check = std::atoi(need("--reloc-check").c_str());
+    else if (a == "--force-loop") {  // "F:C" test hook, see OdometryOptions::force_loop_from
+      const std::string v = need("--force-loop");
+      std::sscanf(v.c_str(), "%d:%d", &opt.force_loop_from, &opt.force_loop_candidate);
+    }
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());
       return 2;
@@ -82,6 +104,14 @@ int main(int argc, char** argv) {
     }
   }
   const double decode_s = std::chrono::duration<double>(Clk::now() - d0).count();
+  if (!drop_spec.empty()) {
+    int a = 0, b = -1;
+    if (std::sscanf(drop_spec.c_str(), "%d-%d", &a, &b) == 2)
+      for (int i = a; i <= b && i < n_frames; i++) {
+        std::fill(left[i].px.begin(), left[i].px.end(), (uint8_t)90);
+        std::fill(right[i].px.begin(), right[i].px.end(), (uint8_t)90);
+      }
+  }
 
   Odometry odo(calib, opt);
   ORBVocabularyAmd voc;
@@ -117,10 +147,30 @@ int main(int argc, char** argv) {
     }
     ready++;
     while (!go) std::this_thread::yield();
+    int drift_frame = -1;
+    double dd[4] = {0, 0, 0, 0};  // dx, dy, dz [m], yaw [deg] about the camera's y axis
+    if (!drift_spec.empty()) std::sscanf(drift_spec.c_str(), "%d:%lf,%lf,%lf,%lf", &drift_frame, &dd[0], &dd[1], &dd[2], &dd[3]);
     for (int i = 0; i < n_frames; i++) {
+      if (i == drift_frame) {
+        const double h = 0.5 * dd[3] * 3.14159265358979323846 / 180.0;
+        Sophus::SE3d yaw;  // identity
+        yaw.data()[1] = std::sin(h);
+        yaw.data()[3] = std::cos(h);
+        o.current_pose = se3_mul(o.current_pose, yaw);
+        o.last_pose = se3_mul(o.last_pose, yaw);
+        for (int c = 0; c < 3; c++) {
+          o.current_pose.data()[4 + c] += dd[c];
+          o.last_pose.data()[4 + c] += dd[c];
+        }
+        o.take_keyframe = true;
+      }
       const bool kf = o.take_keyframe;
       o.next_step(left[i], right[i], (lookahead && i + 1 < n_frames) ? &left[i + 1] : nullptr);
       if (kf_count) *kf_count += kf ? 1 : 0;
+      if (kf_count && trace)
+        std::fprintf(stderr, "frame %d kf %d matches %d inliers %d tracking %d lost %d reloc %d loops %d t = %.3f %.3f %.3f\n", i, (int)kf,
+                     o.last_matches, o.last_inliers, (int)o.tracking_successful, o.n_tracking_lost, o.n_relocalized, o.n_loops_closed,
+                     o.current_pose.data()[4], o.current_pose.data()[5], o.current_pose.data()[6]);
     }
     o.finish();
     o.release_device();  // the thread-local context dies with this thread
@@ -140,6 +190,35 @@ int main(int argc, char** argv) {
     replicas_agree = replicas_agree && o->frame_poses.size() == odo.frame_poses.size() &&
                      std::memcmp(o->frame_poses.back().data(), odo.frame_poses.back().data(), 7 * sizeof(double)) == 0;
 
+  // --reloc-check F: the relocalisation operator on its own (tracking.h:241-419): the frame's keypoints under a fresh
+  // id, a pose prior 0.2 m off, no motion model; success = BoW candidate found + PnP against the candidate's map points
+  int reloc_ok = -1;
+  double reloc_err_m = -1.0;
+  if (reloc_check >= 0 && reloc_check < n_frames && odo.orb_voc) {
+    std::thread t([&] {
+      const FrameCamId probe((FrameId)n_frames + 1000, 0);
+      KeypointsData kd;
+      ImageRef l(left[reloc_check]);
+      detectKeypointsAndDescriptors(l.img, kd, opt.num_features_per_image, opt.rotate_features);
+      odo.feature_corners[probe] = kd;
+      Sophus::SE3d prior = odo.frame_poses[(size_t)reloc_check];
+      prior.data()[4] += 0.2;
+      LandmarkMatchData md;
+      XorShift rng;
+      const bool ok = relocalize_camera(probe, l.img, odo.calib_cam, odo.graph, odo.orb_voc, odo.orb_db, odo.cameras, Sophus::SE3d(), prior,
+                                        odo.feature_corners, odo.landmarks, 1.0, opt.reprojection_error_pnp_inlier_threshold_pixel, md, rng);
+      reloc_ok = ok ? 1 : 0;
+      if (ok) {
+        double e = 0;
+        for (int c = 0; c < 3; c++) {
+          const double d = md.T_w_c.data()[4 + c] - odo.frame_poses[(size_t)reloc_check].data()[4 + c];
+          e += d * d;
+        }
+        reloc_err_m = std::sqrt(e);
+      }
+    });
+    t.join();
+  }
   int n_assoc = 0;
   const double ate = odo.ate(ds.timestamps, ds.gt_t_ns, ds.gt_t_w_i, &n_assoc);
   if (!traj_path.empty()) {
@@ -161,8 +240,10 @@ int main(int argc, char** argv) {
       "{\"frames\": %d, \"keyframes\": %d, \"streams\": %d, \"streams_agree\": %s, \"frames_per_s\": %.2f, \"ms_per_frame\": %.3f, \"image_decode_s\": %.3f, "
       "\"ate_rmse_m\": %.6f, \"ate_associations\": %d, \"landmarks\": %zu, \"active_landmarks\": %zu, \"async_ba\": %s, \"fused_tracking\": %s, "
       "\"stage_ms_total\": {\"detect\": %.1f, \"stereo_match\": %.1f, \"project_match\": %.1f, \"localize\": %.1f, \"map\": %.1f, "
-      "\"ba\": %.1f, \"bow\": %.1f}, \"ba_runs\": %d, \"bow_vectors\": %zu}\n",
+      "\"ba\": %.1f, \"bow\": %.1f, \"loop\": %.1f, \"global_ba\": %.1f}, \"ba_runs\": %d, \"bow_vectors\": %zu, "
+      "\"tracking_lost\": %d, \"relocalized\": %d, \"loops_closed\": %d, \"global_ba_runs\": %d, \"reloc_check_ok\": %d, \"reloc_check_err_m\": %.6f}\n",
       n_frames, n_kf, replicas, replicas_agree ? "true" : "false", replicas * n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
-      opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.bow_ms, c.ba_runs, odo.bow_vectors.size());
+      opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.bow_ms, odo.loop_ms, odo.gba_ms, c.ba_runs, odo.bow_vectors.size(),
+      odo.n_tracking_lost, odo.n_relocalized, odo.n_loops_closed, odo.n_global_ba, reloc_ok, reloc_err_m);
   return 0;
 }

@@ -209,10 +209,26 @@ def trajectory(n_frames, step_m=0.03, radius=1.2):
     return poses
 
 
+_RENDER = {}
+
+
+def _render_frame(k):
+    room, bear, T_i_c, poses, out_dir, stamps, png_level = (_RENDER[x] for x in ("room", "bear", "T_i_c", "poses", "out_dir", "stamps", "png_level"))
+    R_wi, t_wi = poses[k]
+    for c in range(2):
+        R_wc = R_wi @ T_i_c[c][0]
+        t_wc = R_wi @ T_i_c[c][1] + t_wi
+        img = room.render(bear[c], R_wc, t_wc)
+        write_png(os.path.join(out_dir, "cam%d" % c, "data", "%d.png" % stamps[k]), img, level=png_level)
+    return k
+
+
 def render_sequence(out_dir, n_frames=60, seed=1, t0_ns=1403715273262142976, dt_ns=50_000_000, png_level=1,
-                    step_m=0.03, radius=1.2):
+                    step_m=0.03, radius=1.2, workers=1):
     """Writes <out_dir>/{cam0,cam1}/data.csv + data/*.png, state_groundtruth_estimate0/data.csv and
-    <out_dir>/calib.json.  Returns the list of body poses (R_wi, t_wi)."""
+    <out_dir>/calib.json.  Returns the list of body poses (R_wi, t_wi).  The path is a circle: more than
+    2 pi radius / step_m frames revisit the start (loop closure).  workers > 1 renders frames in forked
+    processes (call before anything touches the GPU)."""
     room = BoxRoom(seed)
     poses = trajectory(n_frames, step_m=step_m, radius=radius)
     bear = [ds_unproject_grid(CALIB["intrinsics"][c]) for c in range(2)]
@@ -229,12 +245,14 @@ def render_sequence(out_dir, n_frames=60, seed=1, t0_ns=1403715273262142976, dt_
             f.write("#timestamp [ns],filename\r\n")
             for s in stamps:
                 f.write("%d,%d.png\r\n" % (s, s))
-    for k, (R_wi, t_wi) in enumerate(poses):
-        for c in range(2):
-            R_wc = R_wi @ T_i_c[c][0]
-            t_wc = R_wi @ T_i_c[c][1] + t_wi
-            img = room.render(bear[c], R_wc, t_wc)
-            write_png(os.path.join(out_dir, "cam%d" % c, "data", "%d.png" % stamps[k]), img, level=png_level)
+    _RENDER.update(room=room, bear=bear, T_i_c=T_i_c, poses=poses, out_dir=out_dir, stamps=stamps, png_level=png_level)
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_render_frame, range(n_frames), chunksize=4)
+    else:
+        for k in range(n_frames):
+            _render_frame(k)
     # ground truth at 4x the frame rate (positions interpolated on the same parametrisation), EuRoC columns
     fine = trajectory(4 * (n_frames - 1) + 1, step_m=step_m / 4, radius=radius)
     with open(os.path.join(out_dir, "state_groundtruth_estimate0", "data.csv"), "w", newline="") as f:
