@@ -220,7 +220,8 @@ int main(int argc, char** argv) {
     t.join();
   }
   int n_assoc = 0;
-  const double ate = odo.ate(ds.timestamps, ds.gt_t_ns, ds.gt_t_w_i, &n_assoc);
+  double ate = odo.ate(ds.timestamps, ds.gt_t_ns, ds.gt_t_w_i, &n_assoc);
+  if (!std::isfinite(ate)) ate = -1.0;  // a dataset without ground truth (nan is not JSON)
   if (!traj_path.empty()) {
     FILE* f = std::fopen(traj_path.c_str(), "w");
     if (f) {
