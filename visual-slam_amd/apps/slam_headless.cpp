@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
     else if (a == "--max-kfs") opt.max_num_kfs = std::atoi(need("--max-kfs").c_str());
     else if (a == "--num-features") opt.num_features_per_image = std::atoi(need("--num-features").c_str());
     else if (a == "--ba-verbose") opt.ba_verbose = 1;
+    else if (a == "--ba-iterations") opt.ba_max_iterations = std::atoi(need("--ba-iterations").c_str());
     else if (a == "--relocalization") opt.enable_relocalization = true;   // the reference's ui.relocalization (default on there)
     else if (a == "--loop-closure") opt.enable_loop_closure = true;       // ui.loop_closure
     else if (a == "--no-gba-after-loop") opt.enable_global_ba_after_loop_closure = false;
