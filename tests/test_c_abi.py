@@ -2,6 +2,8 @@
 calls -- there is no GPU here), the oracle library exports what its header declares, and the product
 never references the oracle."""
 import ctypes
+
+import numpy as np
 import re
 from pathlib import Path
 
@@ -73,3 +75,60 @@ def test_host_byte_order_helpers_match_reference_rule(vsl):
     back = np.zeros_like(d)
     lib.vsl_desc_bytes_to_bitset(b.ctypes.data_as(vsl.u8p), 1, back.ctypes.data_as(vsl.u64p))
     assert np.array_equal(back, d)
+
+
+@pytest.mark.gpu
+def test_three_host_threads_inside_the_library_concurrently(vsl, orc, synth):
+    # the reference enters this path from up to three threads at once: next_step on the main thread, bundle_adjustment
+    # on opt_thread (src/slam.cpp:1557), global_bundle_adjustment on global_ba_thread (:1780).  Three contexts, three
+    # threads (ctypes releases the GIL inside a call), results identical to the same calls made alone.
+    import threading
+    left, right = synth.stereo_pair(61)
+    d_local = synth.ba_problem(62, n_kf=6, n_lms=2500)
+    d_global = synth.ba_problem(63, n_kf=30, n_lms=4000, loop_radius=5.0)
+
+    def arrays(d):
+        return orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"], d["obs_cam"], d["obs_lm"], d["obs_uv"],
+                            d["cam_model"])
+
+    def frame_job(ctx):
+        xy, ang, d1 = ctx.detect_describe(left, 1500, True)
+        _, _, d2 = ctx.detect_describe(right, 1500, True)
+        return xy, d1, ctx.match_descriptors(d1, d2, 70, 1.2)
+
+    def local_job(ctx):
+        a = arrays(d_local)
+        s = ctx.bundle_adjust(a, max_iters=8)
+        return a.poses.copy(), s.iterations
+
+    def global_job(ctx):
+        a = arrays(d_global)
+        s = ctx.bundle_adjust(a, max_iters=4)
+        return s.iterations, s.final_cost
+
+    solo_ctx = vsl.Context(0)
+    exp_frame, exp_local, exp_global = frame_job(solo_ctx), local_job(solo_ctx), global_job(solo_ctx)
+    solo_ctx.close()
+    results, errors = {}, []
+
+    def worker(name, job, reps):
+        try:
+            ctx = vsl.Context(0)
+            out = None
+            for _ in range(reps):
+                out = job(ctx)
+            results[name] = out
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, e))
+
+    threads = [threading.Thread(target=worker, args=a) for a in (("frame", frame_job, 40), ("local", local_job, 12), ("global", global_job, 4))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert np.array_equal(results["frame"][0], exp_frame[0]) and np.array_equal(results["frame"][1], exp_frame[1])
+    assert np.array_equal(results["frame"][2], exp_frame[2])
+    assert np.array_equal(results["local"][0], exp_local[0]) and results["local"][1] == exp_local[1]   # small-system path: bit-reproducible
+    assert results["global"][0] == exp_global[0] and results["global"][1] == pytest.approx(exp_global[1], rel=1e-9)
