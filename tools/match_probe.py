@@ -22,9 +22,10 @@ fr.detect_describe(0, 2 * Bu, 1500, True)
 fr.resolve_ties()
 pairs = np.array([[2 * k, 2 * k + 1] for k in range(Bu)], np.int32)
 ref = None
-for var in [()] + [tuple(a.split("=")) for a in sys.argv[1:] if "=" in a] + [()]:
-    if var:
-        ctx.set_diagnostic(var[0], int(var[1]))
+knobs = [tuple(a.split("=")) for a in sys.argv[1:] if "=" in a]
+for var in [()] + ([tuple(knobs)] if knobs else []) + [()]:
+    for kv in var:
+        ctx.set_diagnostic(kv[0], int(kv[1]))
     for _ in range(30):
         fr.match(pairs, 70, 1.2)
     ctx.synchronize()
@@ -43,5 +44,5 @@ for var in [()] + [tuple(a.split("=")) for a in sys.argv[1:] if "=" in a] + [()]
     macs = sum(2 * int(nk[2 * k]) * int(nk[2 * k + 1]) * 256 for k in range(Bu))
     print("%-26s match %.4f ms per launch  %.0f TOP/s (%.3f of 5000)  same results %s  mean kp %.0f"
           % (var or "default", ms / n, 2 * macs / (ms / n * 1e-3) / 1e12, 2 * macs / (ms / n * 1e-3) / 1e12 / 5000, same, nk.mean()), flush=True)
-    if var:
-        ctx.set_diagnostic(var[0], 0)
+    for kv in var:
+        ctx.set_diagnostic(kv[0], 0)

@@ -1,15 +1,32 @@
 #!/bin/bash
-# Regenerates the measurements behind profiles/r01_*: run on the GPU box from the repo root
-# (gpurun -- 'bash tools/refresh_profiles.sh'), then `bash tools/install_profiles.sh` here (tools/README.md).
+# Regenerates the measurements behind profiles/<round>_*: run ON the GPU box from the repo root
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'
+# then `bash tools/install_profiles.sh <round>` here (tools/README.md).  Counters are collected in their own passes,
+# never together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -e
 R=$PWD
-mkdir -p gpurun_out/refresh
-python bench.py > gpurun_out/refresh/bench_line.json 2> gpurun_out/refresh/bench.err
+O=$R/gpurun_out/refresh
+rm -rf $O && mkdir -p $O
+python bench.py > $O/bench_line.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-# kernel durations: one stream of 128 stereo frames per launch (the isolated durations of the roofline), and the
-# default two-stream run
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/refresh/kt1 -- python3 $R/bench.py --batch 512 --streams 1 --cpu-frames 0 --no-ba --no-gba --no-e2e > $R/gpurun_out/refresh/kt1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/refresh/kt2 -- python3 $R/bench.py --cpu-frames 0 --no-ba --no-gba --no-e2e > $R/gpurun_out/refresh/kt2.log 2>&1
-# HBM traffic: separate counter passes, no tracing
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/refresh/pmc/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-ba --no-gba --no-e2e --profile-steps 1 --batch 512 --streams 1 > $R/gpurun_out/refresh/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/refresh/pmc/write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-ba --no-gba --no-e2e --profile-steps 1 --batch 512 --streams 1 > $R/gpurun_out/refresh/pmc_w.log 2>&1
+LITE="--cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0 --gen-workers 1"
+# (no forked generator workers under the profiler; the frames of the plain run above are cached under /tmp)
+python3 $R/bench.py --streams 1 --batch 512 --passes 1 --steps 1 --warmup 0 $LITE > /dev/null 2>&1   # fills the cache of the batch-512 runs
+# kernel durations: one stream (the isolated durations the roofline uses) and the default two-stream run
+echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 8 --steps 6 --warmup 2 $LITE > $O/kt1.log 2>&1
+echo kt2; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 $R/bench.py --passes 8 --steps 6 --warmup 2 $LITE > $O/kt2.log 2>&1
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, plus the calibration of both counters on known byte counts
+PMCARGS="--streams 1 --batch 512 --passes 1 --steps 3 --warmup 1 --profile-steps 1 $LITE"
+echo "bench.py $PMCARGS" > $O/pmc_command.txt
+echo pmc; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc/fetch -- python3 $R/bench.py $PMCARGS > $O/pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc/write -- python3 $R/bench.py $PMCARGS > $O/pmc_w.log 2>&1
+echo calib; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib/fetch -- $R/tools/probes/pmc_calib > $O/calib_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib/write -- $R/tools/probes/pmc_calib > $O/calib_w.log 2>&1
+# matcher: SQ counters of the FP4 kernel and of the int8 kernel (staggered and not)
+echo matcher; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU --output-format csv -d $O/mm1 -- python3 $R/tools/match_probe.py match_use_i8=1 > $O/mm1.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU --output-format csv -d $O/mm2 -- python3 $R/tools/match_probe_nostagger.py > $O/mm2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $O/mm3 -- python3 $R/tools/match_probe.py match_use_i8=1 > $O/mm3.log 2>&1
+# bundle adjustment: kernel durations of the local window and of the 1000-camera map
+echo ba; rocprofv3 --kernel-trace --stats --output-format csv -d $O/lba -- python3 $R/tools/local_ba_probe.py 7 > $O/lba.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gba -- python3 $R/tools/global_ba_bench.py --iters 8 --single-call > $O/gba.log 2>&1
+echo refresh done

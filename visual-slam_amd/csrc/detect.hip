@@ -171,16 +171,33 @@ template <bool STORE_RESPONSE>
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
                                                                float* __restrict__ response, int32_t* __restrict__ meta,
                                                                uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
-                                                               int first, int wlist_cap) {
+                                                               int first, int wlist_cap, int n_images, int tiles_x, int tiles_y) {
   __shared__ uint64_t list[4][K1_WLIST];  // wave-private lists: appended with a scalar counter, no atomics
   __shared__ int wave_n[4], g_base;
-  const int slot = first + blockIdx.z;
+  // XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and the 39 strips of a
+  // 752 x 480 image overlap in halo rows and share 128-byte lines between neighbouring column strips.  With the plain
+  // (x, y, image) grid every XCD fetched most of every image (FETCH_SIZE, calibrated: 3.75 x the image bytes per
+  // launch); here workgroup b works for XCD b % 8, which takes the images congruent to it modulo 8, all tiles of one
+  // image consecutively -- the same trick as the describe kernel.  Speed only: any placement computes the same.
+  const int tiles = tiles_x * tiles_y;
+  int img_i, tile;
+  if (n_images >= 8) {
+    const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3;
+    img_i = (sl / tiles) * 8 + xcd;
+    tile = sl - (sl / tiles) * tiles;
+  } else {
+    img_i = blockIdx.x / tiles;
+    tile = blockIdx.x - img_i * tiles;
+  }
+  if (img_i >= n_images) return;  // workgroup-uniform (the padded tail of the last group of eight)
+  const int bx = tile % tiles_x, by = tile / tiles_x;
+  const int slot = first + img_i;
   const ImgSrd img = __builtin_amdgcn_make_buffer_rsrc((void*)(images + (size_t)slot * w * h), 0, w * h, 0x00020000);
   float* __restrict__ resp = response + (size_t)slot * w * h;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping below stays scalar
-  const int xs = blockIdx.x * K1_COLS;
-  const int y0 = (blockIdx.y * 4 + wave) * K1_ROWS;
+  const int xs = bx * K1_COLS;
+  const int y0 = (by * 4 + wave) * K1_ROWS;
   int n_wave = 0;  // wave-uniform
   if (y0 < h) {
     const float s = (float)(1.0 / (4.0 * 3.0 * 255.0));
@@ -771,14 +788,15 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     if (f->detect_meta_dirty)
       hipLaunchKernelGGL(detect_init_kernel, dim3((f->max_images + 255) / 256), dim3(256), 0, ctx->stream, f->meta, 0, f->max_images);
     f->detect_meta_dirty = true;  // until the selection kernel (which resets the counters) is in the queue
-    const dim3 k1_grid((w + K1_COLS - 1) / K1_COLS, (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS), n);
+    const int tiles_x = (w + K1_COLS - 1) / K1_COLS, tiles_y = (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS);
+    const dim3 k1_grid((unsigned)(tiles_x * tiles_y) * (unsigned)(n >= 8 ? 8 * ((n + 7) / 8) : n));
     const int wcap = min(max(ctx->k1_list_cap, 0), K1_WLIST);
     if (f->store_response)
       hipLaunchKernelGGL(min_eig_response_kernel<true>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
-                         f->cand, f->cand_cap, w, h, first, wcap);
+                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
     else
       hipLaunchKernelGGL(min_eig_response_kernel<false>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
-                         f->cand, f->cand_cap, w, h, first, wcap);
+                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
     VSL_CHECK_LAUNCH(ctx);
   }
   {
