@@ -1,20 +1,19 @@
 #!/bin/bash
 # Regenerates the measurements behind profiles/<round>_*: run ON the GPU box from the repo root
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'
-# then `bash tools/install_profiles.sh <round>` here (tools/README.md).  Counters are collected in their own passes,
-# never together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC slots).
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
+# then `bash tools/install_profiles.sh r02` here (tools/README.md).  Counters are collected in their own passes,
+# never together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC slots).  The HBM-traffic passes come first and their
+# summary is written into the box's profiles/ before the plain bench run, so the committed bench line carries the
+# roofline.traffic of the SAME build.
 set -e
 R=$PWD
+ROUND=${1:-r02}
 O=$R/gpurun_out/refresh
 rm -rf $O && mkdir -p $O
-python bench.py > $O/bench_line.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 LITE="--cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0 --gen-workers 1"
-# (no forked generator workers under the profiler; the frames of the plain run above are cached under /tmp)
-python3 $R/bench.py --streams 1 --batch 512 --passes 1 --steps 1 --warmup 0 $LITE > /dev/null 2>&1   # fills the cache of the batch-512 runs
-# kernel durations: one stream (the isolated durations the roofline uses) and the default two-stream run
-echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 8 --steps 6 --warmup 2 $LITE > $O/kt1.log 2>&1
-echo kt2; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 $R/bench.py --passes 8 --steps 6 --warmup 2 $LITE > $O/kt2.log 2>&1
+# (no forked generator workers under the profiler: the frames are generated once here and cached under /tmp)
+python3 $R/bench.py --streams 1 --batch 512 --passes 1 --steps 1 --warmup 0 --cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0 > /dev/null 2>&1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, plus the calibration of both counters on known byte counts
 PMCARGS="--streams 1 --batch 512 --passes 1 --steps 3 --warmup 1 --profile-steps 1 $LITE"
 echo "bench.py $PMCARGS" > $O/pmc_command.txt
@@ -22,6 +21,11 @@ echo pmc; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc/fetch -- pyth
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc/write -- python3 $R/bench.py $PMCARGS > $O/pmc_w.log 2>&1
 echo calib; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib/fetch -- $R/tools/probes/pmc_calib > $O/calib_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib/write -- $R/tools/probes/pmc_calib > $O/calib_w.log 2>&1
+python3 $R/tools/pmc_summary.py $O $R/profiles/${ROUND}_pmc_traffic.json 512 > $O/pmc_summary.log 2>&1
+echo bench; (cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench.err)
+# kernel durations: one stream (the isolated durations the roofline uses) and the default two-stream run
+echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 8 --steps 6 --warmup 2 $LITE > $O/kt1.log 2>&1
+echo kt2; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 $R/bench.py --passes 8 --steps 6 --warmup 2 $LITE > $O/kt2.log 2>&1
 # matcher: SQ counters of the FP4 kernel and of the int8 kernel (staggered and not)
 echo matcher; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU --output-format csv -d $O/mm1 -- python3 $R/tools/match_probe.py match_use_i8=1 > $O/mm1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU --output-format csv -d $O/mm2 -- python3 $R/tools/match_probe_nostagger.py > $O/mm2.log 2>&1
