@@ -228,6 +228,7 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
                                                                       double* __restrict__ dinvg, int* __restrict__ ok) {
   __shared__ double W[CH_NB + CBF_MAXBW + 1][CH_NB + 1];  // window rows x 32 panel columns (row stride 33: conflict-free)
   __shared__ double red[CBF_THREADS / 32][CH_NB + 1];
+  __shared__ double dinv_s[CH_NB];  // 1 / pivot of the panel's columns (a global store inside a sub-step would make its barrier wait for the round trip)
   __shared__ int fail_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
   if (tid == 0) fail_s = 0;
@@ -300,26 +301,31 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
       }
       if (tid == 0) {
 #pragma unroll
-        for (int c = 0; c < CBF_SUB; c++)
-          if (k + j0 + c < n) dinvg[k + j0 + c] = inv[c];
+        for (int c = 0; c < CBF_SUB; c++) dinv_s[j0 + c] = inv[c];
       }
       __syncthreads();
       CBF_STAMP(6)
-      // the remaining panel columns of this row lose x . (row cc of the factor): W[cc][j0 .. j0 + 7], cc > j0 + 7
-      if (act && tid >= j0 + CBF_SUB) {
-        // four columns at a time (independent chains, LDS reads batched); a diagonal-block row stops at its diagonal
-        const int c_end = tid < CH_NB ? tid + 1 : CH_NB;
-        for (int cc = j0 + CBF_SUB; cc < c_end; cc += 4) {
-          double t[4];
+      // the remaining panel columns lose X . L_d^T: W[r][cc] -= sum_q W[r][j0 + q] W[cc][j0 + q] for rows r >= j0 + 8 and
+      // columns cc in [j0 + 8, 32) -- a rank-8 update in 16 x 16 tiles on the matrix unit (two v_mfma_f64_16x16x4_f64 per
+      // tile; as one row per thread with broadcast LDS reads of the factor rows this phase was LDS-bound: 17k of the
+      // 87k cycles of a panel step).  Entries above the diagonal of the diagonal block receive garbage; nothing reads them.
+      if (j0 + CBF_SUB < CH_NB) {
+        const int r_first = (j0 + CBF_SUB) & ~15, c_first = j0 + CBF_SUB < 16 ? 0 : 16;
+        const int n_rt = (rows - r_first + 15) >> 4, n_ct = (CH_NB - c_first) >> 4;
+        const int kq = lane >> 4, l16 = lane & 15;
+        for (int t = wave; t < n_rt * n_ct; t += CBF_THREADS / 64) {
+          const int rt = t / n_ct, ct = t - rt * n_ct;
+          const int R0 = r_first + 16 * rt, C0 = c_first + 16 * ct;
+          const int ra = min(R0 + l16, rows - 1), rb = C0 + l16;
+          v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][j0 + kq], W[rb][j0 + kq], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][j0 + 4 + kq], W[rb][j0 + 4 + kq], acc, 0, 0, 0);
+          const int cc = C0 + l16;
 #pragma unroll
-          for (int u = 0; u < 4; u++) t[u] = W[tid][min(cc + u, CH_NB - 1)];
-#pragma unroll
-          for (int q = 0; q < CBF_SUB; q++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) t[u] -= x[q] * W[min(cc + u, CH_NB - 1)][j0 + q];
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (cc + u < c_end) W[tid][cc + u] = t[u];
+          for (int q = 0; q < 4; q++) {
+            const int r = R0 + kq + 4 * q;
+            if (r < rows && r >= j0 + CBF_SUB && cc >= j0 + CBF_SUB) W[r][cc] -= acc[q];
+          }
         }
       }
       CBF_STAMP(7)
@@ -339,7 +345,10 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
         A[(size_t)(k + nb + row - CH_NB) * ld + k + c] = W[row][c];
       }
     }
-    if (tid < nb) y[k + tid] = W[rows - 1][tid];
+    if (tid < nb) {
+      y[k + tid] = W[rows - 1][tid];
+      dinvg[k + tid] = dinv_s[tid];
+    }
     if (tid < m) {
       double dot = 0.0;
 #pragma unroll
