@@ -377,6 +377,13 @@ int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl
 /* Plain synchronous copy on the context's device (kind 0 host->device, 1 device->host, 2 device->device): for
  * callers that hold device pointers handed out by this library (all-reduce callbacks). */
 int vsl_ctx_memcpy(vsl_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+/* The solver behind the reduced camera system, on its own (the place Ceres' SPARSE_SCHUR hands S to a Cholesky,
+ * include/visnav/map_utils.h:406-411, loop_closure_utils.h:735): solves S x = b for a symmetric positive definite S
+ * given as a HOST row-major n x n array of which only the lower triangle is read.  half_bandwidth < 0: dense
+ * factorisation; otherwise S is taken to be zero for |i - j| > half_bandwidth and is factorised in band storage
+ * (single-launch kernel for half_bandwidth <= 512 unless the "chol_no_fused" diagnostic is set).  x (host, n doubles)
+ * receives the solution.  VSL_ERR_NUMERIC if S is not positive definite. */
+int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int n, int half_bandwidth, double* x);
 
 /* ------------------------------------------------------------ pose graph optimisation */
 /*

@@ -1,0 +1,93 @@
+"""The solver of the reduced camera system on its own (visual-slam_amd/csrc/chol.hip through vsl_spd_solve): the place
+where Ceres hands S to a sparse Cholesky (include/visnav/map_utils.h:406-411, loop_closure_utils.h:735).  Checked by
+the property the caller relies on -- S x = b to a relative residual of 1e-10 -- against numpy on small systems, and
+at the size of BASELINE configs[4] (5988 unknowns, half bandwidth 221) where a dense reference would take minutes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _band_spd(n, bw, seed):
+    """Random symmetric band matrix made positive definite by diagonal dominance; dense row-major."""
+    rng = np.random.default_rng(seed)
+    S = np.zeros((n, n))
+    for d in range(1, min(bw, n - 1) + 1):
+        v = rng.standard_normal(n - d)
+        S[np.arange(d, n), np.arange(0, n - d)] = v
+    S = S + S.T
+    S[np.arange(n), np.arange(n)] = np.abs(S).sum(1) + rng.uniform(0.5, 1.5, n)
+    return S
+
+
+def _residual(S, x, b):
+    return np.linalg.norm(S @ x - b) / np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 64, 200, 777])
+def test_dense_solve_small(ctx, n):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n + 3))
+    S = A @ A.T + 0.5 * np.eye(n)
+    b = rng.standard_normal(n)
+    x = ctx.spd_solve(S, b)
+    assert _residual(S, x, b) < 1e-10
+    assert np.allclose(x, np.linalg.solve(S, b), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,bw", [(40, 3), (100, 31), (100, 32), (333, 50), (600, 221), (1000, 512), (1000, 513), (700, 640)])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_band_solve_matches_dense_and_numpy(ctx, n, bw, fused):
+    # half bandwidths around the 32-column panel width, at the limit of the single-launch kernel (512) and beyond it;
+    # both band code paths (single launch / one launch per panel step) and the dense path agree
+    S = _band_spd(n, bw, 7 * n + bw)
+    b = np.random.default_rng(n + bw).standard_normal(n)
+    ctx.set_diagnostic("chol_no_fused", 0 if fused else 1)
+    try:
+        x = ctx.spd_solve(S, b, bw)
+    finally:
+        ctx.set_diagnostic("chol_no_fused", 0)
+    assert _residual(S, x, b) < 1e-10
+    xd = ctx.spd_solve(S, b)
+    assert np.allclose(x, xd, rtol=1e-9, atol=1e-12)
+    assert np.allclose(x, np.linalg.solve(S, b), rtol=1e-8, atol=1e-11)
+
+
+def test_band_solve_at_global_ba_size(ctx):
+    # BASELINE configs[4]: 998 free cameras -> 5988 unknowns, half bandwidth 221 after the reverse Cuthill-McKee
+    # renumbering; ||S x - b|| / ||b|| <= 1e-10, and a wider declared band gives the same x
+    n, bw = 5988, 221
+    S = _band_spd(n, bw, 11)
+    b = np.random.default_rng(12).standard_normal(n)
+    x = ctx.spd_solve(S, b, bw)
+    assert _residual(S, x, b) < 1e-10
+    x2 = ctx.spd_solve(S, b, 300)
+    assert np.allclose(x, x2, rtol=1e-9, atol=1e-13)
+
+
+def test_badly_scaled_band_system(ctx):
+    # a reduced camera system mixes rotation and translation blocks of very different scale: rows / columns of a
+    # well-conditioned band matrix scaled over six decades (condition number ~1e12).  Cholesky is scale-invariant, so
+    # the componentwise backward error stays at rounding level and the scaled solution agrees with the unscaled one
+    n, bw = 900, 60
+    rng = np.random.default_rng(5)
+    S0 = _band_spd(n, bw, 21)
+    d = 10.0 ** rng.uniform(-3, 3, n)
+    S = S0 * d[:, None] * d[None, :]
+    b0 = rng.standard_normal(n)
+    b = b0 * d
+    x = ctx.spd_solve(S, b, bw)
+    back = np.abs(S @ x - b) / (np.abs(S) @ np.abs(x) + np.abs(b))
+    assert back.max() < 1e-12
+    x0 = ctx.spd_solve(S0, b0, bw)
+    assert np.allclose(x * d, x0, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("bw", [-1, 40])
+def test_not_positive_definite_is_reported(ctx, vsl, bw):
+    n = 300
+    S = _band_spd(n, 40, 3)
+    S[150, 150] = -1.0
+    with pytest.raises(vsl.VslError) as e:
+        ctx.spd_solve(S, np.ones(n), bw)
+    assert e.value.code == -7  # VSL_ERR_NUMERIC

@@ -10,6 +10,7 @@ order, same f64 bit patterns -- on the same operation streams:
 """
 import importlib.util
 import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -92,3 +93,37 @@ def test_transform_tail_is_the_pinned_container_code(orc, synth, tmp_path):
     rn, rf = orc.ref_featvec_stream(np.array(nodes, np.uint32), np.array(feats, np.uint32))
     assert np.array_equal(ids, ri) and _same_f64(vals, rv)
     assert np.array_equal(fn, rn) and np.array_equal(ff, rf)
+
+
+def _pattern_from_inc(path):
+    import re
+    s = Path(path).read_text()
+    s = s[s.index("*/") + 2:]
+    return np.array([int(x) for x in re.findall(r"-?\d+", s)], np.int8).reshape(-1, 4)
+
+
+# sha256 of the 256 x 4 int8 table {xa, ya, xb, yb} parsed from the reference's include/visnav/keypoints.h:55-131
+REF_PATTERN_SHA256 = "2164181aea6ff9ac426ca512d5130d15e1f6e3cd47b1cbdd568bbe1e55d49023"
+
+
+def test_rbrief_pattern_tables_equal_the_reference_table():
+    """The 256 rBRIEF test pairs of the oracle and of the HIP kernels are the reference's numbers (keypoints.h:55-131):
+    against the checksum recorded from the reference's text, and -- where /root/reference exists -- against that text."""
+    import hashlib
+    import re
+    root = Path(__file__).resolve().parents[1]
+    tabs = [_pattern_from_inc(root / "oracle" / "rbrief_pattern.inc"),
+            _pattern_from_inc(root / "visual-slam_amd" / "csrc" / "rbrief_pattern.inc")]
+    for t in tabs:
+        assert t.shape == (256, 4)
+        assert hashlib.sha256(t.tobytes()).hexdigest() == REF_PATTERN_SHA256
+    ref = Path("/root/reference/include/visnav/keypoints.h")
+    if ref.exists():
+        text = ref.read_text()
+        cols = []
+        for name in ("pattern_31_x_a", "pattern_31_y_a", "pattern_31_x_b", "pattern_31_y_b"):
+            m = re.search(r"char\s+%s\[256\]\s*=\s*\{([^}]*)\}" % name, text)
+            cols.append(np.array([int(x) for x in m.group(1).split(",") if x.strip()], np.int8))
+        live = np.stack(cols, 1)
+        assert hashlib.sha256(live.tobytes()).hexdigest() == REF_PATTERN_SHA256
+        assert (tabs[0] == live).all()

@@ -161,6 +161,17 @@ class Context:
     def set_diagnostic(self, name, value):
         self._ck(self.L.vsl_ctx_set_diagnostic(self.h, name.encode(), C.c_int(int(value))))
 
+    def spd_solve(self, S, b, half_bandwidth=-1):
+        """Solves S x = b with the reduced-camera-system solver (dense, or band storage when half_bandwidth >= 0)."""
+        S = np.ascontiguousarray(S, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        n = len(b)
+        assert S.shape == (n, n)
+        x = np.zeros(n, np.float64)
+        self._ck(self.L.vsl_spd_solve(self.h, S.ctypes.data_as(f64p), b.ctypes.data_as(f64p), n, int(half_bandwidth),
+                                      x.ctypes.data_as(f64p)))
+        return x
+
     # ---- keypoints.h drop-ins (host buffers)
     def detect_describe(self, img, num_features=1500, rotate=True):
         img, p, w, h, pitch = _img(img)

@@ -24,6 +24,7 @@
 // (no atomics).  Written here rather than calling rocSOLVER: librocsolver.so is a 0.9 GB load that
 // takes minutes to page in on a fresh machine.
 #include <algorithm>
+#include <vector>
 
 #include "vsl_common.h"
 
@@ -523,4 +524,46 @@ int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, i
 
 int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev) {
   return vsl_chol_solve_band_dev(ctx, S, b, n, n, n, ok_dev);
+}
+
+// Test / diagnostic entry point: the solver on a caller-provided system (include/vslam_hip.h).
+extern "C" int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int n, int half_bandwidth, double* x) {
+  if (!ctx || !S || !b || !x || n <= 0) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_spd_solve: bad argument");
+  const bool band = half_bandwidth >= 0 && half_bandwidth < n - 1;
+  const int bw = band ? half_bandwidth : n, bws = bw + CH_NB;
+  const size_t elems = band ? (size_t)n * (bws + 1) + 64 : (size_t)n * n;
+  double *dS = nullptr, *db = nullptr;
+  int* dok = nullptr;
+  VSL_HIP(ctx, hipMalloc((void**)&dS, sizeof(double) * elems));
+  int rc = VSL_OK, ok = 0;
+  hipError_t e = hipMalloc((void**)&db, sizeof(double) * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&dok, sizeof(int));
+  if (e == hipSuccess) {
+    if (band) {
+      // row i keeps columns [i - bws, i] at storage[i * (bws + 1) ...]; entries beyond the half bandwidth stay zero
+      std::vector<double> st(elems, 0.0);
+      for (int i = 0; i < n; i++)
+        for (int c = std::max(0, i - bw); c <= i; c++) st[(size_t)i * (bws + 1) + (c - i + bws)] = S[(size_t)i * n + c];
+      e = hipMemcpyAsync(dS, st.data(), sizeof(double) * elems, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    } else {
+      e = hipMemcpyAsync(dS, S, sizeof(double) * elems, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(db, b, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      rc = band ? vsl_chol_solve_band_dev(ctx, dS + bws, db, n, bws, bw, dok) : vsl_chol_solve_band_dev(ctx, dS, db, n, n, n, dok);
+      if (rc == VSL_OK) {
+        e = hipMemcpyAsync(&ok, dok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(x, db, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      }
+    }
+  }
+  hipFree(dS);
+  hipFree(db);
+  hipFree(dok);
+  if (e != hipSuccess) return vsl_fail(ctx, VSL_ERR_HIP, "vsl_spd_solve: %s", hipGetErrorString(e));
+  if (rc != VSL_OK) return rc;
+  if (!ok) return vsl_fail(ctx, VSL_ERR_NUMERIC, "vsl_spd_solve: matrix is not positive definite");
+  return VSL_OK;
 }
