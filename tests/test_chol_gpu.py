@@ -53,6 +53,36 @@ def test_band_solve_matches_dense_and_numpy(ctx, n, bw, fused):
     assert np.allclose(x, np.linalg.solve(S, b), rtol=1e-8, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,bw", [(700, 20), (701, 20), (2000, 100), (2017, 100), (3000, 37), (1500, 150), (4200, 481)])
+def test_two_ended_elimination_matches_one_ended(ctx, n, bw):
+    # long narrow bands (n >= 8 (bw + 32)) are eliminated from both ends towards a separator in the middle; sizes with
+    # whole and ragged panel counts on either side, separators of bw .. bw + 31 unknowns, up to the widest band the
+    # split is used for (bw + 31 <= 512)
+    assert n >= 8 * (bw + 32)
+    S = _band_spd(n, bw, 3 * n + bw)
+    b = np.random.default_rng(n - bw).standard_normal(n)
+    x2 = ctx.spd_solve(S, b, bw)
+    ctx.set_diagnostic("chol_one_ended", 1)
+    try:
+        x1 = ctx.spd_solve(S, b, bw)
+    finally:
+        ctx.set_diagnostic("chol_one_ended", 0)
+    assert _residual(S, x2, b) < 1e-10 and _residual(S, x1, b) < 1e-10
+    assert np.allclose(x2, x1, rtol=1e-9, atol=1e-12)
+    assert np.allclose(x2, np.linalg.solve(S, b), rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("where", [40, 1003, 1990])
+def test_two_ended_elimination_reports_a_bad_pivot_anywhere(ctx, vsl, where):
+    # a negative diagonal entry in the top chunk, in the separator, in the bottom chunk
+    n, bw = 2000, 60
+    S = _band_spd(n, bw, 9)
+    S[where, where] = -1.0
+    with pytest.raises(vsl.VslError) as e:
+        ctx.spd_solve(S, np.ones(n), bw)
+    assert e.value.code == -7
+
+
 def test_band_solve_at_global_ba_size(ctx):
     # BASELINE configs[4]: 998 free cameras -> 5988 unknowns, half bandwidth 221 after the reverse Cuthill-McKee
     # renumbering; ||S x - b|| / ||b|| <= 1e-10, and a wider declared band gives the same x

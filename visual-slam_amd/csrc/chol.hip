@@ -219,45 +219,155 @@ __global__ __launch_bounds__(256) void chol_bwd_kernel(const double* __restrict_
 //   * the m x m window update in 16 x 16 tiles of v_mfma_f64_16x16x4_f64 (faster here than register tiles on the
 //     vector ALU, see the loop); rows of the band are written back coalesced;
 // nothing to synchronise between workgroups, no flags, no spinning.
+//
+// TWO-ENDED FORM.  The 188 panel steps of a 1000-camera system are a dependent chain on one compute unit; a band
+// matrix can be eliminated from both ends at once without any waiting between the two workgroups: workgroup 0 takes
+// the unknowns [0, s) top-down, workgroup 1 the unknowns [N - s', N) bottom-up -- the same algorithm on the
+// index-reversed view i' = N - 1 - i of the same storage (entry (i', j') of the view is A[N-1-j'][N-1-i']: a reversed
+// panel is 32 storage rows x contiguous columns, so its accesses coalesce along the window-row direction instead of
+// along the panel) -- and both stop at a separator of bw .. bw + 31 unknowns in the middle.  Unknowns on the two sides
+// of it are more than bw apart, hence not coupled: the separator block receives the sum of the two Schur updates (the
+// top one in place, the bottom one in a scratch block), is factored last by the single-ended kernel, and the two
+// backward substitutions run outwards from it, again one workgroup each.  Half the chain, three more small launches.
+// Cutting the band into more pieces does not pay at N / bw ~ 27: an interior piece has to carry its upper separator as
+// bw extra rows through every step (3 x the update work) and the separator system has twice the bandwidth.
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 #define CBF_THREADS 576  // 9 wavefronts: one thread per window row (32 + 512 + the right-hand side)
 #define CBF_MAXBW 512
 #define CBF_SUB 8
 #define CBF_TCH 6  // window tiles per wavefront whose old values are in flight together
-__global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __restrict__ A, int ld, int n, int bw,
-                                                                      double* __restrict__ b, double* __restrict__ y,
-                                                                      double* __restrict__ dinvg, int* __restrict__ ok) {
-  __shared__ double W[CH_NB + CBF_MAXBW + 1][CH_NB + 1];  // window rows x 32 panel columns (row stride 33: conflict-free)
-  __shared__ double red[CBF_THREADS / 32][CH_NB + 1];
-  __shared__ double dinv_s[CH_NB];  // 1 / pivot of the panel's columns (a global store inside a sub-step would make its barrier wait for the round trip)
-  __shared__ int fail_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
-  if (tid == 0) fail_s = 0;
-  __syncthreads();
+
+struct CbfView {
+  double* A;       // band storage of the FULL system, pre-offset: A[i * ld + c], c <= i
+  int ld;
+  int N;           // unknowns of the full system (index reversal i -> N - 1 - i)
+  int n;           // unknowns of this view: the chunk it eliminates followed by the separator
+  int bw;
+  int sep0, sepn;  // reversed view, factor phase: view rows [sep0, sep0 + sepn) are the separator -- their mutual entries
+  double* M3;      //   accumulate in M3[(i - sep0) * sepn + (j - sep0)] and their right-hand side in b3[i - sep0]
+  double* b3;      //   (sepn = 0: everything lives in A / b)
+  double* b;       // right-hand side / solution of the full system
+  double* y;       // per view: intermediate vector and 1 / pivot, by view index
+  double* dinv;
+};
+
+// SEP (compile time): the step's window reaches the separator rows of a reversed view, whose mutual entries and
+// right-hand side live in the scratch block; every other step addresses the band storage only
+template <bool REV, bool SEP>
+__device__ __forceinline__ double* cbf_at(const CbfView& v, int i, int j) {  // entry (i, j) of the view, j <= i
+  if (!REV) return v.A + (size_t)i * v.ld + j;
+  if (SEP && j >= v.sep0) return v.M3 + (size_t)(i - v.sep0) * v.sepn + (j - v.sep0);
+  return v.A + (size_t)(v.N - 1 - j) * v.ld + (v.N - 1 - i);
+}
+template <bool REV, bool SEP>
+__device__ __forceinline__ double* cbf_rhs(const CbfView& v, int i) {
+  if (!REV) return v.b + i;
+  if (SEP && i >= v.sep0) return v.b3 + (i - v.sep0);
+  return v.b + (v.N - 1 - i);
+}
+
+struct CbfShared {
+  double W[CH_NB + CBF_MAXBW + 1][CH_NB + 1];  // window rows x 32 panel columns (row stride 33: conflict-free)
+  double red[CBF_THREADS / 32][CH_NB + 1];
+  double xw[CBF_MAXBW];   // backward substitution: the solution entries the panel reaches
+  double dinv_s[CH_NB];   // 1 / pivot of the panel's columns (a global store inside a sub-step would make its barrier wait for the round trip)
+  int fail_s;
+};
+
+// Visits this thread's elements of a rows x 32 block EIGHT at a time -- fn(row[8], c[8], ok[8]) -- in an order whose
+// fastest index is contiguous in memory: the panel column in the plain view (idx -> (idx >> 5, idx & 31)), the window
+// row in the reversed one (wave w takes columns w, w + 9, ...; its lanes 64 consecutive rows).  Eight independent
+// accesses per call: as a one-element loop the staging was 14 dependent global round trips per thread.
+template <bool REV, typename F>
+__device__ __forceinline__ void cbf_visit(int rows, F&& fn) {
+  const int tid = threadIdx.x;
+  int row[8], c[8];
+  bool ok[8];
+  if (!REV) {
+    const int total = rows * CH_NB;
+    for (int i0 = tid; i0 < total; i0 += 8 * CBF_THREADS) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int idx = i0 + u * CBF_THREADS;
+        ok[u] = idx < total;
+        row[u] = idx >> 5;
+        c[u] = idx & 31;
+      }
+      fn(row, c, ok);
+    }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6, RI = (rows + 63) >> 6;
+    for (int cc = 0; cc < 4; cc += 2)
+      for (int rr0 = 0; rr0 < RI; rr0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          c[u] = wave + (CBF_THREADS / 64) * (cc + (u >> 2));
+          row[u] = lane + 64 * (rr0 + (u & 3));
+          ok[u] = c[u] < CH_NB && row[u] < rows;
+        }
+        fn(row, c, ok);
+      }
+  }
+}
+
+// W <- the panel of step k: diagonal block (lower triangle; completed with the identity when UNIT), the m rows below it
+// and, when with_rhs, the right-hand side entries of the panel columns as one more row
+template <bool REV, bool SEP, bool UNIT>
+__device__ __forceinline__ void cbf_stage(const CbfView& v, double (*W)[CH_NB + 1], int k, int nb, int m, bool with_rhs) {
+  const int rows = CH_NB + m + (with_rhs ? 1 : 0);
+  cbf_visit<REV>(rows, [&](const int* row, const int* c, const bool* ok) {
+    const double* ptr[8];
+    double val[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      ptr[u] = nullptr;
+      val[u] = 0.0;
+      if (ok[u]) {
+        const int r = row[u], cc = c[u];
+        if (r < CH_NB) {
+          if (r < nb && cc <= r)
+            ptr[u] = cbf_at<REV, SEP>(v, k + r, k + cc);
+          else if (UNIT && r == cc)
+            val[u] = 1.0;
+        } else if (r < CH_NB + m) {
+          if (cc < nb) ptr[u] = cbf_at<REV, SEP>(v, k + nb + r - CH_NB, k + cc);
+        } else if (cc < nb) {
+          ptr[u] = cbf_rhs<REV, SEP>(v, k + cc);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (ptr[u]) val[u] = *ptr[u];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (ok[u]) W[row[u]][c[u]] = val[u];
+  });
+}
+
 #ifdef CBF_TIMING
-  long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
 #define CBF_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); tph[q] += t2 - tt; tt = t2; }
+#define CBF_TARGS , long long* tph, long long& tt
+#define CBF_TPASS , tph, tt
 #else
 #define CBF_STAMP(q)
+#define CBF_TARGS
+#define CBF_TPASS
 #endif
-  for (int k = 0; k < n; k += CH_NB) {
+
+// One panel step of the view: factorisation of columns [k, k + 32), forward substitution, window update.
+// Returns false (workgroup-uniform) if a pivot is not positive.
+template <bool REV, bool SEP>
+__device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
+  double(*W)[CH_NB + 1] = sh.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = v.n, bw = v.bw;
+  {
     const int nb = min(CH_NB, n - k);
     const int m = min(n - k - nb, bw);
     const int rows = CH_NB + m + 1;  // diagonal block, panel, right-hand side
     const int base = k + nb;
-    // stage the window: 32 consecutive doubles per row (coalesced); the diagonal block is completed with the identity
-    // when nb < 32, its upper triangle is zero
-    for (int idx = tid; idx < rows * CH_NB; idx += CBF_THREADS) {
-      const int row = idx >> 5, c = idx & 31;
-      double v;
-      if (row < CH_NB)
-        v = (row < nb && c <= row) ? A[(size_t)(k + row) * ld + k + c] : (row == c ? 1.0 : 0.0);
-      else if (row < CH_NB + m)
-        v = c < nb ? A[(size_t)(k + nb + row - CH_NB) * ld + k + c] : 0.0;
-      else
-        v = c < nb ? b[k + c] : 0.0;
-      W[row][c] = v;
-    }
+    cbf_stage<REV, SEP, true>(v, W, k, nb, m, true);
     __syncthreads();
     CBF_STAMP(0)
     bool good = true;
@@ -302,7 +412,7 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
       }
       if (tid == 0) {
 #pragma unroll
-        for (int c = 0; c < CBF_SUB; c++) dinv_s[j0 + c] = inv[c];
+        for (int c = 0; c < CBF_SUB; c++) sh.dinv_s[j0 + c] = inv[c];
       }
       __syncthreads();
       CBF_STAMP(6)
@@ -333,38 +443,44 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
       __syncthreads();
       CBF_STAMP(8)
     }
-    if (!good && lane == 0) fail_s = 1;
+    if (!good && lane == 0) sh.fail_s = 1;
     __syncthreads();
     CBF_STAMP(1)
-    if (fail_s) break;  // workgroup-uniform
+    if (sh.fail_s) return false;  // workgroup-uniform
     // write the factored rows back to the band (coalesced), y_k, and b of the window rows
-    for (int idx = tid; idx < (CH_NB + m) * CH_NB; idx += CBF_THREADS) {
-      const int row = idx >> 5, c = idx & 31;
-      if (row < CH_NB) {
-        if (row < nb && c <= row) A[(size_t)(k + row) * ld + k + c] = W[row][c];
-      } else if (c < nb) {
-        A[(size_t)(k + nb + row - CH_NB) * ld + k + c] = W[row][c];
+    cbf_visit<REV>(CH_NB + m, [&](const int* row, const int* c, const bool* ok) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (!ok[u]) continue;
+        const int r = row[u], cc = c[u];
+        if (r < CH_NB) {
+          if (r < nb && cc <= r) *cbf_at<REV, SEP>(v, k + r, k + cc) = W[r][cc];
+        } else if (cc < nb) {
+          *cbf_at<REV, SEP>(v, k + nb + r - CH_NB, k + cc) = W[r][cc];
+        }
       }
-    }
+    });
     if (tid < nb) {
-      y[k + tid] = W[rows - 1][tid];
-      dinvg[k + tid] = dinv_s[tid];
+      v.y[k + tid] = W[rows - 1][tid];
+      v.dinv[k + tid] = sh.dinv_s[tid];
     }
     if (tid < m) {
       double dot = 0.0;
 #pragma unroll
       for (int c = 0; c < CH_NB; c++) dot += W[CH_NB + tid][c] * W[rows - 1][c];
-      b[k + nb + tid] -= dot;
+      *cbf_rhs<REV, SEP>(v, k + nb + tid) -= dot;
     }
     CBF_STAMP(9)
     if (m > 0) {
       // window update A[i][j] -= sum_c P[i][c] P[j][c], j <= i (P = the solved panel, W rows 32 ..): 16 x 16 tiles of
-      // the lower triangle, CBF_THREADS / 64 apart per wavefront, eight v_mfma_f64_16x16x4_f64 each in two chains (lane
-      // l feeds P[i0 + (l & 15)][c0 + (l >> 4)] and P[j0 + (l & 15)][c0 + (l >> 4)]; it receives rows (l >> 4) + 4 reg,
-      // column l & 15 of the tile, so a register is four 128-byte row segments of the band storage).  All old values
-      // of a chunk of tiles are requested before its matrix instructions.  Measured alternatives, cycles per panel
-      // step at bw = 221: 4 x 4 register tiles on the vector ALU with uncoalesced accesses 45k, the same with
-      // 512-byte row segments 90k (LDS-read bound), MFMA one chain 40k, two chains 35k.
+      // the lower triangle, CBF_THREADS / 64 apart per wavefront, eight v_mfma_f64_16x16x4_f64 each in two chains.
+      // Plain view: lane l feeds P[i0 + (l & 15)][c0 + (l >> 4)] and P[j0 + (l & 15)][c0 + (l >> 4)] and receives rows
+      // (l >> 4) + 4 reg, column l & 15 of the tile, so a register is four 128-byte row segments of the band storage;
+      // reversed view: the operands trade places and the lane receives the TRANSPOSED tile, i.e. view rows
+      // i0 + (l & 15) -- contiguous storage columns -- of view columns j0 + (l >> 4) + 4 reg.  All old values of a
+      // chunk of tiles are requested before its matrix instructions.  Measured alternatives, cycles per panel step at
+      // bw = 221: 4 x 4 register tiles on the vector ALU with uncoalesced accesses 45k, the same with 512-byte row
+      // segments 90k (LDS-read bound), MFMA one chain 40k, two chains 35k.
       const int T = (m + 15) >> 4, ntiles = T * (T + 1) / 2;
       const int kq = lane >> 4, l16 = lane & 15;
       int ti = 0, tj = wave;  // tile index -> (ti, tj) by integer stepping (an fp64 sqrt per tile costs more than the tile)
@@ -380,29 +496,30 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
           tis[u] = ti;
           tjs[u] = tj;
           const bool have = tile0 + u * (CBF_THREADS / 64) < ntiles;
-          const int j = 16 * tj + l16;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const int i = 16 * ti + kq + 4 * q;
-            old[u][q] = (have && i < m && j <= i) ? A[(size_t)(base + i) * ld + base + j] : 0.0;
+            const int i = REV ? 16 * ti + l16 : 16 * ti + kq + 4 * q;
+            const int j = REV ? 16 * tj + kq + 4 * q : 16 * tj + l16;
+            old[u][q] = (have && i < m && j <= i) ? *cbf_at<REV, SEP>(v, base + i, base + j) : 0.0;
           }
           tj += CBF_THREADS / 64;
         }
 #pragma unroll
         for (int u = 0; u < CBF_TCH; u++) {
           const bool have = tile0 + u * (CBF_THREADS / 64) < ntiles;
-          const int j = 16 * tjs[u] + l16;
-          const int ra = CH_NB + min(16 * tis[u] + l16, m - 1), rb = CH_NB + min(j, m - 1);
+          const int ra = CH_NB + min(16 * tis[u] + l16, m - 1), rb = CH_NB + min(16 * tjs[u] + l16, m - 1);
+          const int r0 = REV ? rb : ra, r1 = REV ? ra : rb;
           v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int c0 = 0; c0 < CH_NB / 2; c0 += 4) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][c0 + kq], W[rb][c0 + kq], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][CH_NB / 2 + c0 + kq], W[rb][CH_NB / 2 + c0 + kq], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[r0][c0 + kq], W[r1][c0 + kq], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[r0][CH_NB / 2 + c0 + kq], W[r1][CH_NB / 2 + c0 + kq], acc2, 0, 0, 0);
           }
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const int i = 16 * tis[u] + kq + 4 * q;
-            if (have && i < m && j <= i) A[(size_t)(base + i) * ld + base + j] = old[u][q] - (acc[q] + acc2[q]);
+            const int i = REV ? 16 * tis[u] + l16 : 16 * tis[u] + kq + 4 * q;
+            const int j = REV ? 16 * tjs[u] + kq + 4 * q : 16 * tjs[u] + l16;
+            if (have && i < m && j <= i) *cbf_at<REV, SEP>(v, base + i, base + j) = old[u][q] - (acc[q] + acc2[q]);
           }
         }
       }
@@ -410,62 +527,129 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
     __syncthreads();
     CBF_STAMP(2)
   }
-  if (fail_s) {
-    if (tid == 0) *ok = 0;
-    return;
+  return true;
+}
+
+// Panel steps k in [0, k_end) of the view (k_end a multiple of 32, or the view's n): factorisation and forward
+// substitution.  Returns false (workgroup-uniform) if a pivot is not positive.
+template <bool REV>
+__device__ bool cbf_factor(const CbfView& v, int k_end, CbfShared& sh) {
+  if (threadIdx.x == 0) sh.fail_s = 0;
+  __syncthreads();
+#ifdef CBF_TIMING
+  long long tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
+#endif
+  bool good = true;
+  for (int k = 0; k < k_end && good; k += CH_NB) {
+    bool sep_step = false;
+    if (REV) sep_step = v.sepn > 0 && k + CH_NB + v.bw > v.sep0;  // the window reaches the separator rows
+    if (REV && sep_step)
+      good = cbf_step<REV, REV>(v, k, sh CBF_TPASS);
+    else
+      good = cbf_step<REV, false>(v, k, sh CBF_TPASS);
   }
-  // backward substitution L^T x = y, last panel first; x overwrites b
-  const int n_panels = (n + CH_NB - 1) / CH_NB;
+#ifdef CBF_TIMING
+  if (threadIdx.x == 0) printf("chol_band_fused ticks (block %d): stage %lld rest-of-factor %lld update %lld | factor8 %lld solve %lld store+barrier %lld rowupdate %lld barrier %lld writeback+b %lld\n", (int)blockIdx.x, tph[0], tph[1], tph[2], tph[4], tph[5], tph[6], tph[7], tph[8], tph[9]);
+#endif
+  return good;
+}
+
+// Backward substitution L^T x = y over the view's panels [0, k_end), last panel first; x overwrites the right-hand side.
+// The solution entries beyond k_end (the separator, for a chunk) must already be in place (in b: no scratch here).
+template <bool REV>
+__device__ void cbf_backward(const CbfView& v, int k_end, CbfShared& sh) {
+  double(*W)[CH_NB + 1] = sh.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
+  const int n = v.n, bw = v.bw;
+  const int n_panels = (k_end + CH_NB - 1) / CH_NB;
   for (int pi = n_panels - 1; pi >= 0; pi--) {
     const int k = pi * CH_NB;
     const int nb = min(CH_NB, n - k);
     const int m = min(n - k - nb, bw);
+    // stage the factored panel (diagonal block + the m rows below it) and the solution entries it reaches
+    cbf_stage<REV, false, false>(v, W, k, nb, m, false);
+    if (tid < m) sh.xw[tid] = *cbf_rhs<REV, false>(v, k + nb + tid);
+    __syncthreads();
     {
       const int c = tid & 31, part = tid >> 5;  // CBF_THREADS / 32 parts x 32 columns
+      constexpr int NP = CBF_THREADS / 32;
       double sum = 0.0;
-      if (c < nb) {
-        constexpr int NP = CBF_THREADS / 32;
-        for (int t0 = part; t0 < m; t0 += 8 * NP) {  // eight loads in flight per thread
-          double av[8], bv[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int t = t0 + u * NP;
-            av[u] = t < m ? A[(size_t)(k + nb + t) * ld + k + c] : 0.0;
-            bv[u] = t < m ? b[k + nb + t] : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++) sum += av[u] * bv[u];
-        }
-      }
-      red[part][c] = sum;
+      for (int t = part; t < m; t += NP) sum += W[CH_NB + t][c] * sh.xw[t];
+      sh.red[part][c] = sum;
     }
     __syncthreads();
     if (wave == 0) {
       double sacc = 0.0;
 #pragma unroll
-      for (int part = 0; part < CBF_THREADS / 32; part++) sacc += red[part][l32];
-      double v = l32 < nb ? y[k + l32] - sacc : 0.0;
-      const double dv = l32 < nb ? dinvg[k + l32] : 1.0;
+      for (int part = 0; part < CBF_THREADS / 32; part++) sacc += sh.red[part][l32];
+      double val = l32 < nb ? v.y[k + l32] - sacc : 0.0;
+      const double dv = l32 < nb ? v.dinv[k + l32] : 1.0;
       // column `l32` of the diagonal factor: rT[c] = L[c][l32], c >= l32
       double rT[CH_NB];
 #pragma unroll
-      for (int c = 0; c < CH_NB; c++) rT[c] = (c < nb && l32 < nb && c >= l32) ? A[(size_t)(k + c) * ld + k + l32] : 0.0;
+      for (int c = 0; c < CH_NB; c++) rT[c] = (c < nb && l32 < nb && c >= l32) ? W[c][l32] : 0.0;
       double xv = 0.0;
 #pragma unroll
       for (int c = CH_NB - 1; c >= 0; c--) {
-        const double xc = lane_bcast(v, c) * lane_bcast(dv, c);
+        const double xc = lane_bcast(val, c) * lane_bcast(dv, c);
         if (l32 == c) xv = xc;
-        if (l32 < c) v -= rT[c] * xc;
+        if (l32 < c) val -= rT[c] * xc;
       }
-      if (lane < nb) b[k + lane] = xv;
+      if (lane < nb) *cbf_rhs<REV, false>(v, k + lane) = xv;
     }
     __syncthreads();
   }
-  CBF_STAMP(3)
-#ifdef CBF_TIMING
-  if (tid == 0) printf("chol_band_fused ticks: stage %lld rest-of-factor %lld writeback+update %lld backward %lld | factor8 %lld solve %lld store+barrier %lld rowupdate %lld barrier %lld\n", tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6], tph[7], tph[8]);
-  if (tid == 0) printf("   writeback+b %lld\n", tph[9]);
-#endif
+}
+
+// the whole solve of one band system by one workgroup
+__global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(CbfView v, int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  if (!*ok) return;
+  if (!cbf_factor<false>(v, v.n, sh)) {
+    if (threadIdx.x == 0) *ok = 0;
+    return;
+  }
+  cbf_backward<false>(v, v.n, sh);
+}
+
+// two-ended form, phase 1: workgroup 0 factors the top chunk of `top`, workgroup 1 the (reversed) bottom chunk of `rev`
+__global__ __launch_bounds__(CBF_THREADS) void cbf2_factor_kernel(CbfView top, int k_end_top, CbfView rev, int k_end_rev,
+                                                                  int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  const bool good = blockIdx.x == 0 ? cbf_factor<false>(top, k_end_top, sh) : cbf_factor<true>(rev, k_end_rev, sh);
+  if (!good && threadIdx.x == 0) *ok = 0;
+}
+
+// phase 2a: the separator system = separator block of the storage (top update applied in place) + the bottom update
+// (M3, in reversed coordinates: view index a = sepn - 1 - u), into a band storage of its own; likewise its right-hand side
+__global__ void cbf2_mid_build_kernel(const double* __restrict__ A, int ld, int s, int sepn, const double* __restrict__ M3,
+                                      const double* __restrict__ b, const double* __restrict__ b3, double* __restrict__ Am,
+                                      int ldm, double* __restrict__ bm, const int* __restrict__ ok) {
+  if (!*ok) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= sepn * sepn) return;
+  const int u = idx / sepn, w = idx - u * sepn;
+  if (w == 0) bm[u] = b[s + u] + b3[sepn - 1 - u];
+  if (w > u) return;
+  // (u, w), u >= w, is (a, c) = (sepn - 1 - u, sepn - 1 - w) in reversed coordinates with a <= c: stored as M3[c][a]
+  Am[(size_t)u * ldm + w] = A[(size_t)(s + u) * ld + s + w] + M3[(size_t)(sepn - 1 - w) * sepn + (sepn - 1 - u)];
+}
+
+__global__ void cbf2_scatter_kernel(const double* __restrict__ xm, double* __restrict__ b, int s, int sepn, const int* __restrict__ ok) {
+  if (!*ok) return;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < sepn) b[s + u] = xm[u];
+}
+
+// phase 3: both backward substitutions, outwards from the separator
+__global__ __launch_bounds__(CBF_THREADS) void cbf2_backward_kernel(CbfView top, int k_end_top, CbfView rev, int k_end_rev,
+                                                                    const int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  if (!*ok) return;
+  if (blockIdx.x == 0)
+    cbf_backward<false>(top, k_end_top, sh);
+  else
+    cbf_backward<true>(rev, k_end_rev, sh);
 }
 
 // Solves S x = b in place (S destroyed, b <- x).  *ok_dev = 1 on success, 0 if S is not SPD.
@@ -474,13 +658,50 @@ __global__ __launch_bounds__(CBF_THREADS) void chol_band_fused_kernel(double* __
 int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
   const int one = 1;
   const int n_panels = (n + CH_NB - 1) / CH_NB;
-  if (ld != n && bw <= CBF_MAXBW && !ctx->chol_no_fused) {  // narrow band: one launch for the whole solve
-    void* ws = nullptr;
-    int rc = vsl_ctx_dscratch(ctx, sizeof(double) * (2 * (size_t)n + 16), &ws);
-    if (rc) return rc;
+  if (ld != n && bw <= CBF_MAXBW && !ctx->chol_no_fused) {  // narrow band: one launch for the whole solve, or two-ended
     VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(chol_band_fused_kernel, dim3(1), dim3(CBF_THREADS), 0, ctx->stream, S, ld, n, bw, b, (double*)ws,
-                       (double*)ws + n, ok_dev);
+    const bool two_ended = !ctx->chol_one_ended && bw + CH_NB - 1 <= CBF_MAXBW && n >= 8 * (bw + CH_NB);
+    if (!two_ended) {
+      void* ws = nullptr;
+      int rc = vsl_ctx_dscratch(ctx, sizeof(double) * (2 * (size_t)n + 16), &ws);
+      if (rc) return rc;
+      CbfView v = {S, ld, n, n, bw, 0, 0, nullptr, nullptr, b, (double*)ws, (double*)ws + n};
+      hipLaunchKernelGGL(chol_band_fused_kernel, dim3(1), dim3(CBF_THREADS), 0, ctx->stream, v, ok_dev);
+      VSL_CHECK_LAUNCH(ctx);
+      return VSL_OK;
+    }
+    // top chunk [0, s), bottom chunk [n - sp, n) (both whole panels), separator [s, s + sepn) with bw <= sepn <= bw + 31
+    const int s = ((n - bw) / 2) / CH_NB * CH_NB;
+    const int sp = (n - s - bw) / CH_NB * CH_NB;
+    const int sepn = n - s - sp;
+    const int bwm = sepn - 1, ldm = bwm + CH_NB;  // the separator system, dense, in band storage of its own
+    const size_t mid_elems = (size_t)sepn * (ldm + 1) + 64;
+    const size_t need = 4 * (size_t)n + (size_t)sepn * sepn + 4 * (size_t)sepn + mid_elems + 64;
+    void* ws = nullptr;
+    int rc = vsl_ctx_dscratch(ctx, sizeof(double) * need, &ws);
+    if (rc) return rc;
+    double* p = (double*)ws;
+    double *y_top = p, *dinv_top = p + n, *y_rev = p + 2 * (size_t)n, *dinv_rev = p + 3 * (size_t)n;
+    p += 4 * (size_t)n;
+    double* M3 = p;             // sepn x sepn, followed by b3: cleared together
+    double* b3 = p + (size_t)sepn * sepn;
+    p += (size_t)sepn * sepn + sepn;
+    double *bm = p, *ym = p + sepn, *dinvm = p + 2 * (size_t)sepn;
+    p += 3 * (size_t)sepn;
+    double* Am_store = p;       // band storage of the separator system: cleared (explicit zeros outside the lower triangle)
+    VSL_HIP(ctx, hipMemsetAsync(M3, 0, sizeof(double) * ((size_t)sepn * sepn + sepn), ctx->stream));
+    VSL_HIP(ctx, hipMemsetAsync(Am_store, 0, sizeof(double) * mid_elems, ctx->stream));
+    CbfView top = {S, ld, n, s + sepn, bw, 0, 0, nullptr, nullptr, b, y_top, dinv_top};
+    CbfView rev = {S, ld, n, sp + sepn, bw, sp, sepn, M3, b3, b, y_rev, dinv_rev};
+    hipLaunchKernelGGL(cbf2_factor_kernel, dim3(2), dim3(CBF_THREADS), 0, ctx->stream, top, s, rev, sp, ok_dev);
+    double* Am = Am_store + ldm;
+    hipLaunchKernelGGL(cbf2_mid_build_kernel, dim3((sepn * sepn + 255) / 256), dim3(256), 0, ctx->stream, S, ld, s, sepn, M3, b,
+                       b3, Am, ldm, bm, ok_dev);
+    CbfView mid = {Am, ldm, sepn, sepn, bwm, 0, 0, nullptr, nullptr, bm, ym, dinvm};
+    hipLaunchKernelGGL(chol_band_fused_kernel, dim3(1), dim3(CBF_THREADS), 0, ctx->stream, mid, ok_dev);
+    hipLaunchKernelGGL(cbf2_scatter_kernel, dim3((sepn + 255) / 256), dim3(256), 0, ctx->stream, bm, b, s, sepn, ok_dev);
+    rev.sepn = 0;  // the separator's solution is read from b now
+    hipLaunchKernelGGL(cbf2_backward_kernel, dim3(2), dim3(CBF_THREADS), 0, ctx->stream, top, s, rev, sp, ok_dev);
     VSL_CHECK_LAUNCH(ctx);
     return VSL_OK;
   }
@@ -559,9 +780,9 @@ extern "C" int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int
       }
     }
   }
-  hipFree(dS);
-  hipFree(db);
-  hipFree(dok);
+  (void)hipFree(dS);
+  (void)hipFree(db);
+  (void)hipFree(dok);
   if (e != hipSuccess) return vsl_fail(ctx, VSL_ERR_HIP, "vsl_spd_solve: %s", hipGetErrorString(e));
   if (rc != VSL_OK) return rc;
   if (!ok) return vsl_fail(ctx, VSL_ERR_NUMERIC, "vsl_spd_solve: matrix is not positive definite");
