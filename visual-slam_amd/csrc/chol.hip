@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void chol_bwd_kernel(const double* __restrict_
 // Cutting the band into more pieces does not pay at N / bw ~ 27: an interior piece has to carry its upper separator as
 // bw extra rows through every step (3 x the update work) and the separator system has twice the bandwidth.
 typedef double v4d_t __attribute__((ext_vector_type(4)));
-#define CBF_THREADS 576  // 9 wavefronts: one thread per window row (32 + 512 + the right-hand side)
+#define CBF_THREADS 768  // 12 wavefronts = 3 per SIMD (with 9 -- one thread per window row was enough -- one SIMD carried 3 and the window update, bound by its matrix unit, ran at that SIMD's pace)
 #define CBF_MAXBW 512
 #define CBF_SUB 8
 #define CBF_TCH 6  // window tiles per wavefront whose old values are in flight together
@@ -297,7 +297,8 @@ __device__ __forceinline__ void cbf_visit(int rows, F&& fn) {
     }
   } else {
     const int lane = tid & 63, wave = tid >> 6, RI = (rows + 63) >> 6;
-    for (int cc = 0; cc < 4; cc += 2)
+    constexpr int NCC = (CH_NB + CBF_THREADS / 64 - 1) / (CBF_THREADS / 64);  // columns per wavefront
+    for (int cc = 0; cc < NCC; cc += 2)
       for (int rr0 = 0; rr0 < RI; rr0 += 4) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
