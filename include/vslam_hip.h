@@ -206,6 +206,7 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "chol_no_fused" (0/1)           band Cholesky as one launch per panel step instead of the single-launch kernel
  *   "chol_one_ended" (0/1)          narrow-band Cholesky eliminated from the top only instead of from both ends
  *   "ba_force_dense" (0/1)          large bundle adjustment with the dense reduced camera system (no band ordering)
+ *   "ba_schur_atomics" (0/1)        large-system Schur complement by fp64 atomics instead of the per-block gather
  *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
  *                                   detected at the next synchronisation and the range is redone by the f64 kernel

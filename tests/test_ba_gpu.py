@@ -55,6 +55,36 @@ def test_linearize_S_g_cost(ctx, orc, synth, huber):
     assert np.allclose(g, eg, rtol=0, atol=1e-9 * np.abs(eg).max())
 
 
+@pytest.mark.parametrize("atomics", [0, 1])
+@pytest.mark.parametrize("dup", [False, True])
+def test_linearize_large_system_gather_and_atomic_paths(ctx, orc, synth, atomics, dup):
+    # reduced systems beyond 128 unknowns take the large-system path: per-block gather over pair lists built once per
+    # solve (default) or one wavefront per landmark with fp64 atomics (diagnostic) -- both against the oracle, also on a
+    # landmark range, and with a landmark that one camera observes twice (both orders land in the diagonal block)
+    d = synth.ba_problem(33, n_kf=15, n_lms=3000)
+    if dup:
+        k = int(np.flatnonzero(d["obs_lm"] == d["obs_lm"][100])[0])
+        for key in ("obs_cam", "obs_lm"):
+            d[key] = np.concatenate([d[key], d[key][k:k + 1]])
+        d["obs_uv"] = np.concatenate([d["obs_uv"], d["obs_uv"][k:k + 1] + 0.25])
+    arr = _arr(orc, d)
+    assert 6 * arr.n_free > 128
+    ctx.set_diagnostic("ba_schur_atomics", atomics)
+    try:
+        S, g, c = ctx.ba_linearize(arr)
+        S1, g1, c1 = ctx.ba_linearize(arr, lm_first=500, lm_count=1200)
+    finally:
+        ctx.set_diagnostic("ba_schur_atomics", 0)
+    eS, eg, ec = orc.ba_linearize(arr)
+    assert c == pytest.approx(ec, rel=1e-12)
+    assert np.allclose(S, eS, rtol=0, atol=1e-9 * np.abs(eS).max())
+    assert np.allclose(g, eg, rtol=0, atol=1e-9 * np.abs(eg).max())
+    eS1, eg1, ec1 = orc.ba_linearize(arr, lm_first=500, lm_count=1200)
+    assert c1 == pytest.approx(ec1, rel=1e-12)
+    assert np.allclose(S1, eS1, rtol=0, atol=1e-9 * np.abs(eS).max())
+    assert np.allclose(g1, eg1, rtol=0, atol=1e-9 * np.abs(eg).max())
+
+
 @pytest.mark.parametrize("n_kf,n_fixed_cams,n", [(7, 2, 72), (10, 2, 108), (11, 1, 126), (2, 3, 6), (4, 3, 30)])
 @pytest.mark.parametrize("entries", [0, 1])
 def test_schur_small_kernel_variants_at_local_ba_sizes(ctx, orc, synth, n_kf, n_fixed_cams, n, entries):

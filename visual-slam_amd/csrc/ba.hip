@@ -771,6 +771,195 @@ __global__ __launch_bounds__(256) void ba_schur_atomic_kernel(BaDims D, const in
   }
 }
 
+// ---- K7, large systems, gather form (the default).  The block structure of the reduced camera system is fixed over
+// the LM iterations of a solve: block (c1, c2), c1 >= c2, receives one term -Y_i W_j^T per landmark seen by both
+// cameras (i, j = that landmark's observations by c1 and c2).  The (i, j) pairs are listed per block ONCE per solve (count / scan / fill, below); every
+// iteration a per-landmark kernel writes W_i = F_i^T E_i and Y_i = W_i P^-1 for every observation, and a per-block
+// kernel sums its list -- every entry of S is written once, by one lane, no atomics (157 M fp64 atomics per iteration at
+// 1000 cameras / 881k observations took 2.5 ms).
+// Slot of block (c1, c2): band form c1 * (hb + 1) + (c1 - c2) with hb = the half bandwidth in cameras; otherwise the
+// packed lower triangle c1 (c1 + 1) / 2 + c2.
+__device__ __forceinline__ int ba_pair_slot(int c1, int c2, int hbp1) {
+  return hbp1 > 0 ? c1 * hbp1 + (c1 - c2) : c1 * (c1 + 1) / 2 + c2;
+}
+
+// FILL = false: cnt[slot] += 1 per pair; FILL = true: pairs[start[slot] + cursor[slot]++] = (i, j)
+template <bool FILL>
+__global__ void ba_pair_list_kernel(int l_first, int l_count, const int* __restrict__ lm_start, const int* __restrict__ obs_cam,
+                                    const int* __restrict__ cam_free, const int* __restrict__ cam_pos, int hbp1,
+                                    int* __restrict__ cnt, const int* __restrict__ start, int* __restrict__ pairs) {
+  const int l = l_first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= l_first + l_count) return;
+  const int a = lm_start[l], b = lm_start[l + 1];
+  for (int i = a; i < b; i++) {
+    const int ci = cam_free[obs_cam[i]];
+    if (ci < 0) continue;
+    for (int j = a; j < b; j++) {
+      const int cj = cam_free[obs_cam[j]];
+      if (cj < 0 || cj > ci) continue;  // (two observations of one landmark by the SAME camera: both orders land in the diagonal block)
+      const int slot = ba_pair_slot(ci, cj, hbp1);
+      const int k = atomicAdd(&cnt[slot], 1);
+      if (FILL) {
+        const size_t pos = (size_t)start[slot] + k;
+        pairs[2 * pos] = cam_pos[i];  // where W / Y of the observation live (camera-major order)
+        pairs[2 * pos + 1] = cam_pos[j];
+      }
+    }
+  }
+}
+
+// exclusive prefix sum of cnt[0 .. n) into start[0 .. n], one workgroup
+__global__ __launch_bounds__(1024) void ba_pair_scan_kernel(int n, const int* __restrict__ cnt, int* __restrict__ start) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int idx = base + tid;
+    const int v = idx < n ? cnt[idx] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (idx < n) start[idx] = off + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = off + x;
+    __syncthreads();
+  }
+  if (tid == 0) start[n] = carry_s;
+}
+
+// per landmark (one wavefront): P, b, P^-1 (kept for the back-substitution), and for every observation W and Y = W P^-1
+// (Y = 0 for a landmark whose P is singular: it contributes nothing); rhs -= Y b by atomics (6 per observation)
+__global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDims D, const int* __restrict__ lm_start,
+                                                            const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
+                                                            const int* __restrict__ cam_pos, const double* __restrict__ r,
+                                                            const double* __restrict__ F, const double* __restrict__ E,
+                                                            const double* __restrict__ diag_l, double inv_radius,
+                                                            int l_first, int l_count, double* __restrict__ Wg,
+                                                            double* __restrict__ Yg,
+                                                            double* __restrict__ rhs, double* __restrict__ Pinv_out,
+                                                            double* __restrict__ bl_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = l_first + blockIdx.x * 4 + wave;
+  if (l >= l_first + l_count) return;
+  const int a = lm_start[l], b = lm_start[l + 1];
+  if (a == b) return;
+  double P[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};  // P upper: 00 01 02 11 12 22
+  for (int i = a + lane; i < b; i += 64) {
+    const double* e = E + 6 * (size_t)i;
+    const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+    P[0] += e[0] * e[0] + e[3] * e[3];
+    P[1] += e[0] * e[1] + e[3] * e[4];
+    P[2] += e[0] * e[2] + e[3] * e[5];
+    P[3] += e[1] * e[1] + e[4] * e[4];
+    P[4] += e[1] * e[2] + e[4] * e[5];
+    P[5] += e[2] * e[2] + e[5] * e[5];
+    for (int x = 0; x < 3; x++) bb[x] += e[x] * r0 + e[3 + x] * r1;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int q = 0; q < 6; q++) P[q] += __shfl_xor(P[q], o);
+    for (int q = 0; q < 3; q++) bb[q] += __shfl_xor(bb[q], o);
+  }
+  double Pf[9] = {P[0], P[1], P[2], P[1], P[3], P[4], P[2], P[4], P[5]};
+  if (diag_l) {
+    Pf[0] += diag_l[3 * (size_t)l] * inv_radius;
+    Pf[4] += diag_l[3 * (size_t)l + 1] * inv_radius;
+    Pf[8] += diag_l[3 * (size_t)l + 2] * inv_radius;
+  }
+  double Pi[9];
+  const bool ok = inv3(Pf, Pi);
+  if (lane == 0) {
+    if (Pinv_out)
+      for (int q = 0; q < 9; q++) Pinv_out[9 * (size_t)l + q] = ok ? Pi[q] : 0.0;
+    if (bl_out)
+      for (int q = 0; q < 3; q++) bl_out[3 * (size_t)l + q] = ok ? bb[q] : 0.0;
+  }
+  for (int item = lane; item < (b - a) * 6; item += 64) {
+    const int q = item / 6, x = item - q * 6, i = a + q;
+    const int c = cam_free[obs_cam[i]];
+    if (c < 0) continue;
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    double w[3], y[3];
+    for (int z = 0; z < 3; z++) w[z] = f[x] * e[z] + f[6 + x] * e[3 + z];
+    for (int z = 0; z < 3; z++) y[z] = ok ? w[0] * Pi[z] + w[1] * Pi[3 + z] + w[2] * Pi[6 + z] : 0.0;
+    const size_t at = 18 * (size_t)cam_pos[i] + 3 * x;
+    for (int z = 0; z < 3; z++) {
+      Wg[at + z] = w[z];
+      Yg[at + z] = y[z];
+    }
+    if (ok) unsafeAtomicAdd(&rhs[6 * c + x], -(y[0] * bb[0] + y[1] * bb[1] + y[2] * bb[2]));
+  }
+}
+
+// per block slot (one wavefront): S_block = -sum over the slot's pairs of Y_i W_j^T, written once.  A lane takes every
+// 64th pair of the list -- both 144-byte blocks with 16-byte loads, all 36 products -- so 64 pairs' loads are in flight
+// at once (one pair per iteration with the 36 entries over the lanes was bound by the latency of the dependent loads
+// pair -> W / Y: 0.85 ms per iteration at 4.4 M pairs); the 36 x 64 partial sums are folded through LDS in lane order.
+// Band form keeps only x >= y of a diagonal block (lower_mode 2); lower_mode 1 = dense lower triangle (diagonal blocks
+// complete), 0 = full matrix (the mirror block is written as well).
+__global__ __launch_bounds__(64) void ba_schur_gather_kernel(int n_slots, int hbp1, const int* __restrict__ start,
+                                                             const int* __restrict__ pairs, const double* __restrict__ Wg,
+                                                             const double* __restrict__ Yg, double* __restrict__ S, int ldS,
+                                                             int lower_mode) {
+  __shared__ double red[36][65];
+  const int slot = blockIdx.x;
+  const int p0 = start[slot], p1 = start[slot + 1];
+  if (p0 == p1) return;
+  const int lane = threadIdx.x;
+  double acc[36];
+#pragma unroll
+  for (int e = 0; e < 36; e++) acc[e] = 0.0;
+  for (int p = p0 + lane; p < p1; p += 64) {
+    const int2 ij = *(const int2*)(pairs + 2 * (size_t)p);
+    const double2* yp = (const double2*)(Yg + 18 * (size_t)ij.x);
+    const double2* wp = (const double2*)(Wg + 18 * (size_t)ij.y);
+    double yv[18], wv[18];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      const double2 a2 = yp[q], b2 = wp[q];
+      yv[2 * q] = a2.x;
+      yv[2 * q + 1] = a2.y;
+      wv[2 * q] = b2.x;
+      wv[2 * q + 1] = b2.y;
+    }
+#pragma unroll
+    for (int x = 0; x < 6; x++)
+#pragma unroll
+      for (int y = 0; y < 6; y++)
+        acc[6 * x + y] += yv[3 * x] * wv[3 * y] + yv[3 * x + 1] * wv[3 * y + 1] + yv[3 * x + 2] * wv[3 * y + 2];
+  }
+#pragma unroll
+  for (int e = 0; e < 36; e++) red[e][lane] = acc[e];
+  __syncthreads();
+  if (lane >= 36) return;
+  const int x = lane / 6, y = lane - 6 * x;
+  double tot = 0.0;
+  const int nl = min(64, p1 - p0);
+  for (int l = 0; l < nl; l++) tot += red[lane][l];
+  const double v = -tot;
+  int c1, c2;
+  if (hbp1 > 0) {
+    c1 = slot / hbp1;
+    c2 = c1 - (slot - c1 * hbp1);
+  } else {
+    c1 = (int)((sqrt(8.0 * (double)slot + 1.0) - 1.0) * 0.5);
+    while (c1 * (c1 + 1) / 2 > slot) c1--;
+    while ((c1 + 1) * (c1 + 2) / 2 <= slot) c1++;
+    c2 = slot - c1 * (c1 + 1) / 2;
+  }
+  if (!(lower_mode == 2 && c1 == c2 && x < y)) S[(size_t)(6 * c1 + x) * ldS + 6 * c2 + y] = v;
+  if (lower_mode == 0 && c1 != c2) S[(size_t)(6 * c2 + y) * ldS + 6 * c1 + x] = v;
+}
+
 // S += blockdiag(H) + diag(D2); rhs += g_c   (large-system path, S pre-zeroed before the atomics)
 __global__ void ba_add_cam_blocks_kernel(int nfree, const double* __restrict__ H, const double* __restrict__ g_c,
                                          const double* __restrict__ diag_c, double inv_radius, double* __restrict__ S,
@@ -1150,6 +1339,12 @@ struct BaState {
   // read the step's verdict; an accepted step swaps the sets, a rejected one leaves the current set untouched)
   DevBuf r2, F2, E2, n2l2, grad_l2, H2, g_c2, diag_c2, diag_l2;
   bool want_alt_set = false;
+  // large systems, gather form of the Schur complement (ba_schur_gather_kernel): per-block pair lists, built on the
+  // first use for the landmark range they cover, and the per-observation W / Y blocks of the current linearisation
+  DevBuf pair_cnt, pair_start, pairs, Wg, Yg, cam_pos;
+  int n_slots = 0, hbp1 = 0;
+  size_t n_pairs_cap = 0;
+  int pair_l0 = -1, pair_lc = -1;
   // Layout of the reduced camera system S: dense (ldS = n, offset 0) or, for large systems whose cameras can be
   // ordered into a narrow band (reverse Cuthill-McKee on the covisibility graph, ba_setup), LAPACK-style lower band
   // storage -- row i keeps columns [i - bws, i], bws = bw + VSL_CHOL_NB, entry (i, j) at S[i * ldS + j + offS] with
@@ -1338,10 +1533,12 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     s_uv[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
     s_uv[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
   }
+  size_t n_pairs = 0;  // (observation, observation) pairs of the block lists of the gather-form Schur complement
   for (int l = 0; l < D.L; l++) {
     int k = 0;
     for (int q = lm_start[l]; q < lm_start[l + 1]; q++) k += cam_free[s_cam[q]] >= 0;
     kmax_free = std::max(kmax_free, k);
+    n_pairs += (size_t)k * k;  // upper bound (k (k + 1) / 2 when no camera observes a landmark twice)
   }
   // camera CSR over the sorted observation positions
   std::vector<int> cam_start(D.C + 1, 0), cam_obs(D.O);
@@ -1351,6 +1548,10 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     std::vector<int> fill(cam_start.begin(), cam_start.end() - 1);
     for (int q = 0; q < D.O; q++) cam_obs[fill[s_cam[q]]++] = q;
   }
+  // inverse: position of an observation in camera-major order (the gather-form Schur kernels keep W / Y in that order,
+  // so that the blocks of one camera row read one contiguous segment)
+  std::vector<int> cam_pos(D.O);
+  for (int k = 0; k < D.O; k++) cam_pos[cam_obs[k]] = k;
   st.small = D.n <= 128 && D.nfree <= SCH_CMAX && kmax_free <= SCH_KMAX;
   st.nb_obs = (D.O + 255) / 256;
   st.nb_upd = (std::max(D.C, D.L) + 255) / 256;
@@ -1375,6 +1576,17 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   if (st.small) {
     want.push_back({&st.S_part, 8 * n * n * st.G});
     want.push_back({&st.rhs_part, 8 * n * st.G});
+  } else {
+    st.hbp1 = st.banded ? (st.bw - 5) / 6 + 1 : 0;
+    st.n_slots = st.banded ? D.nfree * st.hbp1 : D.nfree * (D.nfree + 1) / 2;
+    st.n_pairs_cap = n_pairs;
+    st.pair_l0 = st.pair_lc = -1;
+    want.push_back({&st.pair_cnt, 4 * ((size_t)st.n_slots + 1)});
+    want.push_back({&st.pair_start, 4 * ((size_t)st.n_slots + 1)});
+    want.push_back({&st.pairs, 8 * std::max<size_t>(n_pairs, 1)});
+    want.push_back({&st.cam_pos, 4 * O});
+    want.push_back({&st.Wg, 8 * 18 * O});
+    want.push_back({&st.Yg, 8 * 18 * O});
   }
   if (st.want_alt_set) {
     const Want alt[] = {{&st.r2, 16 * O}, {&st.F2, 96 * O}, {&st.E2, 48 * O}, {&st.n2l2, 24 * L}, {&st.grad_l2, 24 * L},
@@ -1425,6 +1637,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   BA_HIP(up(st.lm_start, lm_start.data(), 4 * (L + 1)));
   BA_HIP(up(st.cam_start, cam_start.data(), 4 * (C + 1)));
   BA_HIP(up(st.cam_obs, cam_obs.data(), 4 * O));
+  if (!st.small) BA_HIP(up(st.cam_pos, cam_pos.data(), 4 * O));
   BA_HIP(hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors that die here
   return VSL_OK;
 }
@@ -1500,12 +1713,35 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
   } else {
     VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * st.s_elems, ctx->stream));
     VSL_HIP(ctx, hipMemsetAsync(st.rhs.p, 0, sizeof(double) * n, ctx->stream));
-    if (lc > 0)
+    const int lower_mode = st.banded ? 2 : ((lower_only && n > 128) ? 1 : 0);  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
+    if (lc > 0 && ctx->ba_schur_atomics)
       hipLaunchKernelGGL(ba_schur_atomic_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
-                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S_eff(), st.rhs.as<double>(), Pinv, bl,
-                         st.banded ? 2 : ((lower_only && n > 128) ? 1 : 0),  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
+                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.S_eff(), st.rhs.as<double>(), Pinv, bl, lower_mode,
                          st.ldS);
+    else if (lc > 0) {
+      if (st.pair_l0 != l0 || st.pair_lc != lc) {  // block pair lists of this landmark range: once per solve / session
+        VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
+        hipLaunchKernelGGL(ba_pair_list_kernel<false>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
+                           st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
+                           st.pair_cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(ba_pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, st.n_slots, st.pair_cnt.as<int>(),
+                           st.pair_start.as<int>());
+        VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
+        hipLaunchKernelGGL(ba_pair_list_kernel<true>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
+                           st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
+                           st.pair_cnt.as<int>(), st.pair_start.as<int>(), st.pairs.as<int>());
+        st.pair_l0 = l0;
+        st.pair_lc = lc;
+      }
+      hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
+                         st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.r.as<double>(), st.F.as<double>(),
+                         st.E.as<double>(), dgl, inv_radius, l0, lc, st.Wg.as<double>(), st.Yg.as<double>(), st.rhs.as<double>(),
+                         Pinv, bl);
+      hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
+                         st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(),
+                         st.ldS, lower_mode);
+    }
     hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
                        st.H.as<double>(), st.g_c.as<double>(), dgc, inv_radius, st.S_eff(), st.rhs.as<double>(), st.ldS,
                        st.banded ? 1 : 0);

@@ -20,6 +20,7 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
   else if (k == "exact_list_cap") ctx->exact_list_cap = value;
   else if (k == "ba_schur_entries") ctx->ba_schur_entries = value != 0;
+  else if (k == "ba_schur_atomics") ctx->ba_schur_atomics = value != 0;
   else if (k == "ba_force_dense") ctx->ba_force_dense = value != 0;
   else if (k == "chol_no_fused") ctx->chol_no_fused = value != 0;
   else if (k == "chol_one_ended") ctx->chol_one_ended = value != 0;

@@ -61,6 +61,7 @@ struct vsl_ctx {
   bool chol_one_ended = false;          // diagnostic: narrow-band Cholesky by one workgroup from the top only (no two-ended split)
   bool chol_no_fused = false;           // diagnostic: band Cholesky as one launch per panel step instead of the fused single-launch kernel
   bool ba_force_dense = false;          // diagnostic: dense reduced camera system even where the band form applies
+  bool ba_schur_atomics = false;        // diagnostic: large-system Schur complement by fp64 atomics (one wavefront per landmark) instead of the per-block gather
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = 256;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
