@@ -271,6 +271,8 @@ struct CbfShared {
   double red[CBF_THREADS / 32][CH_NB + 1];
   double xw[CBF_MAXBW];   // backward substitution: the solution entries the panel reaches
   double dinv_s[CH_NB];   // 1 / pivot of the panel's columns (a global store inside a sub-step would make its barrier wait for the round trip)
+  double Ld_s[CBF_SUB][CBF_SUB + 1];  // the factored 8 x 8 diagonal sub-block of the current sub-step and
+  double inv_s[CBF_SUB];              //   1 / its pivots, published by wavefront 0
   int fail_s;
 };
 
@@ -303,7 +305,7 @@ __device__ __forceinline__ void cbf_visit(int rows, F&& fn) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           c[u] = wave + (CBF_THREADS / 64) * (cc + (u >> 2));
-          row[u] = lane + 64 * (rr0 + (u & 3));
+          row[u] = (63 - lane) + 64 * (rr0 + (u & 3));  // lanes ascend in ADDRESS (descending view rows): the coalescer merges ascending lanes only (descending: 23k instead of 14k cycles per staging)
           ok[u] = c[u] < CH_NB && row[u] < rows;
         }
         fn(row, c, ok);
@@ -371,16 +373,15 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
     cbf_stage<REV, SEP, true>(v, W, k, nb, m, true);
     __syncthreads();
     CBF_STAMP(0)
-    bool good = true;
-#pragma unroll 1
-    for (int j0 = 0; j0 < CH_NB; j0 += CBF_SUB) {
-      const bool act = tid < rows && tid >= j0;
-      double a[CBF_SUB], dr[CBF_SUB], inv[CBF_SUB], x[CBF_SUB];
+    // The 8 x 8 diagonal sub-block of a sub-step is factored by wavefront 0 ALONE and published through LDS (every
+    // wavefront factoring it redundantly -- ~400 dependent instructions -- cost three wavefronts' worth of issue slots
+    // per SIMD and sub-step: 19k of the 86k cycles of a panel step).  For sub-steps 1..3 wavefront 0 does it inside the
+    // previous sub-step's update phase, right after the tile that completes that sub-block, so no barrier is added.
+    auto factor8 = [&](int j0) {  // wavefront 0 only; lanes 0..7 = the rows of the sub-block
+      double dr[CBF_SUB];
 #pragma unroll
-      for (int c = 0; c < CBF_SUB; c++) {
-        a[c] = act ? W[tid][j0 + c] : 0.0;
-        dr[c] = lane < CBF_SUB ? W[j0 + lane][j0 + c] : (lane == c ? 1.0 : 0.0);
-      }
+      for (int c = 0; c < CBF_SUB; c++) dr[c] = lane < CBF_SUB ? W[j0 + lane][j0 + c] : (lane == c ? 1.0 : 0.0);
+      bool good = true;
 #pragma unroll
       for (int c = 0; c < CBF_SUB; c++) {
         const double d = lane_bcast(dr[c], c);
@@ -391,19 +392,31 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
         double iv = __builtin_amdgcn_rsq(d);
         iv = iv * (1.5 - 0.5 * d * iv * iv);
         iv = iv * (1.5 - 0.5 * d * iv * iv);
-        inv[c] = iv;
+        if (lane == 0) sh.inv_s[c] = iv;
         dr[c] = (lane == c) ? d * iv : dr[c] * iv;  // lanes > c: l(lane, c)
 #pragma unroll
         for (int q = c + 1; q < CBF_SUB; q++) dr[q] -= dr[c] * lane_bcast(dr[c], q);  // meaningful for lanes >= q
       }
-      CBF_STAMP(4)
+      if (lane < CBF_SUB) {
+#pragma unroll
+        for (int c = 0; c < CBF_SUB; c++) sh.Ld_s[lane][c] = dr[c];  // l(lane, c) for c <= lane (the rest is never read)
+      }
+      if (!good && lane == 0) sh.fail_s = 1;
+    };
+    if (wave == 0) factor8(0);
+    __syncthreads();
+    CBF_STAMP(4)
+#pragma unroll 1
+    for (int j0 = 0; j0 < CH_NB; j0 += CBF_SUB) {
+      const bool act = tid < rows && tid >= j0;
       // x L_d^T = a: this row's entries in the sub-panel (for a row of the diagonal sub-block: that row of L_d)
+      double x[CBF_SUB];
 #pragma unroll
       for (int c = 0; c < CBF_SUB; c++) {
-        double t = a[c];
+        double t = act ? W[tid][j0 + c] : 0.0;
 #pragma unroll
-        for (int q = 0; q < c; q++) t -= x[q] * lane_bcast(dr[q], c);
-        x[c] = t * inv[c];
+        for (int q = 0; q < c; q++) t -= x[q] * sh.Ld_s[c][q];
+        x[c] = t * sh.inv_s[c];
       }
       CBF_STAMP(5)
       if (act) {
@@ -411,16 +424,14 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
         for (int c = 0; c < CBF_SUB; c++)
           if (tid >= j0 + CBF_SUB || c <= tid - j0) W[tid][j0 + c] = x[c];
       }
-      if (tid == 0) {
-#pragma unroll
-        for (int c = 0; c < CBF_SUB; c++) sh.dinv_s[j0 + c] = inv[c];
-      }
+      if (tid < CBF_SUB) sh.dinv_s[j0 + tid] = sh.inv_s[tid];
       __syncthreads();
       CBF_STAMP(6)
       // the remaining panel columns lose X . L_d^T: W[r][cc] -= sum_q W[r][j0 + q] W[cc][j0 + q] for rows r >= j0 + 8 and
       // columns cc in [j0 + 8, 32) -- a rank-8 update in 16 x 16 tiles on the matrix unit (two v_mfma_f64_16x16x4_f64 per
       // tile; as one row per thread with broadcast LDS reads of the factor rows this phase was LDS-bound: 17k of the
       // 87k cycles of a panel step).  Entries above the diagonal of the diagonal block receive garbage; nothing reads them.
+      // Tile 0 (wavefront 0's first) holds the next 8 x 8 diagonal sub-block.
       if (j0 + CBF_SUB < CH_NB) {
         const int r_first = (j0 + CBF_SUB) & ~15, c_first = j0 + CBF_SUB < 16 ? 0 : 16;
         const int n_rt = (rows - r_first + 15) >> 4, n_ct = (CH_NB - c_first) >> 4;
@@ -438,14 +449,13 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
             const int r = R0 + kq + 4 * q;
             if (r < rows && r >= j0 + CBF_SUB && cc >= j0 + CBF_SUB) W[r][cc] -= acc[q];
           }
+          if (t == 0) factor8(j0 + CBF_SUB);  // wavefront 0 (t == wave == 0): its own LDS writes above are ordered before these reads
         }
       }
       CBF_STAMP(7)
       __syncthreads();
       CBF_STAMP(8)
     }
-    if (!good && lane == 0) sh.fail_s = 1;
-    __syncthreads();
     CBF_STAMP(1)
     if (sh.fail_s) return false;  // workgroup-uniform
     // write the factored rows back to the band (coalesced), y_k, and b of the window rows
@@ -499,7 +509,7 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
           const bool have = tile0 + u * (CBF_THREADS / 64) < ntiles;
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const int i = REV ? 16 * ti + l16 : 16 * ti + kq + 4 * q;
+            const int i = REV ? 16 * ti + 15 - l16 : 16 * ti + kq + 4 * q;  // (reversed: lanes ascend in address)
             const int j = REV ? 16 * tj + kq + 4 * q : 16 * tj + l16;
             old[u][q] = (have && i < m && j <= i) ? *cbf_at<REV, SEP>(v, base + i, base + j) : 0.0;
           }
@@ -508,7 +518,7 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
 #pragma unroll
         for (int u = 0; u < CBF_TCH; u++) {
           const bool have = tile0 + u * (CBF_THREADS / 64) < ntiles;
-          const int ra = CH_NB + min(16 * tis[u] + l16, m - 1), rb = CH_NB + min(16 * tjs[u] + l16, m - 1);
+          const int ra = CH_NB + min(16 * tis[u] + (REV ? 15 - l16 : l16), m - 1), rb = CH_NB + min(16 * tjs[u] + l16, m - 1);
           const int r0 = REV ? rb : ra, r1 = REV ? ra : rb;
           v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -518,7 +528,7 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
           }
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            const int i = REV ? 16 * tis[u] + l16 : 16 * tis[u] + kq + 4 * q;
+            const int i = REV ? 16 * tis[u] + 15 - l16 : 16 * tis[u] + kq + 4 * q;
             const int j = REV ? 16 * tjs[u] + kq + 4 * q : 16 * tjs[u] + l16;
             if (have && i < m && j <= i) *cbf_at<REV, SEP>(v, base + i, base + j) = old[u][q] - (acc[q] + acc2[q]);
           }
