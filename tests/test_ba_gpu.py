@@ -170,8 +170,24 @@ def test_bundle_adjust_is_run_to_run_reproducible(ctx, orc, synth):
     assert np.array_equal(a1.poses, a2.poses) and np.array_equal(a1.points, a2.points)
 
 
+@pytest.mark.parametrize("dense", [0, 1])
+def test_large_system_bundle_adjust_is_run_to_run_reproducible(ctx, orc, synth, dense):
+    # large-system path: the Schur complement is a gather over per-block pair lists SORTED after their (atomic) fill, the
+    # right-hand side a per-camera gather, the band / dense Cholesky has no atomics -> bit-identical reruns here too
+    d = synth.ba_problem(52, n_kf=60, n_lms=5000, loop_radius=10.0)
+    a1, a2 = _arr(orc, d), _arr(orc, d)
+    ctx.set_diagnostic("ba_force_dense", dense)
+    try:
+        s1 = ctx.bundle_adjust(a1, max_iters=6)
+        s2 = ctx.bundle_adjust(a2, max_iters=6)
+    finally:
+        ctx.set_diagnostic("ba_force_dense", 0)
+    assert s1.iterations == s2.iterations and s1.final_cost == s2.final_cost
+    assert np.array_equal(a1.poses, a2.poses) and np.array_equal(a1.points, a2.points)
+
+
 def test_large_system_path(ctx, orc, synth):
-    # > 21 free cameras: wavefront-per-landmark atomics + blocked dense Cholesky (global-BA path)
+    # > 21 free cameras: per-block gather (or, as a diagnostic, wavefront-per-landmark atomics) + blocked Cholesky (global-BA path)
     d = synth.ba_problem(61, n_kf=40, n_lms=6000, loop_radius=6.0)
     arr = _arr(orc, d)
     assert arr.n_free * 6 > 128

@@ -836,8 +836,60 @@ __global__ __launch_bounds__(1024) void ba_pair_scan_kernel(int n, const int* __
   if (tid == 0) start[n] = carry_s;
 }
 
+// the fill order of a slot's list depends on the scheduling of the atomics above; sorting every list by its
+// (i, j) keys once makes the summation order of the gather -- and with it the whole large-system solve -- reproducible
+// run to run.  One wavefront per slot, rank sort in LDS (lists hold a few hundred pairs; beyond PAIR_SORT_MAX a list
+// stays in fill order).
+#define PAIR_SORT_MAX 2048
+__global__ __launch_bounds__(64) void ba_pair_sort_kernel(const int* __restrict__ start, int* __restrict__ pairs) {
+  __shared__ unsigned long long key[PAIR_SORT_MAX];
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  const int p0 = start[slot], n = start[slot + 1] - p0;
+  if (n < 2 || n > PAIR_SORT_MAX) return;
+  for (int t = lane; t < n; t += 64) {
+    const int2 ij = *(const int2*)(pairs + 2 * (size_t)(p0 + t));
+    key[t] = ((unsigned long long)(unsigned)ij.x << 32) | (unsigned)ij.y;
+  }
+  __syncthreads();
+  for (int t = lane; t < n; t += 64) {
+    const unsigned long long mine = key[t];
+    int rank = 0;
+    for (int u = 0; u < n; u++) rank += key[u] < mine;  // keys are distinct: (i, j) occurs once
+    int2 ij;
+    ij.x = (int)(mine >> 32);
+    ij.y = (int)(mine & 0xffffffffu);
+    *(int2*)(pairs + 2 * (size_t)(p0 + rank)) = ij;
+  }
+}
+
+// rhs of the reduced system, gather form: rhs[6 fc + x] = -sum over the observations of free camera fc (contiguous in
+// camera-major order) whose landmark lies in [l_first, l_first + l_count) of Y_i[x] . b_l -- one wavefront per camera,
+// lanes stride the observations, xor-tree (fixed order).  ba_add_cam_blocks_kernel adds g_c afterwards.
+__global__ __launch_bounds__(64) void ba_schur_rhs_kernel(int nfree, const int* __restrict__ free_cams,
+                                                          const int* __restrict__ cam_start, const int* __restrict__ cam_obs,
+                                                          const int* __restrict__ obs_lm, const double* __restrict__ Yg,
+                                                          const double* __restrict__ bl, int l_first, int l_count,
+                                                          double* __restrict__ rhs) {
+  const int fc = blockIdx.x, lane = threadIdx.x;
+  const int c = free_cams[fc];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = cam_start[c] + lane; k < cam_start[c + 1]; k += 64) {
+    const int l = obs_lm[cam_obs[k]];
+    if (l < l_first || l >= l_first + l_count) continue;
+    const double* y = Yg + 18 * (size_t)k;
+    const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+#pragma unroll
+    for (int x = 0; x < 6; x++) acc[x] += y[3 * x] * b0 + y[3 * x + 1] * b1 + y[3 * x + 2] * b2;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int x = 0; x < 6; x++) acc[x] += __shfl_xor(acc[x], o);
+  if (lane < 6) rhs[6 * fc + lane] = -acc[lane];
+}
+
 // per landmark (one wavefront): P, b, P^-1 (kept for the back-substitution), and for every observation W and Y = W P^-1
-// (Y = 0 for a landmark whose P is singular: it contributes nothing); rhs -= Y b by atomics (6 per observation)
+// (Y = 0 for a landmark whose P is singular: it contributes nothing)
 __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDims D, const int* __restrict__ lm_start,
                                                             const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
                                                             const int* __restrict__ cam_pos, const double* __restrict__ r,
@@ -896,7 +948,6 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDims D, const int*
       Wg[at + z] = w[z];
       Yg[at + z] = y[z];
     }
-    if (ok) unsafeAtomicAdd(&rhs[6 * c + x], -(y[0] * bb[0] + y[1] * bb[1] + y[2] * bb[2]));
   }
 }
 
@@ -1731,13 +1782,19 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
         hipLaunchKernelGGL(ba_pair_list_kernel<true>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
                            st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
                            st.pair_cnt.as<int>(), st.pair_start.as<int>(), st.pairs.as<int>());
+        hipLaunchKernelGGL(ba_pair_sort_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.pair_start.as<int>(),
+                           st.pairs.as<int>());
         st.pair_l0 = l0;
         st.pair_lc = lc;
       }
       hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.r.as<double>(), st.F.as<double>(),
                          st.E.as<double>(), dgl, inv_radius, l0, lc, st.Wg.as<double>(), st.Yg.as<double>(), st.rhs.as<double>(),
-                         Pinv, bl);
+                         Pinv, st.bl.as<double>());
+      if (D.nfree > 0)
+        hipLaunchKernelGGL(ba_schur_rhs_kernel, dim3(D.nfree), dim3(64), 0, ctx->stream, D.nfree, st.free_cams.as<int>(),
+                           st.cam_start.as<int>(), st.cam_obs.as<int>(), st.obs_lm.as<int>(), st.Yg.as<double>(),
+                           st.bl.as<double>(), l0, lc, st.rhs.as<double>());
       hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
                          st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(),
                          st.ldS, lower_mode);
