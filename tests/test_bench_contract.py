@@ -28,7 +28,10 @@ def test_committed_bench_line_has_the_contract_keys():
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-4
     # achieved = algorithmic bytes per launch / average launch duration
     assert abs(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 - r["achieved"]) < 1e-2 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] >= 0.95 * r["algorithmic_bytes_per_launch"]
+    # K1 must at least read every image byte of the launch (its own outputs are a few MB; the 56 B per keypoint of the
+    # stage's algorithmic figure are written by the kernels behind it)
+    images = 2 * d["config"]["stereo_frames_per_launch"]
+    assert r["traffic"] is None or 0.95 * images * 752 * 480 <= r["traffic"] <= 3 * r["algorithmic_bytes_per_launch"]
     # the sustained-rate and upload-inclusive figures of round 2
     assert d["config"]["inputs_resident_in_hbm"] is True and d["config"]["h2d_in_timed_region"] is False
     assert d["config"]["timed_region_s"] >= 1.0
