@@ -12,6 +12,7 @@ cp $(ls $O/lba/*/*_kernel_stats.csv | head -1) profiles/${R}_local_ba_kernel_sta
 cp $(ls $O/gba/*/*_kernel_stats.csv | head -1) profiles/${R}_global_ba_kernel_stats.csv
 python tools/pmc_summary.py $O profiles/${R}_pmc_traffic.json 512
 python tools/sq_summary.py $O profiles/${R}_matcher_sq_counters.json
+python tools/frame_sq_summary.py $O profiles/${R}_frame_sq_counters.json
 python - $R <<'PY'
 import csv, glob, statistics, re, sys
 R = sys.argv[1]

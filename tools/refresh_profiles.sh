@@ -26,6 +26,8 @@ echo bench; (cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench.err)
 # kernel durations: one stream (the isolated durations the roofline uses) and the default two-stream run
 echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 8 --steps 6 --warmup 2 $LITE > $O/kt1.log 2>&1
 echo kt2; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 $R/bench.py --passes 8 --steps 6 --warmup 2 $LITE > $O/kt2.log 2>&1
+# per-frame kernels: SQ counters of the bench launch (what binds K1 / describe / select / match)
+echo fsq; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --output-format csv -d $O/fsq -- python3 $R/bench.py $PMCARGS > $O/fsq.log 2>&1
 # matcher: SQ counters of the FP4 kernel and of the int8 kernel (staggered and not)
 echo matcher; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU --output-format csv -d $O/mm1 -- python3 $R/tools/match_probe.py match_use_i8=1 > $O/mm1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU --output-format csv -d $O/mm2 -- python3 $R/tools/match_probe_nostagger.py > $O/mm2.log 2>&1
