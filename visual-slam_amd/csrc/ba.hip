@@ -1634,7 +1634,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     st.pair_l0 = st.pair_lc = -1;
     want.push_back({&st.pair_cnt, 4 * ((size_t)st.n_slots + 1)});
     want.push_back({&st.pair_start, 4 * ((size_t)st.n_slots + 1)});
-    want.push_back({&st.pairs, 8 * std::max<size_t>(n_pairs, 1)});
+    want.push_back({&st.pairs, 8 * std::max<size_t>(n_pairs < ((size_t)1 << 31) ? n_pairs : 1, 1)});
     want.push_back({&st.cam_pos, 4 * O});
     want.push_back({&st.Wg, 8 * 18 * O});
     want.push_back({&st.Yg, 8 * 18 * O});
@@ -1765,7 +1765,8 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
     VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * st.s_elems, ctx->stream));
     VSL_HIP(ctx, hipMemsetAsync(st.rhs.p, 0, sizeof(double) * n, ctx->stream));
     const int lower_mode = st.banded ? 2 : ((lower_only && n > 128) ? 1 : 0);  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
-    if (lc > 0 && ctx->ba_schur_atomics)
+    // (pair lists index with 32-bit positions: a problem with 2^31 pairs or more keeps the atomic form)
+    if (lc > 0 && (ctx->ba_schur_atomics || st.n_pairs_cap >= ((size_t)1 << 31)))
       hipLaunchKernelGGL(ba_schur_atomic_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(),
                          st.E.as<double>(), dgl, inv_radius, l0, lc, st.S_eff(), st.rhs.as<double>(), Pinv, bl, lower_mode,
