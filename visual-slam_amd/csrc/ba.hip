@@ -425,7 +425,7 @@ inline __device__ bool inv3(const double* P, double* Pi) {
 //   beyond that count own nothing (own = false guards every use) -- 18 LDS doubles per 27 fused multiply-adds; the
 //   finish kernel mirrors the strictly-upper sub-blocks (S is symmetric).  A first attempt at this variant in round 1
 //   faulted on the GPU and was reverted uncommitted (its source is lost); this one was written against the extents
-//   listed in DESIGN.md "Schur kernel extents" and is tested at n = 72, 108 and 126.
+//   listed in DESIGN.md section 5 (the round-1 Schur fault) and is tested at n = 72, 108 and 126.
 template <bool BLOCK3>
 __global__ __launch_bounds__(SCH_THREADS) void ba_schur_small_kernel(
     BaDims D, const int* __restrict__ lm_start, const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
@@ -1058,6 +1058,13 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
   for (int i = tid; i < n; i += 256) bvec[i] = rhs[i];
   if (tid == 0) fail_s = 0;
   __syncthreads();
+#ifdef CHS_TIMING
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
+#define CHS_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); tp[q] += t2 - tt; tt = t2; }
+#else
+#define CHS_STAMP(q)
+#endif
+  CHS_STAMP(0)
   for (int j0 = 0; j0 < n; j0 += CH_NB) {
     const int w = min(CH_NB, n - j0);  // a ragged last panel is completed with identity columns
     const int row = j0 + tid;
@@ -1071,6 +1078,7 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
       }
     }
     __syncthreads();  // the second wavefront has read the diagonal block before the first one overwrites it with L
+    CHS_STAMP(1)
     if (tid < 128) {
       double inv[CH_NB], x[CH_NB];
       bool good = true;
@@ -1078,9 +1086,14 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
       for (int c = 0; c < CH_NB; c++) {
         const double d = readlane_f64(dr[c], c);
         if (!(d > 0.0) || !isfinite(d)) good = false;  // wave-uniform
-        const double sq = sqrt(d);
-        inv[c] = 1.0 / sq;
-        dr[c] = (lane == c) ? sq : dr[c] * inv[c];     // lanes > c: l(lane, c)
+        // 1 / sqrt(d) by the hardware estimate and two Newton steps, sqrt(d) = d / sqrt(d): the IEEE sqrt and divide
+        // expansions are ~100 dependent fp64 instructions each, and the pivots are a serial chain (measured in the band
+        // solver of chol.hip: ~1500 cycles per pivot, i.e. most of this kernel's 60 us at n = 72)
+        double iv = __builtin_amdgcn_rsq(d);
+        iv = iv * (1.5 - 0.5 * d * iv * iv);
+        iv = iv * (1.5 - 0.5 * d * iv * iv);
+        inv[c] = iv;
+        dr[c] = (lane == c) ? d * iv : dr[c] * iv;     // lanes > c: l(lane, c)
 #pragma unroll
         for (int k = c + 1; k < CH_NB; k++) dr[k] -= dr[c] * readlane_f64(dr[c], k);  // meaningful for lanes >= k
       }
@@ -1105,12 +1118,13 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
       }
     }
     __syncthreads();
+    CHS_STAMP(2)
     if (fail_s) break;  // workgroup-uniform
     const int r0 = j0 + CH_NB, rem = n - r0;
     if (rem > 0) {
       const int T = (rem + 3) >> 2, ntiles = T * (T + 1) / 2;
       for (int tile = tid; tile < ntiles; tile += 256) {
-        int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        int ti = (int)((__fsqrt_rn(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);  // fp32 estimate, corrected below (an fp64 sqrt costs more than the tile)
         while (ti * (ti + 1) / 2 > tile) ti--;
         while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
         const int tj = tile - ti * (ti + 1) / 2;
@@ -1140,31 +1154,68 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
       }
     }
     __syncthreads();
+    CHS_STAMP(3)
   }
   const bool good = fail_s == 0;
   if (good && tid < 64) {
-    // substitutions by one wavefront, two rows per lane, no workgroup barriers: L y = b, then L^T x = y
+    // substitutions by one wavefront, two rows per lane, no workgroup barriers: L y = b, then L^T x = y.  Panel by
+    // panel: the eight factor entries a lane needs for a panel are read from LDS BEFORE the panel's eight serial steps
+    // (with the read inside every step the chain was 144 x (LDS latency + broadcast): 52k of the kernel's 125k cycles)
     const int r0 = lane, r1 = lane + 64;
     double b0 = r0 < n ? bvec[r0] : 0.0, b1 = r1 < n ? bvec[r1] : 0.0;
-    for (int j = 0; j < n; j++) {
-      const double yj = __shfl(j < 64 ? b0 : b1, j & 63) * invd[j];
-      if (lane == (j & 63)) {
-        if (j < 64) b0 = yj; else b1 = yj;
+    // the reciprocal pivots ride in registers too (lane l: pivots l and l + 64) and are broadcast like the solution
+    // entries: an LDS read of invd[j] inside a step put the LDS latency back into the chain
+    const double inv0 = r0 < n ? invd[r0] : 0.0, inv1 = r1 < n ? invd[r1] : 0.0;
+    for (int j0 = 0; j0 < n; j0 += CH_NB) {
+      double a0[CH_NB], a1[CH_NB];
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) {
+        const int j = min(j0 + c, n - 1);
+        a0[c] = (r0 > j && r0 < n) ? A[r0 * ld + j] : 0.0;
+        a1[c] = (r1 > j && r1 < n) ? A[r1 * ld + j] : 0.0;
       }
-      if (r0 > j && r0 < n) b0 -= A[r0 * ld + j] * yj;
-      if (r1 > j && r1 < n) b1 -= A[r1 * ld + j] * yj;
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) {
+        const int j = j0 + c;
+        if (j < n) {  // wave-uniform
+          // j is wave-uniform: scalar broadcasts, not LDS permutes
+          const double yj = readlane_f64(j < 64 ? b0 : b1, j & 63) * readlane_f64(j < 64 ? inv0 : inv1, j & 63);
+          if (lane == (j & 63)) {
+            if (j < 64) b0 = yj; else b1 = yj;
+          }
+          b0 -= a0[c] * yj;  // a0 / a1 are zero for rows at or above j
+          b1 -= a1[c] * yj;
+        }
+      }
     }
-    for (int j = n - 1; j >= 0; j--) {
-      const double xj = __shfl(j < 64 ? b0 : b1, j & 63) * invd[j];
-      if (lane == (j & 63)) {
-        if (j < 64) b0 = xj; else b1 = xj;
+    for (int j0 = ((n - 1) / CH_NB) * CH_NB; j0 >= 0; j0 -= CH_NB) {
+      double a0[CH_NB], a1[CH_NB];
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) {
+        const int j = min(j0 + c, n - 1);
+        a0[c] = (r0 < j && j0 + c < n) ? A[j * ld + r0] : 0.0;
+        a1[c] = (r1 < j && j0 + c < n) ? A[j * ld + r1] : 0.0;
       }
-      if (r0 < j) b0 -= A[j * ld + r0] * xj;
-      if (r1 < j) b1 -= A[j * ld + r1] * xj;
+#pragma unroll
+      for (int c = CH_NB - 1; c >= 0; c--) {
+        const int j = j0 + c;
+        if (j < n) {
+          const double xj = readlane_f64(j < 64 ? b0 : b1, j & 63) * readlane_f64(j < 64 ? inv0 : inv1, j & 63);
+          if (lane == (j & 63)) {
+            if (j < 64) b0 = xj; else b1 = xj;
+          }
+          b0 -= a0[c] * xj;  // zero for rows at or below j
+          b1 -= a1[c] * xj;
+        }
+      }
     }
     if (r0 < n) dc[r0] = -b0;
     if (r1 < n) dc[r1] = -b1;
   }
+  CHS_STAMP(4)
+#ifdef CHS_TIMING
+  if (tid == 0) printf("chol_small n %d cycles: load %lld panel-load+barrier %lld factor+solve+store %lld trailing %lld substitutions %lld\n", n, tp[0], tp[1], tp[2], tp[3], tp[4]);
+#endif
   if (tid == 0) *ok_flag = good ? 1 : 0;
 }
 
