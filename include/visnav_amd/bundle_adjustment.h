@@ -45,7 +45,7 @@ inline int camera_model_id(const std::string& name) {
 template <bool kAllObs>
 inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_parameter, int max_num_iterations,
                    int verbosity_level, const std::set<FrameCamId>& fixed_cameras, Calibration& calib_cam,
-                   Cameras& cameras, Landmarks& landmarks) {
+                   Cameras& cameras, Landmarks& landmarks, bool optimize_intrinsics = false) {
   if (cameras.empty() || landmarks.empty()) return;
   std::vector<double> poses, points, uv, intr(16, 0.0);
   std::vector<uint8_t> fixed;
@@ -107,6 +107,11 @@ inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_
           "global_bundle_adjustment (RCCL)");
   } else
 #endif
+  if (optimize_intrinsics) {  // map_utils.h:397-403: the intrinsics blocks stay variable and are written back
+    check(vsl_bundle_adjust_intrinsics(ctx(), &prob, &opt, intr.data(), &sum), "bundle_adjustment (optimize_intrinsics)");
+    for (int k = 0; k < 2; k++)
+      for (int j = 0; j < 8; j++) calib_cam.intrinsics[k]->data()[j] = intr[8 * k + j];
+  } else
     check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
   for (size_t c = 0; c < cam_ptr.size(); c++) {
     double* d = cam_ptr[c]->T_w_c.data();
@@ -120,17 +125,14 @@ inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_
 }
 }  // namespace amd
 
-// include/visnav/map_utils.h:337-421.  options.optimize_intrinsics == true is not supported (the
-// reference never sets it: src/slam.cpp uses the default false) and aborts loudly.
+// include/visnav/map_utils.h:337-421, including options.optimize_intrinsics (:397-403; the reference wires it to a
+// hidden GUI variable that defaults to false, src/slam.cpp:304, :1545): the two intrinsics blocks are then optimised
+// with the poses and landmarks and calib_cam.intrinsics is updated.
 inline void bundle_adjustment(const Corners& feature_corners, const BundleAdjustmentOptions& options,
                               const std::set<FrameCamId>& fixed_cameras, Calibration& calib_cam, Cameras& cameras,
                               Landmarks& landmarks) {
-  if (options.optimize_intrinsics) {
-    std::fprintf(stderr, "visnav_amd: bundle_adjustment with optimize_intrinsics is not implemented\n");
-    std::abort();
-  }
   amd::run_ba<false>(feature_corners, options.use_huber, options.huber_parameter, options.max_num_iterations,
-                     options.verbosity_level, fixed_cameras, calib_cam, cameras, landmarks);
+                     options.verbosity_level, fixed_cameras, calib_cam, cameras, landmarks, options.optimize_intrinsics);
 }
 
 // include/visnav/loop_closure_utils.h:672-748.  With rccl_world.h included first and VISNAV_AMD_WORLD > 1 (one process

@@ -379,6 +379,12 @@ int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl
 /* Plain synchronous copy on the context's device (kind 0 host->device, 1 device->host, 2 device->device): for
  * callers that hold device pointers handed out by this library (all-reduce callbacks). */
 int vsl_ctx_memcpy(vsl_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+/* visnav::bundle_adjustment with BundleAdjustmentOptions::optimize_intrinsics = true (include/visnav/map_utils.h:324,
+ * :397-403: the two intrinsics blocks are not set constant; wired to a hidden GUI variable, src/slam.cpp:304, :1545):
+ * poses, landmarks AND the two 8-parameter intrinsics blocks are optimised jointly (same restated Ceres policy; the
+ * parameters a model does not use keep their values).  intr_io [16] in/out; prob->intr is ignored. */
+int vsl_bundle_adjust_intrinsics(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, double* intr_io,
+                                 vsl_ba_summary* summary);
 /* The solver behind the reduced camera system, on its own (the place Ceres' SPARSE_SCHUR hands S to a Cholesky,
  * include/visnav/map_utils.h:406-411, loop_closure_utils.h:735): solves S x = b for a symmetric positive definite S
  * given as a HOST row-major n x n array of which only the lower triangle is read.  half_bandwidth < 0: dense

@@ -97,7 +97,7 @@ int vsl_find_matches_landmarks(vsl_ctx*, const double* kp_xy, const uint64_t* kp
   return VSL_OK;
 }
 
-static int run_ba(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary) {
+static int run_ba(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary, double* intr_io = nullptr) {
   orc_ba_problem p;
   p.n_cams = prob->n_cams;
   p.n_lms = prob->n_lms;
@@ -119,7 +119,8 @@ static int run_ba(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* 
   o.verbosity = opt->verbosity;
   o.num_threads = (int32_t)std::thread::hardware_concurrency();  // ceres_options.num_threads (map_utils.h:409)
   orc_ba_summary s;
-  if (orc_bundle_adjust(&p, &o, &s) != 0) return fail(c, VSL_ERR_NUMERIC, "oracle bundle adjustment failed");
+  if ((intr_io ? orc_bundle_adjust_intrinsics(&p, &o, intr_io, &s) : orc_bundle_adjust(&p, &o, &s)) != 0)
+    return fail(c, VSL_ERR_NUMERIC, "oracle bundle adjustment failed");
   if (summary) {
     std::memset(summary, 0, sizeof(*summary));
     summary->initial_cost = s.initial_cost;
@@ -133,6 +134,10 @@ static int run_ba(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* 
 }
 int vsl_bundle_adjust(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary) {
   return run_ba(c, prob, opt, summary);
+}
+int vsl_bundle_adjust_intrinsics(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* opt, double* intr_io,
+                                 vsl_ba_summary* summary) {
+  return run_ba(c, prob, opt, summary, intr_io);
 }
 int vsl_global_bundle_adjust(vsl_ctx* c, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_allreduce_fn, void*, int, int,
                              vsl_ba_summary* summary) {

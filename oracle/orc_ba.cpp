@@ -58,8 +58,8 @@ inline double atan2(double y, double x) { return std::atan2(y, x); }
 
 // --------------------------------------------------------------------------------- camera models
 // camera_models.h:75-94 (pinhole), :158-178 (eucm), :246-270 (ds), :341-374 (kb4)
-template <class T>
-void project(int model, const double* param, const T p[3], T res[2]) {
+template <class T, class P = double>
+void project(int model, const P* param, const T p[3], T res[2]) {
   const T fx(param[0]), fy(param[1]), cx(param[2]), cy(param[3]);
   const T& x = p[0];
   const T& y = p[1];
@@ -165,6 +165,27 @@ void residual_jacobian(int model, const double* pose, const double* point, const
     }
     for (int j = 0; j < 3; j++) Jl[3 * a + j] = res[a].v[7 + j];
   }
+}
+
+// The third parameter block of AutoDiffCostFunction<., 2, 7, 3, 8> (map_utils.h:377-380): d residual / d intrinsics,
+// 2 x 8 row-major, by dual numbers over the eight intrinsic parameters (pose and point constant).
+void residual_jacobian_intr(int model, const double* pose, const double* point, const double* intr, const double* uv,
+                            double* Ji /*2x8*/) {
+  (void)uv;  // the detected corner is a constant of the residual
+  typedef Jet<8> J;
+  J ji[8], jp[7], jl[3];
+  for (int i = 0; i < 8; i++) ji[i] = J(intr[i], i);
+  for (int i = 0; i < 7; i++) jp[i] = J(pose[i]);
+  for (int i = 0; i < 3; i++) jl[i] = J(point[i]);
+  const J qi[4] = {-jp[0], -jp[1], -jp[2], jp[3]};
+  const J nt[3] = {jp[4] * J(-1.0), jp[5] * J(-1.0), jp[6] * J(-1.0)};
+  J ti[3], rp[3], pc[3], proj[2];
+  quat_rotate(qi, nt, ti);
+  quat_rotate(qi, jl, rp);
+  for (int i = 0; i < 3; i++) pc[i] = rp[i] + ti[i];
+  project<J, J>(model, ji, pc, proj);
+  for (int a = 0; a < 2; a++)
+    for (int j = 0; j < 8; j++) Ji[8 * a + j] = -proj[a].v[j];  // residual = p_2d - projection
 }
 
 // [upstream] Sophus SO3::exp / SE3::exp and the group product, then q re-normalised.
@@ -718,6 +739,313 @@ int orc_bundle_adjust(const orc_ba_problem* p, const orc_ba_options* o, orc_ba_s
     std::fprintf(stderr, "orc BA: iterations %d, initial cost %.6e, final cost %.6e, termination %d\n", s.iterations, s.initial_cost, s.final_cost, s.termination);
   if (sum) *sum = s;
   return 0;
+}
+
+// map_utils.h:337-421 with options.optimize_intrinsics = true (:397-403: the two intrinsics blocks are NOT set constant):
+// the same Levenberg-Marquardt / Schur loop as orc_bundle_adjust with two more 8-wide parameter blocks on the camera
+// side of the reduced system.  Every residual depends on its camera pose (6 tangent columns, absent for a fixed
+// camera), on the intrinsics block cam_intr[cam] (8 columns, all of them like Ceres' size-8 block: the unused trailing
+// parameters of a model have zero columns and keep their values) and on its landmark (3 columns, eliminated).
+// intr_io [16]: in = initial intrinsics, out = optimised.  p->intr is not used.
+int orc_bundle_adjust_intrinsics(const orc_ba_problem* p, const orc_ba_options* o, double* intr_io, orc_ba_summary* sum) {
+  const double t_start = now_ms();
+  Work w;
+  setup(w, p, o);
+  const int nc = 6 * w.n_free, ni = 16, nt = nc + ni, nl = 3 * p->n_lms, O = p->n_obs;
+  std::vector<double> x_pose(p->poses, p->poses + 7 * (size_t)p->n_cams), x_pt(p->points, p->points + 3 * (size_t)p->n_lms);
+  std::vector<double> x_in(intr_io, intr_io + 16);
+  std::vector<double> c_pose(x_pose), c_pt(x_pt), c_in(x_in);
+  orc_ba_summary s;
+  std::memset(&s, 0, sizeof(s));
+  // per observation: residual (2), camera-side Jacobian J (2 x 14: pose 6 | intrinsics 8), landmark Jacobian E (2 x 3)
+  std::vector<double> R(2 * (size_t)O), J(28 * (size_t)O), E(6 * (size_t)O);
+  auto col_of = [&](int i, int j) {  // column of the reduced system of camera-side column j of observation i, or -1
+    const int cam = p->obs_cam[i];
+    if (j < 6) return w.free_idx[cam] >= 0 ? 6 * w.free_idx[cam] + j : -1;
+    return nc + 8 * p->cam_intr[cam] + (j - 6);
+  };
+  auto cost_at = [&](const double* poses, const double* pts, const double* in) {
+    double c = 0;
+    for (int i = 0; i < O; i++) {
+      const int cam = p->obs_cam[i], k = p->cam_intr[cam];
+      double r[2];
+      functor<double>(p->cam_model[k], in + 8 * k, p->obs_uv + 2 * i, poses + 7 * cam, pts + 3 * p->obs_lm[i], r);
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      double rho0 = sq, rho1 = 1;
+      if (o->use_huber) huber(sq, o->huber_parameter, rho0, rho1);
+      c += 0.5 * rho0;
+    }
+    return c;
+  };
+  auto linearize_all = [&]() {
+    double c = 0;
+    for (int i = 0; i < O; i++) {
+      const int cam = p->obs_cam[i], k = p->cam_intr[cam], model = p->cam_model[k];
+      double r[2], F[12], El[6], G[16];
+      residual_jacobian(model, &x_pose[7 * cam], &x_pt[3 * p->obs_lm[i]], &x_in[8 * k], p->obs_uv + 2 * i, r, F, El);
+      residual_jacobian_intr(model, &x_pose[7 * cam], &x_pt[3 * p->obs_lm[i]], &x_in[8 * k], p->obs_uv + 2 * i, G);
+      const double sq = r[0] * r[0] + r[1] * r[1];
+      double rho0 = sq, rho1 = 1;
+      if (o->use_huber) huber(sq, o->huber_parameter, rho0, rho1);
+      c += 0.5 * rho0;
+      const double sr = std::sqrt(rho1);
+      for (int a = 0; a < 2; a++) {
+        R[2 * (size_t)i + a] = r[a] * sr;
+        for (int j = 0; j < 6; j++) J[28 * (size_t)i + 14 * a + j] = F[6 * a + j] * sr;
+        for (int j = 0; j < 8; j++) J[28 * (size_t)i + 14 * a + 6 + j] = G[8 * a + j] * sr;
+        for (int j = 0; j < 3; j++) E[6 * (size_t)i + 3 * a + j] = El[3 * a + j] * sr;
+      }
+    }
+    return c;
+  };
+  auto x_norm_of = [&](const std::vector<double>& ps, const std::vector<double>& pt, const std::vector<double>& in) {
+    double q = 0;
+    for (int c = 0; c < p->n_cams; c++)
+      if (w.free_idx[c] >= 0)
+        for (int j = 0; j < 7; j++) q += ps[7 * c + j] * ps[7 * c + j];
+    for (double v : pt) q += v * v;
+    for (double v : in) q += v * v;
+    return std::sqrt(q);
+  };
+  double cost = linearize_all();
+  s.initial_cost = cost;
+  double x_norm = x_norm_of(x_pose, x_pt, x_in);
+  std::vector<double> scale_c(nt, 1.0), scale_l(nl, 1.0), grad_c(nt), grad_l(nl), n2c(nt), n2l(nl);
+  auto column_stats = [&]() {  // gradient and squared column norms of the current (possibly scaled) Jacobian
+    std::fill(grad_c.begin(), grad_c.end(), 0.0);
+    std::fill(grad_l.begin(), grad_l.end(), 0.0);
+    std::fill(n2c.begin(), n2c.end(), 0.0);
+    std::fill(n2l.begin(), n2l.end(), 0.0);
+    for (int i = 0; i < O; i++) {
+      const double* Ji = &J[28 * (size_t)i];
+      const double* Ei = &E[6 * (size_t)i];
+      const double* r = &R[2 * (size_t)i];
+      for (int j = 0; j < 14; j++) {
+        const int c = col_of(i, j);
+        if (c < 0) continue;
+        grad_c[c] += Ji[j] * r[0] + Ji[14 + j] * r[1];
+        n2c[c] += Ji[j] * Ji[j] + Ji[14 + j] * Ji[14 + j];
+      }
+      const int lm = p->obs_lm[i];
+      for (int j = 0; j < 3; j++) {
+        grad_l[3 * lm + j] += Ei[j] * r[0] + Ei[3 + j] * r[1];
+        n2l[3 * lm + j] += Ei[j] * Ei[j] + Ei[3 + j] * Ei[3 + j];
+      }
+    }
+  };
+  auto apply_scale = [&]() {
+    for (int i = 0; i < O; i++) {
+      double* Ji = &J[28 * (size_t)i];
+      double* Ei = &E[6 * (size_t)i];
+      for (int j = 0; j < 14; j++) {
+        const int c = col_of(i, j);
+        if (c < 0) continue;
+        Ji[j] *= scale_c[c];
+        Ji[14 + j] *= scale_c[c];
+      }
+      const int lm = p->obs_lm[i];
+      for (int j = 0; j < 3; j++) { Ei[j] *= scale_l[3 * lm + j]; Ei[3 + j] *= scale_l[3 * lm + j]; }
+    }
+  };
+  auto grad_max = [&]() {
+    double m = 0;
+    for (double v : grad_c) m = std::max(m, std::fabs(v));
+    for (double v : grad_l) m = std::max(m, std::fabs(v));
+    return m;
+  };
+  column_stats();
+  for (int i = 0; i < nt; i++) scale_c[i] = 1.0 / (1.0 + std::sqrt(n2c[i]));
+  for (int i = 0; i < nl; i++) scale_l[i] = 1.0 / (1.0 + std::sqrt(n2l[i]));
+  apply_scale();
+  column_stats();
+  double gmax = grad_max();
+
+  double radius = 1e4, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  std::vector<double> diag_c(nt), diag_l(nl), S, rhs, Pinv(9 * (size_t)p->n_lms), bl(3 * (size_t)p->n_lms), dc(nt), dl(nl);
+  int iteration = 0, invalid = 0;
+  s.termination = 0;
+  while (true) {
+    if (iteration >= o->max_num_iterations) { s.termination = 0; break; }
+    if (gmax <= 1e-10) { s.termination = 2; break; }
+    if (radius <= 1e-32) { s.termination = 4; break; }
+    iteration++;
+    if (!reuse_diagonal) {
+      for (int i = 0; i < nt; i++) diag_c[i] = std::min(std::max(n2c[i], 1e-6), 1e32);
+      for (int i = 0; i < nl; i++) diag_l[i] = std::min(std::max(n2l[i], 1e-6), 1e32);
+    }
+    // Schur complement of the landmark blocks
+    S.assign((size_t)nt * nt, 0.0);
+    rhs.assign(nt, 0.0);
+    for (int i = 0; i < nt; i++) S[(size_t)i * nt + i] += diag_c[i] / radius;
+    std::fill(Pinv.begin(), Pinv.end(), 0.0);
+    std::fill(bl.begin(), bl.end(), 0.0);
+    std::vector<double> Wb, Yb;
+    for (int l = 0; l < p->n_lms; l++) {
+      const int a = w.lm_start[l], b = w.lm_start[l + 1];
+      if (a == b) continue;
+      double P[9] = {0}, bb[3] = {0};
+      P[0] = diag_l[3 * l] / radius; P[4] = diag_l[3 * l + 1] / radius; P[8] = diag_l[3 * l + 2] / radius;
+      Wb.assign(42 * (size_t)(b - a), 0.0);
+      for (int q = a; q < b; q++) {
+        const int i = w.lm_obs[q];
+        const double* Ji = &J[28 * (size_t)i];
+        const double* Ei = &E[6 * (size_t)i];
+        const double* r = &R[2 * (size_t)i];
+        for (int x = 0; x < 3; x++) {
+          for (int y = 0; y < 3; y++) P[3 * x + y] += Ei[x] * Ei[y] + Ei[3 + x] * Ei[3 + y];
+          bb[x] += Ei[x] * r[0] + Ei[3 + x] * r[1];
+        }
+        double* W = &Wb[42 * (size_t)(q - a)];
+        for (int x = 0; x < 14; x++) {
+          const int cx = col_of(i, x);
+          if (cx < 0) continue;
+          for (int y = 0; y < 14; y++) {
+            const int cy = col_of(i, y);
+            if (cy >= 0) S[(size_t)cx * nt + cy] += Ji[x] * Ji[y] + Ji[14 + x] * Ji[14 + y];
+          }
+          rhs[cx] += Ji[x] * r[0] + Ji[14 + x] * r[1];
+          for (int y = 0; y < 3; y++) W[3 * x + y] = Ji[x] * Ei[y] + Ji[14 + x] * Ei[3 + y];
+        }
+      }
+      double Pi[9];
+      if (!inv3_spd(P, Pi)) continue;
+      std::memcpy(&Pinv[9 * (size_t)l], Pi, sizeof(Pi));
+      std::memcpy(&bl[3 * (size_t)l], bb, sizeof(bb));
+      Yb.assign(42 * (size_t)(b - a), 0.0);
+      for (int q = 0; q < b - a; q++)
+        for (int x = 0; x < 14; x++)
+          for (int y = 0; y < 3; y++)
+            Yb[42 * (size_t)q + 3 * x + y] = Wb[42 * (size_t)q + 3 * x] * Pi[y] + Wb[42 * (size_t)q + 3 * x + 1] * Pi[3 + y] +
+                                            Wb[42 * (size_t)q + 3 * x + 2] * Pi[6 + y];
+      for (int q1 = 0; q1 < b - a; q1++) {
+        const int i1 = w.lm_obs[a + q1];
+        const double* Y = &Yb[42 * (size_t)q1];
+        for (int x = 0; x < 14; x++) {
+          const int cx = col_of(i1, x);
+          if (cx < 0) continue;
+          rhs[cx] -= Y[3 * x] * bb[0] + Y[3 * x + 1] * bb[1] + Y[3 * x + 2] * bb[2];
+          for (int q2 = 0; q2 < b - a; q2++) {
+            const int i2 = w.lm_obs[a + q2];
+            const double* W2 = &Wb[42 * (size_t)q2];
+            for (int y = 0; y < 14; y++) {
+              const int cy = col_of(i2, y);
+              if (cy >= 0) S[(size_t)cx * nt + cy] -= Y[3 * x] * W2[3 * y] + Y[3 * x + 1] * W2[3 * y + 1] + Y[3 * x + 2] * W2[3 * y + 2];
+            }
+          }
+        }
+      }
+    }
+    std::vector<double> y(rhs);
+    bool ok = chol_solve(S, y, nt);
+    if (ok) {
+      for (int i = 0; i < nt; i++) dc[i] = -y[i];
+      for (int l = 0; l < p->n_lms; l++) {
+        double t[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};
+        for (int q = w.lm_start[l]; q < w.lm_start[l + 1]; q++) {
+          const int i = w.lm_obs[q];
+          const double* Ji = &J[28 * (size_t)i];
+          const double* Ei = &E[6 * (size_t)i];
+          double fd[2] = {0, 0};
+          for (int j = 0; j < 14; j++) {
+            const int c = col_of(i, j);
+            if (c >= 0) { fd[0] += Ji[j] * dc[c]; fd[1] += Ji[14 + j] * dc[c]; }
+          }
+          for (int j = 0; j < 3; j++) t[j] += Ei[j] * fd[0] + Ei[3 + j] * fd[1];
+        }
+        const double* Pi = &Pinv[9 * (size_t)l];
+        for (int j = 0; j < 3; j++) dl[3 * l + j] = -(Pi[3 * j] * t[0] + Pi[3 * j + 1] * t[1] + Pi[3 * j + 2] * t[2]);
+      }
+      for (double v : dc) ok = ok && std::isfinite(v);
+      for (double v : dl) ok = ok && std::isfinite(v);
+    }
+    double model_cost_change = 0;
+    if (ok) {
+      for (int i = 0; i < O; i++) {
+        const double* Ji = &J[28 * (size_t)i];
+        const double* Ei = &E[6 * (size_t)i];
+        const double* r = &R[2 * (size_t)i];
+        const int lm = p->obs_lm[i];
+        double m[2] = {0, 0};
+        for (int j = 0; j < 14; j++) {
+          const int c = col_of(i, j);
+          if (c >= 0) { m[0] += Ji[j] * dc[c]; m[1] += Ji[14 + j] * dc[c]; }
+        }
+        for (int j = 0; j < 3; j++) { m[0] += Ei[j] * dl[3 * lm + j]; m[1] += Ei[3 + j] * dl[3 * lm + j]; }
+        model_cost_change -= m[0] * (r[0] + m[0] / 2.0) + m[1] * (r[1] + m[1] / 2.0);
+      }
+      ok = model_cost_change > 0.0;
+    }
+    if (!ok) {
+      if (++invalid >= 5) { s.termination = 4; break; }
+      radius *= 0.5;
+      reuse_diagonal = true;
+      continue;
+    }
+    invalid = 0;
+    double step_norm2 = 0;
+    for (int c = 0; c < p->n_cams; c++) {
+      const int fc = w.free_idx[c];
+      if (fc < 0) continue;
+      double d6[6];
+      for (int j = 0; j < 6; j++) { d6[j] = dc[6 * fc + j] * scale_c[6 * fc + j]; step_norm2 += d6[j] * d6[j]; }
+      se3_plus(&x_pose[7 * c], d6, &c_pose[7 * c]);
+    }
+    for (int j = 0; j < ni; j++) {
+      const double d = dc[nc + j] * scale_c[nc + j];
+      step_norm2 += d * d;
+      c_in[j] = x_in[j] + d;
+    }
+    for (int i = 0; i < nl; i++) {
+      const double d = dl[i] * scale_l[i];
+      step_norm2 += d * d;
+      c_pt[i] = x_pt[i] + d;
+    }
+    const double cand_cost = cost_at(c_pose.data(), c_pt.data(), c_in.data());
+    const double step_norm = std::sqrt(step_norm2);
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { s.termination = 3; break; }
+    const double cost_change = cost - cand_cost;
+    if (std::fabs(cost_change) <= 1e-6 * cost) { s.termination = 1; break; }
+    const double rel = cost_change / model_cost_change;
+    if (o->verbosity >= 2)
+      std::fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", iteration, cand_cost, cost_change, gmax, step_norm, rel, radius);
+    if (rel > 1e-3) {
+      x_pose = c_pose;
+      x_pt = c_pt;
+      x_in = c_in;
+      x_norm = x_norm_of(x_pose, x_pt, x_in);
+      cost = cand_cost;
+      linearize_all();
+      apply_scale();
+      column_stats();
+      gmax = grad_max();
+      s.successful_steps++;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
+      radius = std::min(1e16, radius);
+      decrease_factor = 2.0;
+      reuse_diagonal = false;
+    } else {
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      reuse_diagonal = true;
+    }
+  }
+  s.iterations = iteration;
+  s.final_cost = cost;
+  std::memcpy(p->poses, x_pose.data(), sizeof(double) * x_pose.size());
+  std::memcpy(p->points, x_pt.data(), sizeof(double) * x_pt.size());
+  std::memcpy(intr_io, x_in.data(), sizeof(double) * 16);
+  s.total_ms = now_ms() - t_start;
+  if (o->verbosity >= 1)
+    std::fprintf(stderr, "orc BA (intrinsics): iterations %d, initial cost %.6e, final cost %.6e, termination %d\n", s.iterations, s.initial_cost, s.final_cost, s.termination);
+  if (sum) *sum = s;
+  return 0;
+}
+
+// d residual / d intrinsics (2 x 8 row-major) for the parity tests of the device Jacobian
+void orc_ba_residual_jacobian_intr(int model, const double* pose7, const double* point3, const double* intr8,
+                                   const double* uv2, double* J_intr) {
+  residual_jacobian_intr(model, pose7, point3, intr8, uv2, J_intr);
 }
 
 }  // extern "C"

@@ -449,6 +449,23 @@ def bundle_adjust(arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0, thr
     return s
 
 
+def bundle_adjust_intrinsics(arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0):
+    """optimize_intrinsics = true: optimises arr.poses / arr.points / arr.intr in place; returns the summary struct."""
+    st = arr.fill(BaProblem())
+    o = _opts(use_huber, huber, max_iters, verbosity, 1)
+    s = BaSummary()
+    lib().orc_bundle_adjust_intrinsics(C.byref(st), C.byref(o), arr.intr.ctypes.data_as(f64p), C.byref(s))
+    return s
+
+
+def ba_residual_jacobian_intr(model, pose7, point3, intr8, uv2):
+    a = [np.ascontiguousarray(x, np.float64) for x in (pose7, point3, intr8, uv2)]
+    Ji = np.zeros((2, 8))
+    lib().orc_ba_residual_jacobian_intr(int(model), a[0].ctypes.data_as(f64p), a[1].ctypes.data_as(f64p),
+                                        a[2].ctypes.data_as(f64p), a[3].ctypes.data_as(f64p), Ji.ctypes.data_as(f64p))
+    return Ji
+
+
 # ---- pose graph optimisation ([upstream] Ceres + Sophus restated, parity unpinned)
 class PgoProblem(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_edges", C.c_int32), ("poses", f64p), ("node_fixed", u8p),

@@ -150,6 +150,12 @@ int orc_ba_linearize(const orc_ba_problem*, const orc_ba_options*, int lm_first,
                      double* g, double* cost, int* n_free);
 /* map_utils.h:337-421 / loop_closure_utils.h:672-748 with [upstream] Ceres LM semantics. */
 int orc_bundle_adjust(const orc_ba_problem*, const orc_ba_options*, orc_ba_summary*);
+/* The same with BundleAdjustmentOptions::optimize_intrinsics = true (map_utils.h:324, :397-403): the two 8-parameter
+ * intrinsics blocks are optimised with the poses and landmarks.  intr_io [16] in/out; the problem's intr is not used. */
+int orc_bundle_adjust_intrinsics(const orc_ba_problem*, const orc_ba_options*, double* intr_io, orc_ba_summary*);
+/* d residual / d intrinsics, 2 x 8 row-major (the third block of AutoDiffCostFunction<., 2, 7, 3, 8>) */
+void orc_ba_residual_jacobian_intr(int model, const double* pose7, const double* point3, const double* intr8,
+                                   const double* uv2, double* J_intr);
 
 /* ---- pose graph optimisation (loop_closure_utils.h:446-587, reprojection.h:107-126) ------------- */
 typedef struct orc_pgo_problem {

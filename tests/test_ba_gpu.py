@@ -211,3 +211,58 @@ def test_bad_arguments(ctx, orc, synth, vsl):
     with pytest.raises(vsl.VslError) as e:
         ctx.bundle_adjust(arr)
     assert e.value.code == -1
+
+
+# ---- BundleAdjustmentOptions::optimize_intrinsics = true (map_utils.h:324, :397-403)
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+@pytest.mark.parametrize("n_kf", [4, 24])
+def test_bundle_adjust_intrinsics_matches_oracle(ctx, orc, synth, model, n_kf):
+    # poses, landmarks and the two intrinsics blocks optimised jointly, from intrinsics that start up to 2 % off; the same
+    # LM trajectory as the oracle (iterations, termination, accepted steps; cost 1e-7; parameters 1e-6 relative), for the
+    # four camera models and for a reduced system below / above the 128 unknowns that select the dense solver.  The
+    # parameters a model does not use keep their values exactly.
+    n_used = {0: 6, 1: 4, 2: 6, 3: 8}[model]
+    d = synth.ba_problem(300 + 10 * model + n_kf, n_kf=n_kf, n_lms=900, loop_radius=6.0 if n_kf > 10 else None)
+    d["intr"] = np.array([INTR[model], INTR[model]])
+    d["cam_model"] = (model, model)
+    # re-observe the (noisy) scene through THIS model so that the problem is consistent with it
+    gt = orc.BaArrays(d["gt_poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["gt_points"], d["obs_cam"], d["obs_lm"], d["obs_uv"],
+                      d["cam_model"])
+    rng = np.random.default_rng(model)
+    uv = np.zeros_like(d["obs_uv"])
+    for i in range(len(uv)):
+        c, l = gt.obs_cam[i], gt.obs_lm[i]
+        uv[i] = -orc.ba_residual(model, gt.poses[c], gt.points[l], gt.intr[gt.cam_intr[c]], np.zeros(2))
+    d["obs_uv"] = uv + rng.normal(0, 0.3, uv.shape)
+    start = d["intr"].copy()
+    start[:, :4] *= np.array([1.02, 0.985, 1.01, 0.99])
+    start[:, 4:n_used] *= 1.015
+    d["intr"] = start
+    a_gpu, a_cpu = _arr(orc, d), _arr(orc, d)
+    s_gpu = ctx.bundle_adjust_intrinsics(a_gpu, max_iters=25)
+    s_cpu = orc.bundle_adjust_intrinsics(a_cpu, max_iters=25)
+    assert s_gpu.initial_cost == pytest.approx(s_cpu.initial_cost, rel=1e-12)
+    assert (s_gpu.iterations, s_gpu.termination, s_gpu.successful_steps) == (s_cpu.iterations, s_cpu.termination, s_cpu.successful_steps)
+    assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
+    assert s_gpu.final_cost < 0.5 * s_gpu.initial_cost
+    assert np.allclose(a_gpu.intr, a_cpu.intr, rtol=1e-6, atol=1e-9)
+    assert np.array_equal(a_gpu.intr[:, n_used:], start[:, n_used:])
+    assert np.allclose(a_gpu.poses, a_cpu.poses, rtol=0, atol=1e-6)
+    assert np.allclose(a_gpu.points, a_cpu.points, rtol=0, atol=1e-5)
+    assert not np.allclose(a_gpu.intr[:, :4], start[:, :4], rtol=1e-4)  # the intrinsics did move
+    fixed = d["cam_fixed"].astype(bool)
+    assert np.array_equal(a_gpu.poses[fixed], d["poses"][fixed])
+
+
+def test_bundle_adjust_intrinsics_first_iteration(ctx, orc, synth):
+    # one LM iteration: every Jacobian block (including d residual / d intrinsics), the bordered Schur complement and the
+    # solve enter the candidate cost -- a wrong entry shows here without being averaged away by later iterations
+    d = synth.ba_problem(77, n_kf=5, n_lms=700)
+    d["intr"] = d["intr"] * np.array([1.01, 0.99, 1.005, 0.995, 1.02, 0.98, 1, 1])
+    a_gpu, a_cpu = _arr(orc, d), _arr(orc, d)
+    s_gpu = ctx.bundle_adjust_intrinsics(a_gpu, max_iters=1)
+    s_cpu = orc.bundle_adjust_intrinsics(a_cpu, max_iters=1)
+    assert s_gpu.successful_steps == s_cpu.successful_steps == 1
+    assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-9)
+    assert np.allclose(a_gpu.intr, a_cpu.intr, rtol=1e-9, atol=1e-12)
+    assert np.allclose(a_gpu.poses, a_cpu.poses, rtol=0, atol=1e-9)

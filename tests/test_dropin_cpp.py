@@ -12,9 +12,9 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _compile(out):
+def _compile(out, src="dropin_test.cpp"):
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", str(ROOT / "include"),
-           str(ROOT / "tests/cpp/dropin_test.cpp"), "-o", str(out), "-L", str(ROOT / "visual-slam_amd"),
+           str(ROOT / "tests/cpp" / src), "-o", str(out), "-L", str(ROOT / "visual-slam_amd"),
            "-lvslam_hip", "-Wl,-rpath," + str(ROOT / "visual-slam_amd")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -24,6 +24,37 @@ def _compile(out):
 def test_dropin_headers_compile(tmp_path, vsl):
     assert vsl.library_path().exists()
     _compile(tmp_path / "dropin_test")
+    _compile(tmp_path / "ba_intrinsics_test", "ba_intrinsics_test.cpp")
+
+
+@pytest.mark.gpu
+def test_dropin_bundle_adjustment_with_optimize_intrinsics(tmp_path, orc, synth):
+    # BundleAdjustmentOptions::optimize_intrinsics = true (map_utils.h:324, :397-403) through the wrapper: the two
+    # intrinsics blocks move with the poses and landmarks and calib_cam.intrinsics is written back.  Same optimum as the
+    # oracle (the wrapper walks an unordered_map, so summation orders differ: cost 1e-5, intrinsics 1e-5 relative)
+    exe = _compile(tmp_path / "ba_intrinsics_test", "ba_intrinsics_test.cpp")
+    d = synth.ba_problem(9, n_kf=4, n_lms=500)
+    d["intr"] = d["intr"] * np.array([1.01, 0.99, 1.005, 0.995, 1.02, 0.98, 1, 1])
+    with open(tmp_path / "ba.bin", "wb") as f:
+        f.write(struct.pack("iii", len(d["poses"]), len(d["points"]), len(d["obs_cam"])))
+        for a, t in ((d["poses"], np.float64), (d["cam_fixed"], np.uint8), (d["intr"], np.float64),
+                     (d["points"], np.float64), (d["obs_cam"], np.int32), (d["obs_lm"], np.int32),
+                     (d["obs_uv"], np.float64)):
+            f.write(np.ascontiguousarray(a, t).tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / "ba.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    buf = np.fromfile(tmp_path / "out.bin", np.float64)
+    nc, nl = len(d["poses"]), len(d["points"])
+    poses, points, intr = buf[:7 * nc].reshape(-1, 7), buf[7 * nc:7 * nc + 3 * nl].reshape(-1, 3), buf[7 * nc + 3 * nl:].reshape(2, 8)
+    arr = orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"], d["obs_cam"], d["obs_lm"],
+                       d["obs_uv"], d["cam_model"])
+    s = orc.bundle_adjust_intrinsics(arr, max_iters=20)
+    assert np.allclose(intr, arr.intr, rtol=1e-5, atol=1e-8)
+    assert not np.allclose(intr[:, :6], d["intr"][:, :6], rtol=1e-4)   # they moved
+    assert np.array_equal(intr[:, 6:], d["intr"][:, 6:])               # the double-sphere model has six parameters
+    assert np.allclose(poses, arr.poses, rtol=0, atol=1e-5)
+    got = orc.BaArrays(poses, d["cam_fixed"], d["cam_intr"], intr, points, d["obs_cam"], d["obs_lm"], d["obs_uv"], d["cam_model"])
+    assert orc.ba_linearize(got)[2] == pytest.approx(s.final_cost, rel=1e-5)
 
 
 @pytest.mark.gpu

@@ -111,3 +111,52 @@ def test_linearize_partition_is_additive(orc, synth):
     assert np.allclose(g1 + g2, g, rtol=1e-12, atol=1e-9)
     assert c1 + c2 == pytest.approx(c, rel=1e-12)
     assert np.allclose(S, S.T, rtol=1e-9, atol=1e-9 * np.abs(S).max())
+
+
+# ---- optimize_intrinsics = true (map_utils.h:324, :397-403)
+INTR8 = {0: [350.0, 348.0, 365.0, 249.0, -0.24, 0.57, 0, 0],
+         1: [350.0, 348.0, 365.0, 249.0, 0, 0, 0, 0],
+         2: [350.0, 348.0, 365.0, 249.0, 0.6, 1.1, 0, 0],
+         3: [350.0, 348.0, 365.0, 249.0, 0.01, -0.004, 0.002, -0.0005]}
+N_INTR = {0: 6, 1: 4, 2: 6, 3: 8}
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+def test_intrinsics_jacobian_against_finite_differences(orc, synth, model):
+    d = synth.ba_problem(70 + model, n_kf=2, n_lms=60)
+    intr = np.array(INTR8[model])
+    rng = np.random.default_rng(model)
+    for i in rng.choice(len(d["obs_cam"]), 12, replace=False):
+        pose, pt, uv = d["poses"][d["obs_cam"][i]], d["points"][d["obs_lm"][i]], d["obs_uv"][i]
+        Ji = orc.ba_residual_jacobian_intr(model, pose, pt, intr, uv)
+        for j in range(8):
+            h = 1e-6 * max(1.0, abs(intr[j]))
+            ip, im = intr.copy(), intr.copy()
+            ip[j] += h
+            im[j] -= h
+            fd = (orc.ba_residual(model, pose, pt, ip, uv) - orc.ba_residual(model, pose, pt, im, uv)) / (2 * h)
+            assert np.allclose(Ji[:, j], fd, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(Ji).max()))
+        assert np.all(Ji[:, N_INTR[model]:] == 0)  # parameters a model does not use have zero columns
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+def test_bundle_adjust_intrinsics_recovers_perturbed_intrinsics(orc, synth, model):
+    # noise-free observations generated with the true intrinsics; start from intrinsics that are off by up to 2 % (and
+    # perturbed poses / landmarks): the joint optimisation must drive the cost to ~0 and return to the true intrinsics
+    # (the unused trailing parameters keep their values exactly)
+    d = synth.ba_problem(80 + model, n_kf=5, n_lms=600, pix_noise=0.0, outlier_frac=0.0, integer_pixels=False)
+    true = np.array([INTR8[model], INTR8[model]])
+    uv = np.zeros_like(d["obs_uv"])
+    gt_poses, gt_points = d["gt_poses"], d["gt_points"]
+    for i in range(len(uv)):  # observations of the ground-truth scene through the TRUE model
+        c, l = d["obs_cam"][i], d["obs_lm"][i]
+        r = orc.ba_residual(model, gt_poses[c], gt_points[l], true[d["cam_intr"][c]], np.zeros(2))
+        uv[i] = -r
+    arr = orc.BaArrays(d["poses"], d["cam_fixed"], d["cam_intr"], true, d["points"], d["obs_cam"], d["obs_lm"], uv, (model, model))
+    start = true.copy()
+    start[:, :4] *= np.array([1.02, 0.985, 1.01, 0.99])
+    start[:, 4:N_INTR[model]] *= 1.02
+    arr.intr[...] = start
+    s = orc.bundle_adjust_intrinsics(arr, max_iters=60)
+    assert s.final_cost < 1e-10 * max(s.initial_cost, 1.0)
+    assert np.array_equal(arr.intr[:, N_INTR[model]:], start[:, N_INTR[model]:])

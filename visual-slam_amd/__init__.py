@@ -334,6 +334,15 @@ class Context:
                                           C.byref(cost), C.byref(nf)))
         return Hc.reshape(n, n), g[:n].copy(), cost.value
 
+    def bundle_adjust_intrinsics(self, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0):
+        """optimize_intrinsics = true: optimises arr.poses / arr.points / arr.intr in place."""
+        st = self._ba_struct(arr)
+        o = self._ba_opts(use_huber, huber, max_iters, verbosity)
+        out = BaSummary()
+        self._ck(self.L.vsl_bundle_adjust_intrinsics(self.h, C.byref(st), C.byref(o), arr.intr.ctypes.data_as(f64p),
+                                                     C.byref(out)))
+        return out
+
     def ba_linearize(self, arr, use_huber=True, huber=1.0, lm_first=0, lm_count=-1):
         st = self._ba_struct(arr)
         o = self._ba_opts(use_huber, huber, 0, 0)

@@ -2651,3 +2651,582 @@ extern "C" int vsl_ctx_memcpy(vsl_ctx* ctx, void* dst, const void* src, size_t b
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VSL_OK;
 }
+
+// =================================================================================================
+// bundle_adjustment with BundleAdjustmentOptions::optimize_intrinsics = true (include/visnav/map_utils.h:324, :397-403:
+// the two 8-parameter intrinsics blocks are NOT set constant).  The reference never enables it (a hidden GUI variable,
+// src/slam.cpp:304, :1545), so this path is written for correctness, not for the last microsecond: its own plain
+// Levenberg-Marquardt loop (several host round trips per iteration) over the same restated Ceres policy, the reduced
+// system [poses (6 per free camera) | intrinsics (2 x 8)] assembled densely with fp64 atomics -- the camera-camera part
+// by the large-system kernel above, the intrinsics border by the kernels below -- and solved by the dense Cholesky.
+// The unused trailing parameters of a model have zero Jacobian columns, exactly like Ceres' size-8 block: the LM
+// diagonal floor (1e-6 / radius) keeps the system definite and they keep their values.
+namespace {
+
+// d(u, v) / d intrinsics at the camera-frame point (x, y, z): Gu[8], Gv[8] (camera_models.h project() of the four models)
+__device__ __forceinline__ void project_intr_jac(int model, const double* __restrict__ ip, double x, double y, double z,
+                                                 double* Gu, double* Gv) {
+  const double fx = ip[0], fy = ip[1];
+  for (int j = 0; j < 8; j++) Gu[j] = Gv[j] = 0.0;
+  Gu[2] = 1.0;
+  Gv[3] = 1.0;
+  if (model == VSL_CAM_PINHOLE) {
+    Gu[0] = x / z;
+    Gv[1] = y / z;
+  } else if (model == VSL_CAM_EUCM) {
+    const double alpha = ip[4], beta = ip[5];
+    const double rho2 = x * x + y * y;
+    const double d = sqrt(beta * rho2 + z * z);
+    const double den = alpha * d + (1.0 - alpha) * z;
+    const double id = 1.0 / den, id2 = id * id;
+    Gu[0] = x * id;
+    Gv[1] = y * id;
+    const double dden_da = d - z, dden_db = alpha * rho2 / (2.0 * d);
+    Gu[4] = -fx * x * dden_da * id2; Gv[4] = -fy * y * dden_da * id2;
+    Gu[5] = -fx * x * dden_db * id2; Gv[5] = -fy * y * dden_db * id2;
+  } else if (model == VSL_CAM_KB4) {
+    const double k1 = ip[4], k2 = ip[5], k3 = ip[6], k4 = ip[7];
+    const double r = sqrt(x * x + y * y);
+    if (r == 0.0) return;  // u = cx, v = cy
+    const double th = atan2(r, z);
+    const double t2 = th * th, t3 = t2 * th, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+    const double d = th + k1 * t3 + k2 * t5 + k3 * t7 + k4 * t9;
+    const double xr = x / r, yr = y / r;
+    Gu[0] = d * xr;
+    Gv[1] = d * yr;
+    Gu[4] = fx * xr * t3; Gv[4] = fy * yr * t3;
+    Gu[5] = fx * xr * t5; Gv[5] = fy * yr * t5;
+    Gu[6] = fx * xr * t7; Gv[6] = fy * yr * t7;
+    Gu[7] = fx * xr * t9; Gv[7] = fy * yr * t9;
+  } else {  // double sphere
+    const double xi = ip[4], alpha = ip[5];
+    const double d1 = sqrt(x * x + y * y + z * z);
+    const double k = xi * d1 + z;
+    const double d2 = sqrt(x * x + y * y + k * k);
+    const double den = alpha * d2 + (1.0 - alpha) * k;
+    const double id = 1.0 / den, id2 = id * id;
+    Gu[0] = x * id;
+    Gv[1] = y * id;
+    const double dden_dxi = alpha * (k * d1 / d2) + (1.0 - alpha) * d1, dden_da = d2 - k;
+    Gu[4] = -fx * x * dden_dxi * id2; Gv[4] = -fy * y * dden_dxi * id2;
+    Gu[5] = -fx * x * dden_da * id2;  Gv[5] = -fy * y * dden_da * id2;
+  }
+}
+
+// one thread per observation: robustified residual and the three Jacobian blocks F (2x6, pose tangent), G (2x8,
+// intrinsics), E (2x3, landmark), Jacobi-scaled when `scale` (n camera columns followed by 16 intrinsics columns) is given
+__global__ __launch_bounds__(256) void bai_linearize_kernel(BaDims D, const double* __restrict__ poses,
+                                                            const double* __restrict__ points, const double* __restrict__ intr,
+                                                            const int* __restrict__ cam_intr, const int* __restrict__ cam_free,
+                                                            const int* __restrict__ obs_cam, const int* __restrict__ obs_lm,
+                                                            const double* __restrict__ obs_uv, const double* __restrict__ scale,
+                                                            const double* __restrict__ scale_l, double* __restrict__ r_out,
+                                                            double* __restrict__ F_out, double* __restrict__ E_out,
+                                                            double* __restrict__ G_out, double* __restrict__ partials) {
+  __shared__ double sh[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double c = 0;
+  if (i < D.O) {
+    const int cam = obs_cam[i], lm = obs_lm[i], k = cam_intr[cam], model = k ? D.model1 : D.model0;
+    const double* pose = poses + 7 * (size_t)cam;
+    const double* pw = points + 3 * (size_t)lm;
+    double r[2], F[12], E[6], Gu[8], Gv[8];
+    residual_blocks(model, intr + 8 * k, pose, pw, obs_uv + 2 * (size_t)i, r, F, E, true);
+    {
+      double R[9];
+      quat_R(pose, R);
+      const double d[3] = {pw[0] - pose[4], pw[1] - pose[5], pw[2] - pose[6]};
+      project_intr_jac(model, intr + 8 * k, R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
+                       R[2] * d[0] + R[5] * d[1] + R[8] * d[2], Gu, Gv);
+    }
+    const double s = r[0] * r[0] + r[1] * r[1];
+    double rho0 = s, rho1 = 1.0;
+    if (D.use_huber) huber(s, D.huber, rho0, rho1);
+    c = 0.5 * rho0;
+    const double sr = sqrt(rho1);
+    r_out[2 * (size_t)i] = r[0] * sr;
+    r_out[2 * (size_t)i + 1] = r[1] * sr;
+    const int fc = cam_free[cam];
+    for (int j = 0; j < 6; j++) {
+      const double sc = (scale && fc >= 0) ? scale[6 * fc + j] : 1.0;
+      F_out[12 * (size_t)i + j] = F[j] * sr * sc;
+      F_out[12 * (size_t)i + 6 + j] = F[6 + j] * sr * sc;
+    }
+    for (int j = 0; j < 8; j++) {  // residual = p_2d - projection
+      const double sc = scale ? scale[D.n + 8 * k + j] : 1.0;
+      G_out[16 * (size_t)i + j] = -Gu[j] * sr * sc;
+      G_out[16 * (size_t)i + 8 + j] = -Gv[j] * sr * sc;
+    }
+    for (int j = 0; j < 3; j++) {
+      const double sc = scale_l ? scale_l[3 * (size_t)lm + j] : 1.0;
+      E_out[6 * (size_t)i + j] = E[j] * sr * sc;
+      E_out[6 * (size_t)i + 3 + j] = E[3 + j] * sr * sc;
+    }
+  }
+  const double t = block_sum_256(c, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// squared column norms and gradient J^T r of all columns: cameras + intrinsics in n2 / grad (n + 16), landmarks in
+// n2l / gradl (3 L).  Outputs pre-zeroed.  The 32 intrinsics sums go through LDS first.
+__global__ __launch_bounds__(256) void bai_stats_kernel(BaDims D, const int* __restrict__ cam_free, const int* __restrict__ cam_intr,
+                                                        const int* __restrict__ obs_cam, const int* __restrict__ obs_lm,
+                                                        const double* __restrict__ r, const double* __restrict__ F,
+                                                        const double* __restrict__ E, const double* __restrict__ G,
+                                                        double* __restrict__ n2, double* __restrict__ grad,
+                                                        double* __restrict__ n2l, double* __restrict__ gradl) {
+  __shared__ double acc[32];
+  if (threadIdx.x < 32) acc[threadIdx.x] = 0.0;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D.O) {
+    const int cam = obs_cam[i], fc = cam_free[cam], k = cam_intr[cam], lm = obs_lm[i];
+    const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    const double* g = G + 16 * (size_t)i;
+    if (fc >= 0)
+      for (int j = 0; j < 6; j++) {
+        unsafeAtomicAdd(&n2[6 * fc + j], f[j] * f[j] + f[6 + j] * f[6 + j]);
+        unsafeAtomicAdd(&grad[6 * fc + j], f[j] * r0 + f[6 + j] * r1);
+      }
+    for (int j = 0; j < 8; j++) {
+      unsafeAtomicAdd(&acc[8 * k + j], g[j] * g[j] + g[8 + j] * g[8 + j]);
+      unsafeAtomicAdd(&acc[16 + 8 * k + j], g[j] * r0 + g[8 + j] * r1);
+    }
+    for (int j = 0; j < 3; j++) {
+      unsafeAtomicAdd(&n2l[3 * (size_t)lm + j], e[j] * e[j] + e[3 + j] * e[3 + j]);
+      unsafeAtomicAdd(&gradl[3 * (size_t)lm + j], e[j] * r0 + e[3 + j] * r1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) unsafeAtomicAdd(&n2[D.n + threadIdx.x], acc[threadIdx.x]);
+  else if (threadIdx.x < 32) unsafeAtomicAdd(&grad[D.n + threadIdx.x - 16], acc[threadIdx.x]);
+}
+
+__global__ void bai_make_scale_kernel(int nt, int L3, const double* __restrict__ n2, const double* __restrict__ n2l,
+                                      double* __restrict__ scale, double* __restrict__ scale_l) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nt) scale[i] = 1.0 / (1.0 + sqrt(n2[i]));
+  if (i < L3) scale_l[i] = 1.0 / (1.0 + sqrt(n2l[i]));
+}
+
+__global__ void bai_apply_scale_kernel(BaDims D, const int* __restrict__ cam_free, const int* __restrict__ cam_intr,
+                                       const int* __restrict__ obs_cam, const int* __restrict__ obs_lm,
+                                       const double* __restrict__ scale, const double* __restrict__ scale_l,
+                                       double* __restrict__ F, double* __restrict__ E, double* __restrict__ G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D.O) return;
+  const int cam = obs_cam[i], fc = cam_free[cam], k = cam_intr[cam], lm = obs_lm[i];
+  if (fc >= 0)
+    for (int j = 0; j < 6; j++) {
+      F[12 * (size_t)i + j] *= scale[6 * fc + j];
+      F[12 * (size_t)i + 6 + j] *= scale[6 * fc + j];
+    }
+  for (int j = 0; j < 8; j++) {
+    G[16 * (size_t)i + j] *= scale[D.n + 8 * k + j];
+    G[16 * (size_t)i + 8 + j] *= scale[D.n + 8 * k + j];
+  }
+  for (int j = 0; j < 3; j++) {
+    E[6 * (size_t)i + j] *= scale_l[3 * (size_t)lm + j];
+    E[6 * (size_t)i + 3 + j] *= scale_l[3 * (size_t)lm + j];
+  }
+}
+
+// LM diagonal clamp(||column||^2) of all columns and max |gradient| (one workgroup; scalars[slot] = the maximum)
+__global__ __launch_bounds__(256) void bai_diag_gmax_kernel(int nt, int L3, const double* __restrict__ n2, const double* __restrict__ n2l,
+                                                            const double* __restrict__ grad, const double* __restrict__ gradl,
+                                                            int write_diag, double* __restrict__ diag, double* __restrict__ diag_l,
+                                                            double* __restrict__ scalars, int slot) {
+  __shared__ double sh[256];
+  double m = 0.0;
+  for (int i = threadIdx.x; i < nt; i += 256) {
+    if (write_diag) diag[i] = fmin(fmax(n2[i], 1e-6), 1e32);
+    m = fmax(m, fabs(grad[i]));
+  }
+  for (int i = threadIdx.x; i < L3; i += 256) {
+    if (write_diag) diag_l[i] = fmin(fmax(n2l[i], 1e-6), 1e32);
+    m = fmax(m, fabs(gradl[i]));
+  }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scalars[slot] = sh[0];
+}
+
+// J^T J of the camera side before the Schur correction, and J^T r: pose-pose diagonal blocks, pose-intrinsics blocks
+// (both triangles of the full matrix), intrinsics-intrinsics blocks (through LDS), into S (nt x nt) and rhs (nt)
+__global__ __launch_bounds__(256) void bai_hess_kernel(BaDims D, int nt, const int* __restrict__ cam_free,
+                                                       const int* __restrict__ cam_intr, const int* __restrict__ obs_cam,
+                                                       const double* __restrict__ r, const double* __restrict__ F,
+                                                       const double* __restrict__ G, double* __restrict__ S,
+                                                       double* __restrict__ rhs) {
+  __shared__ double hii[2][64];
+  __shared__ double gi[16];
+  if (threadIdx.x < 128) hii[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
+  if (threadIdx.x < 16) gi[threadIdx.x] = 0.0;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < D.O) {
+    const int cam = obs_cam[i], fc = cam_free[cam], k = cam_intr[cam];
+    const double r0 = r[2 * (size_t)i], r1 = r[2 * (size_t)i + 1];
+    const double* f = F + 12 * (size_t)i;
+    const double* g = G + 16 * (size_t)i;
+    const int ci = D.n + 8 * k;
+    if (fc >= 0) {
+      for (int x = 0; x < 6; x++) {
+        unsafeAtomicAdd(&rhs[6 * fc + x], f[x] * r0 + f[6 + x] * r1);
+        for (int y = 0; y < 6; y++)
+          unsafeAtomicAdd(&S[(size_t)(6 * fc + x) * nt + 6 * fc + y], f[x] * f[y] + f[6 + x] * f[6 + y]);
+        for (int j = 0; j < 8; j++) {
+          const double v = f[x] * g[j] + f[6 + x] * g[8 + j];
+          if (v != 0.0) {
+            unsafeAtomicAdd(&S[(size_t)(6 * fc + x) * nt + ci + j], v);
+            unsafeAtomicAdd(&S[(size_t)(ci + j) * nt + 6 * fc + x], v);
+          }
+        }
+      }
+    }
+    for (int a = 0; a < 8; a++) {
+      unsafeAtomicAdd(&gi[8 * k + a], g[a] * r0 + g[8 + a] * r1);
+      for (int b = 0; b < 8; b++) {
+        const double v = g[a] * g[b] + g[8 + a] * g[8 + b];
+        if (v != 0.0) unsafeAtomicAdd(&hii[k][8 * a + b], v);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int k = threadIdx.x >> 6, e = threadIdx.x & 63, a = e >> 3, b = e & 7;
+    const double v = hii[k][e];
+    if (v != 0.0) unsafeAtomicAdd(&S[(size_t)(D.n + 8 * k + a) * nt + D.n + 8 * k + b], v);
+  } else if (threadIdx.x < 144) {
+    unsafeAtomicAdd(&rhs[D.n + threadIdx.x - 128], gi[threadIdx.x - 128]);
+  }
+}
+
+// Schur correction of the intrinsics border, one wavefront per landmark (P^-1 and b of the landmark come from the
+// camera-camera kernel): W_i = sum_o G_o^T E_o (16 x 3), T = P^-1 W_i^T (3 x 16, kept for the back-substitution);
+//   S_ii -= W_i T,  rhs_i -= T^T b,  S_ci(camera of o) -= (F_o^T E_o) T  (and its mirror)
+__global__ __launch_bounds__(256) void bai_border_kernel(BaDims D, int nt, const int* __restrict__ lm_start,
+                                                         const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
+                                                         const int* __restrict__ cam_intr, const double* __restrict__ F,
+                                                         const double* __restrict__ E, const double* __restrict__ G,
+                                                         const double* __restrict__ Pinv, const double* __restrict__ bl,
+                                                         double* __restrict__ T_out, double* __restrict__ S,
+                                                         double* __restrict__ rhs) {
+  __shared__ double Wi[4][16][3];
+  __shared__ double Ts[4][3][16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = blockIdx.x * 4 + wave;
+  if (l >= D.L) return;
+  const int a = lm_start[l], b = lm_start[l + 1];
+  const double* Pi = Pinv + 9 * (size_t)l;
+  if (lane < 48) {
+    const int col = lane / 3, y = lane - 3 * col, k = col >> 3, j = col & 7;
+    double s = 0.0;
+    for (int i = a; i < b; i++) {
+      if (cam_intr[obs_cam[i]] != k) continue;
+      const double* g = G + 16 * (size_t)i;
+      const double* e = E + 6 * (size_t)i;
+      s += g[j] * e[y] + g[8 + j] * e[3 + y];
+    }
+    Wi[wave][col][y] = s;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 48) {
+    const int y = lane >> 4, col = lane & 15;
+    const double t = Pi[3 * y] * Wi[wave][col][0] + Pi[3 * y + 1] * Wi[wave][col][1] + Pi[3 * y + 2] * Wi[wave][col][2];
+    Ts[wave][y][col] = t;
+    T_out[48 * (size_t)l + 16 * y + col] = t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int e = lane; e < 256; e += 64) {
+    const int c1 = e >> 4, c2 = e & 15;
+    const double v = Wi[wave][c1][0] * Ts[wave][0][c2] + Wi[wave][c1][1] * Ts[wave][1][c2] + Wi[wave][c1][2] * Ts[wave][2][c2];
+    if (v != 0.0) unsafeAtomicAdd(&S[(size_t)(D.n + c1) * nt + D.n + c2], -v);
+  }
+  if (lane < 16) {
+    const double v = Ts[wave][0][lane] * bl[3 * (size_t)l] + Ts[wave][1][lane] * bl[3 * (size_t)l + 1] + Ts[wave][2][lane] * bl[3 * (size_t)l + 2];
+    if (v != 0.0) unsafeAtomicAdd(&rhs[D.n + lane], -v);
+  }
+  for (int item = lane; item < (b - a) * 96; item += 64) {
+    const int q = item / 96, rem = item - 96 * q, x = rem >> 4, c = rem & 15, i = a + q;
+    const int fc = cam_free[obs_cam[i]];
+    if (fc < 0) continue;
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    double v = 0.0;
+    for (int z = 0; z < 3; z++) v += (f[x] * e[z] + f[6 + x] * e[3 + z]) * Ts[wave][z][c];
+    if (v != 0.0) {
+      unsafeAtomicAdd(&S[(size_t)(6 * fc + x) * nt + D.n + c], -v);
+      unsafeAtomicAdd(&S[(size_t)(D.n + c) * nt + 6 * fc + x], -v);
+    }
+  }
+}
+
+__global__ void bai_damp_kernel(int nt, const double* __restrict__ diag, double inv_radius, double* __restrict__ S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nt) S[(size_t)i * nt + i] += diag[i] * inv_radius;
+}
+
+// delta_l = -P^-1 (b_l + sum_o E_o^T (F_o dc + G_o di)); d = [dc (n) | di (16)]
+__global__ __launch_bounds__(256) void bai_backsub_kernel(BaDims D, const int* __restrict__ lm_start, const int* __restrict__ obs_cam,
+                                                          const int* __restrict__ cam_free, const int* __restrict__ cam_intr,
+                                                          const double* __restrict__ F, const double* __restrict__ E,
+                                                          const double* __restrict__ G, const double* __restrict__ Pinv,
+                                                          const double* __restrict__ bl, const double* __restrict__ d,
+                                                          double* __restrict__ dl) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= D.L) return;
+  double t[3] = {bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2]};
+  for (int i = lm_start[l]; i < lm_start[l + 1]; i++) {
+    const int cam = obs_cam[i], fc = cam_free[cam], k = cam_intr[cam];
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    const double* g = G + 16 * (size_t)i;
+    double m0 = 0, m1 = 0;
+    if (fc >= 0)
+      for (int j = 0; j < 6; j++) {
+        m0 += f[j] * d[6 * fc + j];
+        m1 += f[6 + j] * d[6 * fc + j];
+      }
+    for (int j = 0; j < 8; j++) {
+      m0 += g[j] * d[D.n + 8 * k + j];
+      m1 += g[8 + j] * d[D.n + 8 * k + j];
+    }
+    for (int j = 0; j < 3; j++) t[j] += e[j] * m0 + e[3 + j] * m1;
+  }
+  const double* Pi = Pinv + 9 * (size_t)l;
+  for (int j = 0; j < 3; j++) dl[3 * (size_t)l + j] = -(Pi[3 * j] * t[0] + Pi[3 * j + 1] * t[1] + Pi[3 * j + 2] * t[2]);
+}
+
+__global__ __launch_bounds__(256) void bai_model_kernel(BaDims D, const int* __restrict__ obs_cam, const int* __restrict__ obs_lm,
+                                                        const int* __restrict__ cam_free, const int* __restrict__ cam_intr,
+                                                        const double* __restrict__ r, const double* __restrict__ F,
+                                                        const double* __restrict__ E, const double* __restrict__ G,
+                                                        const double* __restrict__ d, const double* __restrict__ dl,
+                                                        double* __restrict__ partials) {
+  __shared__ double sh[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double v = 0;
+  if (i < D.O) {
+    const int cam = obs_cam[i], fc = cam_free[cam], k = cam_intr[cam], lm = obs_lm[i];
+    const double* f = F + 12 * (size_t)i;
+    const double* e = E + 6 * (size_t)i;
+    const double* g = G + 16 * (size_t)i;
+    double m0 = 0, m1 = 0;
+    if (fc >= 0)
+      for (int j = 0; j < 6; j++) {
+        m0 += f[j] * d[6 * fc + j];
+        m1 += f[6 + j] * d[6 * fc + j];
+      }
+    for (int j = 0; j < 8; j++) {
+      m0 += g[j] * d[D.n + 8 * k + j];
+      m1 += g[8 + j] * d[D.n + 8 * k + j];
+    }
+    for (int j = 0; j < 3; j++) {
+      m0 += e[j] * dl[3 * (size_t)lm + j];
+      m1 += e[3 + j] * dl[3 * (size_t)lm + j];
+    }
+    v = -(m0 * (r[2 * (size_t)i] + m0 / 2.0) + m1 * (r[2 * (size_t)i + 1] + m1 / 2.0));
+  }
+  const double t = block_sum_256(v, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// candidate intrinsics = intrinsics + step .* scale; scalars[slot] = squared step norm, scalars[slot + 1] = squared norm
+// of the current intrinsics (both blocks are non-constant parameter blocks)
+__global__ void bai_intr_update_kernel(int n, const double* __restrict__ intr, const double* __restrict__ d,
+                                       const double* __restrict__ scale, double* __restrict__ cand_intr,
+                                       double* __restrict__ scalars, int slot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s2 = 0, x2 = 0;
+  for (int j = 0; j < 16; j++) {
+    const double dd = d[n + j] * scale[n + j];
+    s2 += dd * dd;
+    x2 += intr[j] * intr[j];
+    cand_intr[j] = intr[j] + dd;
+  }
+  scalars[slot] = s2;
+  scalars[slot + 1] = x2;
+}
+
+}  // namespace
+
+extern "C" int vsl_bundle_adjust_intrinsics(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, double* intr_io,
+                                            vsl_ba_summary* summary) {
+  int rc = ba_validate(ctx, prob);
+  if (rc) return rc;
+  if (!opt || !intr_io) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_bundle_adjust_intrinsics: null argument");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  const double t_start = now_ms();
+  vsl_ba_problem p2 = *prob;
+  p2.intr = intr_io;
+  BaState st;
+  if ((rc = ba_setup(ctx, &p2, opt, st))) return rc;
+  const BaDims& D = st.D;
+  const int n = D.n, nt = n + 16, L3 = 3 * D.L;
+  DevBuf G, scale, n2, grad, diag, Sf, rhsf, df, cand_intr, Tl;
+  BA_HIP(G.alloc(8 * 16 * (size_t)D.O));
+  BA_HIP(scale.alloc(8 * (size_t)nt));
+  BA_HIP(n2.alloc(8 * (size_t)nt));
+  BA_HIP(grad.alloc(8 * (size_t)nt));
+  BA_HIP(diag.alloc(8 * (size_t)nt));
+  BA_HIP(Sf.alloc(8 * (size_t)nt * nt));
+  BA_HIP(rhsf.alloc(8 * (size_t)nt));
+  BA_HIP(df.alloc(8 * (size_t)nt));
+  BA_HIP(cand_intr.alloc(8 * 16));
+  BA_HIP(Tl.alloc(8 * 48 * (size_t)D.L));
+  vsl_ba_summary sum;
+  memset(&sum, 0, sizeof(sum));
+  hipStream_t q = ctx->stream;
+  const int nbo = st.nb_obs, nbu = st.nb_upd;
+  double* scal = st.scalars.as<double>();
+
+  auto linearize = [&](bool scaled) -> int {  // at the CURRENT point; scalars[0] = cost
+    hipLaunchKernelGGL(bai_linearize_kernel, dim3(nbo), dim3(256), 0, q, D, st.poses.as<double>(), st.points.as<double>(),
+                       st.intr.as<double>(), st.cam_intr.as<int>(), st.cam_free.as<int>(), st.obs_cam.as<int>(),
+                       st.obs_lm.as<int>(), st.obs_uv.as<double>(), scaled ? scale.as<double>() : (const double*)nullptr,
+                       scaled ? st.scale_l.as<double>() : (const double*)nullptr, st.r.as<double>(), st.F.as<double>(),
+                       st.E.as<double>(), G.as<double>(), st.partials.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, q, st.partials.as<double>(), nbo, scal, 0, 0);
+    VSL_CHECK_LAUNCH(ctx);
+    return VSL_OK;
+  };
+  auto stats = [&](bool write_diag) -> int {  // column norms / gradient of the current blocks; scalars[1] = max |gradient|
+    VSL_HIP(ctx, hipMemsetAsync(n2.p, 0, 8 * (size_t)nt, q));
+    VSL_HIP(ctx, hipMemsetAsync(grad.p, 0, 8 * (size_t)nt, q));
+    VSL_HIP(ctx, hipMemsetAsync(st.n2l.p, 0, 8 * (size_t)L3, q));
+    VSL_HIP(ctx, hipMemsetAsync(st.grad_l.p, 0, 8 * (size_t)L3, q));
+    hipLaunchKernelGGL(bai_stats_kernel, dim3(nbo), dim3(256), 0, q, D, st.cam_free.as<int>(), st.cam_intr.as<int>(),
+                       st.obs_cam.as<int>(), st.obs_lm.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(),
+                       G.as<double>(), n2.as<double>(), grad.as<double>(), st.n2l.as<double>(), st.grad_l.as<double>());
+    hipLaunchKernelGGL(bai_diag_gmax_kernel, dim3(1), dim3(256), 0, q, nt, L3, n2.as<double>(), st.n2l.as<double>(),
+                       grad.as<double>(), st.grad_l.as<double>(), write_diag ? 1 : 0, diag.as<double>(), st.diag_l.as<double>(),
+                       scal, 1);
+    VSL_CHECK_LAUNCH(ctx);
+    return VSL_OK;
+  };
+  double h[16];
+  // initial linearisation, Jacobi scaling from the unscaled column norms (once), statistics of the scaled blocks
+  if ((rc = linearize(false))) return rc;
+  if ((rc = stats(false))) return rc;
+  hipLaunchKernelGGL(bai_make_scale_kernel, dim3((std::max(nt, L3) + 255) / 256), dim3(256), 0, q, nt, L3, n2.as<double>(),
+                     st.n2l.as<double>(), scale.as<double>(), st.scale_l.as<double>());
+  hipLaunchKernelGGL(bai_apply_scale_kernel, dim3(nbo), dim3(256), 0, q, D, st.cam_free.as<int>(), st.cam_intr.as<int>(),
+                     st.obs_cam.as<int>(), st.obs_lm.as<int>(), scale.as<double>(), st.scale_l.as<double>(), st.F.as<double>(),
+                     st.E.as<double>(), G.as<double>());
+  if ((rc = stats(true))) return rc;
+  if ((rc = read_scalars(ctx, st, h, 2))) return rc;
+  double cost = h[0], gmax = h[1];
+  sum.initial_cost = cost;
+  double radius = 1e4, decrease_factor = 2.0;
+  bool have_diag = true;  // stats(true) above wrote the LM diagonal of the current Jacobian
+  int iteration = 0, invalid = 0;
+  sum.termination = 0;
+  if (opt->verbosity >= 2) fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, cost);
+  while (true) {
+    if (iteration >= opt->max_num_iterations) { sum.termination = 0; break; }
+    if (gmax <= 1e-10) { sum.termination = 2; break; }
+    if (radius <= 1e-32) { sum.termination = 4; break; }
+    iteration++;
+    (void)have_diag;
+    const double inv_radius = 1.0 / radius;
+    // reduced system: J^T J of the camera side, damping, Schur corrections (camera-camera, then the border)
+    VSL_HIP(ctx, hipMemsetAsync(Sf.p, 0, 8 * (size_t)nt * nt, q));
+    VSL_HIP(ctx, hipMemsetAsync(rhsf.p, 0, 8 * (size_t)nt, q));
+    hipLaunchKernelGGL(bai_hess_kernel, dim3(nbo), dim3(256), 0, q, D, nt, st.cam_free.as<int>(), st.cam_intr.as<int>(),
+                       st.obs_cam.as<int>(), st.r.as<double>(), st.F.as<double>(), G.as<double>(), Sf.as<double>(),
+                       rhsf.as<double>());
+    hipLaunchKernelGGL(bai_damp_kernel, dim3((nt + 255) / 256), dim3(256), 0, q, nt, diag.as<double>(), inv_radius, Sf.as<double>());
+    hipLaunchKernelGGL(ba_schur_atomic_kernel, dim3((D.L + 3) / 4), dim3(256), 0, q, D, st.lm_start.as<int>(), st.obs_cam.as<int>(),
+                       st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(), st.diag_l.as<double>(),
+                       inv_radius, 0, D.L, Sf.as<double>(), rhsf.as<double>(), st.Pinv.as<double>(), st.bl.as<double>(), 0, nt);
+    hipLaunchKernelGGL(bai_border_kernel, dim3((D.L + 3) / 4), dim3(256), 0, q, D, nt, st.lm_start.as<int>(), st.obs_cam.as<int>(),
+                       st.cam_free.as<int>(), st.cam_intr.as<int>(), st.F.as<double>(), st.E.as<double>(), G.as<double>(),
+                       st.Pinv.as<double>(), st.bl.as<double>(), Tl.as<double>(), Sf.as<double>(), rhsf.as<double>());
+    hipLaunchKernelGGL(ba_set_flags_kernel, dim3(1), dim3(64), 0, q, st.flag.as<int>());
+    if (nt <= 128) {
+      hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, q, nt, Sf.as<double>(), rhsf.as<double>(), df.as<double>(),
+                         st.flag.as<int>() + 1);
+    } else {
+      if ((rc = vsl_chol_solve_band_dev(ctx, Sf.as<double>(), rhsf.as<double>(), nt, nt, nt, st.flag.as<int>() + 1))) return rc;
+      hipLaunchKernelGGL(ba_negate_kernel, dim3((nt + 255) / 256), dim3(256), 0, q, nt, rhsf.as<double>(), df.as<double>());
+    }
+    hipLaunchKernelGGL(bai_backsub_kernel, dim3((D.L + 255) / 256), dim3(256), 0, q, D, st.lm_start.as<int>(), st.obs_cam.as<int>(),
+                       st.cam_free.as<int>(), st.cam_intr.as<int>(), st.F.as<double>(), st.E.as<double>(), G.as<double>(),
+                       st.Pinv.as<double>(), st.bl.as<double>(), df.as<double>(), st.dl.as<double>());
+    hipLaunchKernelGGL(ba_all_finite2_kernel, dim3((std::max(nt, L3) + 255) / 256), dim3(256), 0, q, nt, df.as<double>(), L3,
+                       st.dl.as<double>(), st.flag.as<int>());
+    hipLaunchKernelGGL(bai_model_kernel, dim3(nbo), dim3(256), 0, q, D, st.obs_cam.as<int>(), st.obs_lm.as<int>(),
+                       st.cam_free.as<int>(), st.cam_intr.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(),
+                       G.as<double>(), df.as<double>(), st.dl.as<double>(), st.partials.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, q, st.partials.as<double>(), nbo, scal, 2, 0);
+    // candidate point and its cost
+    hipLaunchKernelGGL(ba_update_kernel, dim3(nbu), dim3(256), 0, q, D, st.cam_free.as<int>(), st.poses.as<double>(),
+                       st.points.as<double>(), df.as<double>(), st.dl.as<double>(), scale.as<double>(), st.scale_l.as<double>(),
+                       st.cand_poses.as<double>(), st.cand_points.as<double>(), st.partials.as<double>(), nbu);
+    hipLaunchKernelGGL(ba_reduce2_kernel, dim3(2), dim3(256), 0, q, st.partials.as<double>(), nbu, scal, 3);
+    hipLaunchKernelGGL(bai_intr_update_kernel, dim3(1), dim3(64), 0, q, n, st.intr.as<double>(), df.as<double>(), scale.as<double>(),
+                       cand_intr.as<double>(), scal, 6);
+    hipLaunchKernelGGL(ba_cost_kernel, dim3(nbo), dim3(256), 0, q, D, st.cand_poses.as<double>(), st.cand_points.as<double>(),
+                       cand_intr.as<double>(), st.cam_intr.as<int>(), st.obs_cam.as<int>(), st.obs_lm.as<int>(),
+                       st.obs_uv.as<double>(), 0, D.O, st.partials.as<double>());
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, q, st.partials.as<double>(), nbo, scal, 5, 0);
+    VSL_CHECK_LAUNCH(ctx);
+    int hflag[2];
+    VSL_HIP(ctx, hipMemcpyAsync(h, scal, sizeof(double) * 8, hipMemcpyDeviceToHost, q));
+    VSL_HIP(ctx, hipMemcpyAsync(hflag, st.flag.p, sizeof(int) * 2, hipMemcpyDeviceToHost, q));
+    VSL_HIP(ctx, hipStreamSynchronize(q));
+    const double model_change = h[2], step_norm = sqrt(h[3] + h[6]), x_norm = sqrt(h[4] + h[7]), cand_cost = h[5];
+    const bool ok = hflag[0] != 0 && hflag[1] != 0 && model_change > 0.0;
+    if (!ok) {
+      if (++invalid >= 5) { sum.termination = 4; break; }
+      radius *= 0.5;
+      if (opt->verbosity >= 2) fprintf(stderr, "%4d  invalid step, radius %.3e\n", iteration, radius);
+      continue;  // the LM diagonal is reused (the Jacobian is unchanged)
+    }
+    invalid = 0;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 3; break; }
+    const double cost_change = cost - cand_cost;
+    if (fabs(cost_change) <= 1e-6 * cost) { sum.termination = 1; break; }
+    const double rel = cost_change / model_change;
+    if (opt->verbosity >= 2)
+      fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", iteration, cand_cost, cost_change, gmax, step_norm, rel, radius);
+    if (rel > 1e-3) {
+      std::swap(st.poses.p, st.cand_poses.p);
+      std::swap(st.points.p, st.cand_points.p);
+      VSL_HIP(ctx, hipMemcpyAsync(st.intr.p, cand_intr.p, 8 * 16, hipMemcpyDeviceToDevice, q));
+      cost = cand_cost;
+      if ((rc = linearize(true))) return rc;
+      if ((rc = stats(true))) return rc;   // new LM diagonal
+      if ((rc = read_scalars(ctx, st, h, 2))) return rc;
+      gmax = h[1];
+      sum.successful_steps++;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+      radius = std::min(1e16, radius);
+      decrease_factor = 2.0;
+    } else {
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+    }
+  }
+  sum.iterations = iteration;
+  sum.final_cost = cost;
+  VSL_HIP(ctx, hipMemcpyAsync(prob->poses, st.poses.p, sizeof(double) * 7 * (size_t)D.C, hipMemcpyDeviceToHost, q));
+  VSL_HIP(ctx, hipMemcpyAsync(prob->points, st.points.p, sizeof(double) * 3 * (size_t)D.L, hipMemcpyDeviceToHost, q));
+  VSL_HIP(ctx, hipMemcpyAsync(intr_io, st.intr.p, sizeof(double) * 16, hipMemcpyDeviceToHost, q));
+  VSL_HIP(ctx, hipStreamSynchronize(q));
+  sum.total_ms = now_ms() - t_start;
+  if (opt->verbosity >= 1)
+    fprintf(stderr, "vsl BA (intrinsics): iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n", sum.iterations,
+            sum.initial_cost, sum.final_cost, sum.termination, sum.total_ms);
+  if (summary) *summary = sum;
+  return VSL_OK;
+}
