@@ -307,7 +307,8 @@ typedef struct vsl_ba_summary {
   int32_t successful_steps;
   int32_t termination;           /* 0 no-convergence(max iters) 1 function tol 2 gradient tol
                                     3 parameter tol 4 failure                      */
-  double linearize_ms, schur_ms, solve_ms, total_ms; /* device time, summed */
+  double linearize_ms, schur_ms, solve_ms; /* device time per stage, summed; 0 unless vsl_ctx_set_profiling(ctx, 1) */
+  double total_ms;                         /* host wall time of the call */
 } vsl_ba_summary;
 
 int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
