@@ -1044,7 +1044,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // `lane` 
 // rows per lane, multiplying by the stored reciprocal pivots.
 #define CH_NB 8
 __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double* __restrict__ S, const double* __restrict__ rhs,
-                                                            double* __restrict__ dc, int* __restrict__ ok_flag) {
+                                                            double* __restrict__ dc, int* __restrict__ ok_flag,
+                                                            int* __restrict__ arm_flag = nullptr) {
   __shared__ double A[128 * 129 + 256];  // static: dynamic LDS above 64 KiB is refused by the runtime
   __shared__ int fail_s;
   const int ld = n | 1;
@@ -1216,7 +1217,10 @@ __global__ __launch_bounds__(256) void ba_chol_small_kernel(int n, const double*
 #ifdef CHS_TIMING
   if (tid == 0) printf("chol_small n %d cycles: load %lld panel-load+barrier %lld factor+solve+store %lld trailing %lld substitutions %lld\n", n, tp[0], tp[1], tp[2], tp[3], tp[4]);
 #endif
-  if (tid == 0) *ok_flag = good ? 1 : 0;
+  if (tid == 0) {
+    *ok_flag = good ? 1 : 0;
+    if (arm_flag) *arm_flag = 1;  // the 'all finite' flag of the step: armed here, cleared by the back-substitution kernel
+  }
 }
 
 __global__ void ba_negate_kernel(int n, const double* __restrict__ y, double* __restrict__ dc) {
@@ -1229,8 +1233,12 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims D, const int* __
                                                          const int* __restrict__ obs_cam, const int* __restrict__ cam_free,
                                                          const double* __restrict__ F, const double* __restrict__ E,
                                                          const double* __restrict__ Pinv, const double* __restrict__ bl,
-                                                         const double* __restrict__ dc, double* __restrict__ dl) {
+                                                         const double* __restrict__ dc, double* __restrict__ dl,
+                                                         int* __restrict__ finite_flag = nullptr) {
   const int l = blockIdx.x * 256 + threadIdx.x;
+  if (finite_flag)  // the camera step is checked here as well (it saves the launch of ba_all_finite2_kernel)
+    for (int j = l; j < D.n; j += gridDim.x * 256)
+      if (!isfinite(dc[j])) *finite_flag = 0;
   if (l >= D.L) return;
   double t[3] = {bl[3 * (size_t)l], bl[3 * (size_t)l + 1], bl[3 * (size_t)l + 2]};
   for (int i = lm_start[l]; i < lm_start[l + 1]; i++) {
@@ -1246,7 +1254,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDims D, const int* __
     for (int j = 0; j < 3; j++) t[j] += e[j] * fd0 + e[3 + j] * fd1;
   }
   const double* Pi = Pinv + 9 * (size_t)l;
-  for (int j = 0; j < 3; j++) dl[3 * (size_t)l + j] = -(Pi[3 * j] * t[0] + Pi[3 * j + 1] * t[1] + Pi[3 * j + 2] * t[2]);
+  for (int j = 0; j < 3; j++) {
+    const double v = -(Pi[3 * j] * t[0] + Pi[3 * j + 1] * t[1] + Pi[3 * j + 2] * t[2]);
+    dl[3 * (size_t)l + j] = v;
+    if (finite_flag && !isfinite(v)) *finite_flag = 0;
+  }
 }
 
 // model cost change partials: -(J d)^T (r + J d / 2)
@@ -1863,11 +1875,11 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
 int ba_solve_enqueue(vsl_ctx* ctx, BaState& st) {
   const int n = st.D.n;
   VslStage s(ctx, VSL_STAGE_BA_SOLVE);
-  hipLaunchKernelGGL(ba_set_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, st.flag.as<int>());
+  if (n == 0 || n > 128) hipLaunchKernelGGL(ba_set_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, st.flag.as<int>());
   if (n == 0) return VSL_OK;
   if (n <= 128) {
     hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, ctx->stream, n, st.S.as<double>(), st.rhs.as<double>(),
-                       st.dc.as<double>(), st.flag.as<int>() + 1);
+                       st.dc.as<double>(), st.flag.as<int>() + 1, st.flag.as<int>());
   } else {
     int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>() + 1);
     if (rc) return rc;
@@ -2073,9 +2085,7 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
       VslStage s(ctx, VSL_STAGE_BA_SOLVE);
       hipLaunchKernelGGL(ba_backsub_kernel, dim3((D.L + 255) / 256), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.F.as<double>(), st.E.as<double>(),
-                         st.Pinv.as<double>(), st.bl.as<double>(), st.dc.as<double>(), st.dl.as<double>());
-      hipLaunchKernelGGL(ba_all_finite2_kernel, dim3((std::max(nc, nl) + 255) / 256), dim3(256), 0, ctx->stream, nc,
-                         st.dc.as<double>(), nl, st.dl.as<double>(), st.flag.as<int>());
+                         st.Pinv.as<double>(), st.bl.as<double>(), st.dc.as<double>(), st.dl.as<double>(), st.flag.as<int>());
       hipLaunchKernelGGL(ba_model_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D, st.obs_cam.as<int>(),
                          st.obs_lm.as<int>(), st.cam_free.as<int>(), st.r.as<double>(), st.F.as<double>(), st.E.as<double>(),
                          st.dc.as<double>(), st.dl.as<double>(), st.partials.as<double>());
