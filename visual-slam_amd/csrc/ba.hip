@@ -1589,8 +1589,26 @@ int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free
   return half;
 }
 
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// set-up phase times on stderr when VSL_BA_TRACE is set (developer aid)
+struct BaTrace {
+  bool on;
+  double t0;
+  BaTrace() : on(getenv("VSL_BA_TRACE") != nullptr), t0(now_ms()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const double t = now_ms();
+    fprintf(stderr, "  [ba set-up] %-28s %8.3f ms\n", what, t - t0);
+    t0 = t;
+  }
+};
+
 int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaState& st, bool allow_band = false,
              const vsl_ba_problem* graph_prob = nullptr) {
+  BaTrace tr;
   BaDims& D = st.D;
   D.C = p->n_cams;
   D.L = p->n_lms;
@@ -1628,6 +1646,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       st.s_elems = (size_t)D.n * (bws + 1) + 64;  // + slack: the diagonal kernels read (never use) a few entries past a row
     }
   }
+  tr.lap("free cameras + band order");
   // sort observations by landmark (stable: keeps the caller's order inside a landmark)
   std::vector<int> lm_start(D.L + 1, 0);
   for (int i = 0; i < D.O; i++) lm_start[p->obs_lm[i] + 1]++;
@@ -1666,6 +1685,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   // so that the blocks of one camera row read one contiguous segment)
   std::vector<int> cam_pos(D.O);
   for (int k = 0; k < D.O; k++) cam_pos[cam_obs[k]] = k;
+  tr.lap("sort + CSRs");
   st.small = D.n <= 128 && D.nfree <= SCH_CMAX && kmax_free <= SCH_KMAX;
   st.nb_obs = (D.O + 255) / 256;
   st.nb_upd = (std::max(D.C, D.L) + 255) / 256;
@@ -1736,6 +1756,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     }
   }
   st.flag.p = (char*)st.scalars.p + 8 * 16;  // behind the 16 scalars: one copy brings both back
+  tr.lap("arena");
   auto up = [&](DevBuf& bf, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpyAsync(bf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
   };
@@ -1753,11 +1774,8 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   BA_HIP(up(st.cam_obs, cam_obs.data(), 4 * O));
   if (!st.small) BA_HIP(up(st.cam_pos, cam_pos.data(), 4 * O));
   BA_HIP(hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors that die here
+  tr.lap("uploads");
   return VSL_OK;
-}
-
-double now_ms() {
-  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // linearize at (poses, points): r, F, E (scaled when `scaled`), cost -> scalars[0]; per-landmark and
@@ -2283,26 +2301,33 @@ extern "C" int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, c
   if (lm_first < 0 || lm_count < 1 || lm_first + lm_count > prob->n_lms)
     return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_session_create: landmark range [%d, %d) must be non-empty and inside [0, %d)", lm_first, lm_first + lm_count, prob->n_lms);
   VSL_HIP(ctx, hipSetDevice(ctx->device));
+  BaTrace tr;
   // sub-problem of the owned landmarks (all cameras)
   std::vector<int32_t> ocam, olm;
   std::vector<double> ouv;
-  for (int i = 0; i < prob->n_obs; i++) {
-    const int l = prob->obs_lm[i];
-    if (l >= lm_first && l < lm_first + lm_count) {
-      ocam.push_back(prob->obs_cam[i]);
-      olm.push_back(l - lm_first);
-      ouv.push_back(prob->obs_uv[2 * (size_t)i]);
-      ouv.push_back(prob->obs_uv[2 * (size_t)i + 1]);
+  const bool whole = lm_first == 0 && lm_count == prob->n_lms;  // one rank: the problem itself, no copy
+  if (!whole) {
+    for (int i = 0; i < prob->n_obs; i++) {
+      const int l = prob->obs_lm[i];
+      if (l >= lm_first && l < lm_first + lm_count) {
+        ocam.push_back(prob->obs_cam[i]);
+        olm.push_back(l - lm_first);
+        ouv.push_back(prob->obs_uv[2 * (size_t)i]);
+        ouv.push_back(prob->obs_uv[2 * (size_t)i + 1]);
+      }
     }
+    if (ocam.empty()) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_session_create: landmark range has no observations");
   }
-  if (ocam.empty()) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ba_session_create: landmark range has no observations");
+  tr.lap("session: sub-problem");
   vsl_ba_problem sub = *prob;
-  sub.n_lms = lm_count;
-  sub.n_obs = (int32_t)ocam.size();
-  sub.points = prob->points + 3 * (size_t)lm_first;
-  sub.obs_cam = ocam.data();
-  sub.obs_lm = olm.data();
-  sub.obs_uv = ouv.data();
+  if (!whole) {
+    sub.n_lms = lm_count;
+    sub.n_obs = (int32_t)ocam.size();
+    sub.points = prob->points + 3 * (size_t)lm_first;
+    sub.obs_cam = ocam.data();
+    sub.obs_lm = olm.data();
+    sub.obs_uv = ouv.data();
+  }
   vsl_ba_session* s = new (std::nothrow) vsl_ba_session;
   if (!s) return vsl_fail(ctx, VSL_ERR_NOMEM, "out of host memory");
   s->ctx = ctx;
