@@ -204,6 +204,7 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
  *   "chol_no_fused" (0/1)           band Cholesky as one launch per panel step instead of the single-launch kernel
+ *   "chol_no_bcr" (0/1)             long narrow bands by the band Cholesky instead of block cyclic reduction
  *   "chol_one_ended" (0/1)          narrow-band Cholesky eliminated from the top only instead of from both ends
  *   "ba_force_dense" (0/1)          large bundle adjustment with the dense reduced camera system (no band ordering)
  *   "ba_schur_atomics" (0/1)        large-system Schur complement by fp64 atomics instead of the per-block gather

@@ -61,25 +61,57 @@ def test_two_ended_elimination_matches_one_ended(ctx, n, bw):
     assert n >= 8 * (bw + 32)
     S = _band_spd(n, bw, 3 * n + bw)
     b = np.random.default_rng(n - bw).standard_normal(n)
-    x2 = ctx.spd_solve(S, b, bw)
-    ctx.set_diagnostic("chol_one_ended", 1)
+    ctx.set_diagnostic("chol_no_bcr", 1)   # (long bands default to block cyclic reduction: next test)
     try:
+        x2 = ctx.spd_solve(S, b, bw)
+        ctx.set_diagnostic("chol_one_ended", 1)
         x1 = ctx.spd_solve(S, b, bw)
     finally:
         ctx.set_diagnostic("chol_one_ended", 0)
+        ctx.set_diagnostic("chol_no_bcr", 0)
     assert _residual(S, x2, b) < 1e-10 and _residual(S, x1, b) < 1e-10
     assert np.allclose(x2, x1, rtol=1e-9, atol=1e-12)
     assert np.allclose(x2, np.linalg.solve(S, b), rtol=1e-8, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,bw", [(300, 20), (700, 20), (701, 31), (2000, 100), (2017, 100), (3000, 37), (1500, 150), (2100, 255),
+                                  (5988, 221)])
+def test_block_cyclic_reduction_matches_band_cholesky(ctx, n, bw):
+    # long narrow bands (n >= 8 blocks of B = ceil((bw + 1) / 32) * 32 <= 256 unknowns) are solved by block cyclic
+    # reduction: odd and even block counts, a ragged last block (identity-padded), block sizes from 32 to 256, and the
+    # size of BASELINE configs[4]; same solution as the band Cholesky and as numpy
+    B = (bw + 1 + 31) // 32 * 32
+    assert n >= 8 * B and B <= 256
+    S = _band_spd(n, bw, 5 * n + bw)
+    b = np.random.default_rng(n + 3 * bw).standard_normal(n)
+    x = ctx.spd_solve(S, b, bw)
+    ctx.set_diagnostic("chol_no_bcr", 1)
+    try:
+        xb = ctx.spd_solve(S, b, bw)
+    finally:
+        ctx.set_diagnostic("chol_no_bcr", 0)
+    assert _residual(S, x, b) < 1e-10
+    assert np.allclose(x, xb, rtol=1e-9, atol=1e-12)
+    if n <= 3000:
+        assert np.allclose(x, np.linalg.solve(S, b), rtol=1e-8, atol=1e-11)
+    x_again = ctx.spd_solve(S, b, bw)
+    assert np.array_equal(x, x_again)  # no atomics anywhere: bit-identical reruns
+
+
 @pytest.mark.parametrize("where", [40, 1003, 1990])
-def test_two_ended_elimination_reports_a_bad_pivot_anywhere(ctx, vsl, where):
-    # a negative diagonal entry in the top chunk, in the separator, in the bottom chunk
+@pytest.mark.parametrize("no_bcr", [0, 1])
+def test_long_band_solvers_report_a_bad_pivot_anywhere(ctx, vsl, where, no_bcr):
+    # a negative diagonal entry near the top, in the middle (the separator of the two-ended form), near the bottom --
+    # through block cyclic reduction (different blocks / levels) and through the two-ended band Cholesky
     n, bw = 2000, 60
     S = _band_spd(n, bw, 9)
     S[where, where] = -1.0
-    with pytest.raises(vsl.VslError) as e:
-        ctx.spd_solve(S, np.ones(n), bw)
+    ctx.set_diagnostic("chol_no_bcr", no_bcr)
+    try:
+        with pytest.raises(vsl.VslError) as e:
+            ctx.spd_solve(S, np.ones(n), bw)
+    finally:
+        ctx.set_diagnostic("chol_no_bcr", 0)
     assert e.value.code == -7
 
 

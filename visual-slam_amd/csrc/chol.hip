@@ -663,12 +663,18 @@ __global__ __launch_bounds__(CBF_THREADS) void cbf2_backward_kernel(CbfView top,
     cbf_backward<true>(rev, k_end_rev, sh);
 }
 
+#define BCR_MAXB 256  // block size limit of the cyclic reduction: static LDS Us[256][33] + Lp[32][257] = 133 KB (dynamic LDS above 64 KiB is refused by the runtime)
+int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev);
+
 // Solves S x = b in place (S destroyed, b <- x).  *ok_dev = 1 on success, 0 if S is not SPD.
 // Dense: ld = n, bw = n.  Band: S = storage + bws, ld = bws = bw + CH_NB (see the file header); bw = the largest
 // i - c of a non-zero entry.
 int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
   const int one = 1;
   const int n_panels = (n + CH_NB - 1) / CH_NB;
+  if (ld != n && !ctx->chol_no_fused && !ctx->chol_no_bcr && (bw + 1 + 31) / 32 * 32 <= BCR_MAXB &&
+      n >= 8 * ((bw + 1 + 31) / 32 * 32))  // long narrow band: block cyclic reduction over the whole chip
+    return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev);
   if (ld != n && bw <= CBF_MAXBW && !ctx->chol_no_fused) {  // narrow band: one launch for the whole solve, or two-ended
     VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     const bool two_ended = !ctx->chol_one_ended && bw + CH_NB - 1 <= CBF_MAXBW && n >= 8 * (bw + CH_NB);
@@ -797,5 +803,402 @@ extern "C" int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int
   if (e != hipSuccess) return vsl_fail(ctx, VSL_ERR_HIP, "vsl_spd_solve: %s", hipGetErrorString(e));
   if (rc != VSL_OK) return rc;
   if (!ok) return vsl_fail(ctx, VSL_ERR_NUMERIC, "vsl_spd_solve: matrix is not positive definite");
+  return VSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BLOCK CYCLIC REDUCTION of a long narrow band (n >= 8 blocks of B >= bw + 1 unknowns).  The band Cholesky above is a
+// chain of n / 32 dependent panel steps on one compute unit (two with the two-ended form); cutting the band into
+// blocks of B unknowns makes it block tridiagonal, and eliminating every other block is independent work:
+//   level 0: blocks 1, 3, 5, ... are factored at once (one workgroup each, the single-workgroup kernel on a dense B x B
+//   block), their Schur updates D_p -= U1^T U1, D_q -= U2^T U2 and the fill K(q, p) = -U2^T U1 between their two
+//   neighbours (U1 = L_e^-1 K(e, p), U2 = L_e^-1 K(q, e)^T) are dense B x B products spread over the chip; the
+//   remaining blocks 0, 2, 4, ... are block tridiagonal again, and so on: log2(n / B) levels whose critical path is one
+//   dense B x B Cholesky each instead of n / 32 panel steps -- at 2.7 x the flops.  It is the Cholesky factorisation
+//   under a nested-dissection ordering of the blocks: no pivoting issues for an SPD matrix, no atomics, reproducible.
+// The right-hand side rides along (z_e = L_e^-1 b_e, b_p -= U1^T z_e, b_q -= U2^T z_e) and the solution is recovered
+// level by level in reverse: x_e = L_e^-T (z_e - U1 x_p - U2 x_q).
+struct BcrJob {
+  int e, p, q;      // eliminated block and its two active neighbours (q = -1: none below)
+  int kp, kq;       // indices of K(e, p) and K(q, e) in this level's coupling array
+  int knew;         // index of K(q, p) in the next level's coupling array (-1: none)
+  int u;            // slot of U1 / U2
+};
+
+// band storage -> dense blocks: D[i] (lower triangle, identity-padded past n), C[i] = block (i + 1, i), b[i]
+__global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, int bws, const double* __restrict__ b, int B,
+                                   int nblk, double* __restrict__ D, double* __restrict__ C, double* __restrict__ bb) {
+  const int blk = blockIdx.y;
+  const size_t BB = (size_t)B * B;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * B; idx += gridDim.x * blockDim.x) {
+    const int r = idx / B, c = idx - r * B;
+    const int gi = blk * B + r, gc = blk * B + c;
+    double d = 0.0;
+    if (gi < n && gc < n) {
+      if (c <= r) d = A[(size_t)gi * ld + gc];  // r - c <= B - 1 <= bws: inside the row's slots (zeros beyond the band)
+    } else if (r == c) {
+      d = 1.0;
+    }
+    D[blk * BB + idx] = d;
+    if (blk + 1 < nblk) {
+      const int gr = (blk + 1) * B + r;
+      C[blk * BB + idx] = (gr < n && gr - gc <= bws) ? A[(size_t)gr * ld + gc] : 0.0;
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int r = threadIdx.x; r < B; r += blockDim.x) bb[(size_t)blk * B + r] = blk * B + r < n ? b[blk * B + r] : 0.0;
+}
+
+// dense Cholesky of the blocks jobs[].e of one level + z = L^-1 b (in y), by the single-workgroup band kernel
+__global__ __launch_bounds__(CBF_THREADS) void bcr_chol_kernel(const BcrJob* __restrict__ jobs, int B, double* __restrict__ D,
+                                                               double* __restrict__ bb, double* __restrict__ yy,
+                                                               double* __restrict__ dinv, int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  const int e = jobs[blockIdx.x].e;
+  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B};
+  if (!cbf_factor<false>(v, B, sh) && threadIdx.x == 0) *ok = 0;
+}
+
+// the last remaining block: the whole solve
+__global__ __launch_bounds__(CBF_THREADS) void bcr_last_kernel(int e, int B, double* __restrict__ D, double* __restrict__ bb,
+                                                               double* __restrict__ yy, double* __restrict__ dinv,
+                                                               int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  if (!*ok) return;
+  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B};
+  if (!cbf_factor<false>(v, B, sh)) {
+    if (threadIdx.x == 0) *ok = 0;
+    return;
+  }
+  cbf_backward<false>(v, B, sh);
+}
+
+// inverses of the 32 x 32 diagonal blocks of the factors of one level (one wavefront per block: lane = row of L in
+// registers, column broadcasts by v_readlane, lane j solves L x = e_j): they turn the triangular part of the solves
+// below into small dense products.  Linv[(job * B / 32 + blk) * 1024 + r * 32 + c]
+__global__ __launch_bounds__(64) void bcr_dinv_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ D,
+                                                      const double* __restrict__ dinv, double* __restrict__ Linv,
+                                                      const int* __restrict__ ok) {
+  if (!*ok) return;
+  const BcrJob jb = jobs[blockIdx.x];
+  const int blk = blockIdx.y, lane = threadIdx.x & 31, k0 = 32 * blk;
+  const double* L = D + (size_t)jb.e * B * B;
+  double r[32], x[32];
+#pragma unroll
+  for (int c = 0; c < 32; c++) r[c] = c <= lane ? L[(size_t)(k0 + lane) * B + k0 + c] : 0.0;
+  const double* di = dinv + (size_t)jb.e * B + k0;
+#pragma unroll
+  for (int rr = 0; rr < 32; rr++) {
+    double t = (rr == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = 0; p < rr; p++) t -= lane_bcast(r[p], rr) * x[p];
+    x[rr] = (rr < lane) ? 0.0 : t * di[rr];
+  }
+  double* out = Linv + ((size_t)blockIdx.x * (B / 32) + blk) * 1024;
+  if (threadIdx.x < 32) {
+#pragma unroll
+    for (int rr = 0; rr < 32; rr++) out[rr * 32 + lane] = x[rr];
+  }
+}
+
+// U = L_e^-1 R for 32 right-hand-side columns per workgroup: tiles 0 .. B/32 - 1 are columns of R1 = K(e, p), the next
+// B/32 columns of R2 = K(q, e)^T.  Forward substitution by 32-row panels of L: the panel's product with the rows
+// already solved by all 256 threads, its 32 x 32 diagonal part by one thread per column.
+__global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ D,
+                                                       const double* __restrict__ Linv, const double* __restrict__ K,
+                                                       double* __restrict__ U, const int* __restrict__ ok) {
+  if (!*ok) return;
+  __shared__ double Us[BCR_MAXB * 33];
+  __shared__ double Lp[32 * (BCR_MAXB + 1)];
+  const BcrJob jb = jobs[blockIdx.x];
+  const int tiles = B / 32, tile = blockIdx.y;
+  const bool second = tile >= tiles;
+  if (second && jb.q < 0) return;
+  const int c0 = 32 * (second ? tile - tiles : tile);
+  const size_t BB = (size_t)B * B;
+  const double* L = D + (size_t)jb.e * BB;
+  const double* Li = Linv + (size_t)blockIdx.x * (B / 32) * 1024;
+  __shared__ double Ls[32 * 33];
+  const double* R = K + (size_t)(second ? jb.kq : jb.kp) * BB;
+  double* Uo = U + ((size_t)2 * jb.u + (second ? 1 : 0)) * BB;
+  const int tid = threadIdx.x;
+  // the right-hand-side tile into Us: R1[r][c0 + c], or R2[r][c0 + c] = K(q, e)[c0 + c][r]
+  // (all global loads eight at a time: as one-element loops every load waited for the previous one -- 28 dependent
+  // round trips per panel)
+  if (!second) {
+    for (int r0 = tid >> 5; r0 < B; r0 += 64) {  // 8 rows per thread per round, 32 contiguous doubles per row
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = r0 + 8 * u < B ? R[(size_t)(r0 + 8 * u) * B + c0 + (tid & 31)] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (r0 + 8 * u < B) Us[(r0 + 8 * u) * 33 + (tid & 31)] = v[u];
+    }
+  } else {
+    for (int cc = 0; cc < 32; cc += 8) {  // R2[r][c0 + c] = K(q, e)[c0 + c][r]: a row of K per column, contiguous in r = tid
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = tid < B ? R[(size_t)(c0 + cc + u) * B + tid] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tid < B) Us[tid * 33 + cc + u] = v[u];
+    }
+  }
+  __syncthreads();
+  const int col = tid & 31, grp = tid >> 5;  // 8 groups x 4 rows of a panel
+  for (int p0 = 0; p0 < B; p0 += 32) {
+    for (int rr0 = 0; rr0 < 32; rr0 += 8) {  // the panel's rows of L left of its diagonal block: column k = tid (B <= 256)
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = tid < p0 ? L[(size_t)(p0 + rr0 + u) * B + tid] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tid < p0) Lp[(rr0 + u) * (B + 1) + tid] = v[u];
+    }
+    __syncthreads();
+    double acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) acc[a] = Us[(p0 + 4 * grp + a) * 33 + col];
+    for (int k = 0; k < p0; k++) {
+      const double u = Us[k * 33 + col];
+#pragma unroll
+      for (int a = 0; a < 4; a++) acc[a] -= Lp[(4 * grp + a) * (B + 1) + k] * u;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) Us[(p0 + 4 * grp + a) * 33 + col] = acc[a];
+    __syncthreads();
+    // the 32 x 32 diagonal part: U_p = Linv_pp T_p, a dense product (all threads)
+    for (int idx = tid; idx < 1024; idx += 256) Ls[(idx >> 5) * 33 + (idx & 31)] = Li[(size_t)(p0 >> 5) * 1024 + idx];
+    __syncthreads();
+    {
+      double o[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+      for (int k = 0; k < 32; k++) {
+        const double t = Us[(p0 + k) * 33 + col];
+#pragma unroll
+        for (int a = 0; a < 4; a++) o[a] += Ls[(4 * grp + a) * 33 + k] * t;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; a++) Us[(p0 + 4 * grp + a) * 33 + col] = o[a];
+    }
+    __syncthreads();
+  }
+  for (int r = tid >> 5; r < B; r += 8) Uo[(size_t)r * B + c0 + (tid & 31)] = Us[r * 33 + (tid & 31)];
+}
+
+// C (B x B) = C - M^T N   (mode 0: D_p -= U1^T U1, lower tiles only; mode 1: D_q -= U2^T U2, lower tiles only) or
+// K(q, p) = -U2^T U1 (mode 2, all tiles): one 32 x 32 tile per workgroup, the two 32-column slabs of M and N in LDS
+__global__ __launch_bounds__(256) void bcr_gemm_kernel(const BcrJob* __restrict__ jobs, int B, int mode, const double* __restrict__ U,
+                                                       double* __restrict__ D, double* __restrict__ Knext,
+                                                       const int* __restrict__ ok) {
+  if (!*ok) return;
+  __shared__ double Ms[BCR_MAXB * 33];
+  __shared__ double Ns[BCR_MAXB * 33];
+  const BcrJob jb = jobs[blockIdx.x];
+  const int tiles = B / 32, ti = blockIdx.y / tiles, tj = blockIdx.y - ti * tiles;
+  if (mode != 2 && tj > ti) return;
+  if (mode != 0 && jb.q < 0) return;
+  if (mode == 2 && jb.knew < 0) return;
+  const size_t BB = (size_t)B * B;
+  const double* U1 = U + (size_t)2 * jb.u * BB;
+  const double* U2 = U1 + BB;
+  const double* M = mode == 0 ? U1 : U2;
+  const double* N = mode == 1 ? U2 : U1;
+  const int tid = threadIdx.x;
+  for (int r0 = tid >> 5; r0 < B; r0 += 32) {  // 4 rows of both slabs per thread per round (eight loads in flight)
+    double vm[4], vn[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + 8 * u;
+      vm[u] = r < B ? M[(size_t)r * B + 32 * ti + (tid & 31)] : 0.0;
+      vn[u] = r < B ? N[(size_t)r * B + 32 * tj + (tid & 31)] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + 8 * u;
+      if (r < B) {
+        Ms[r * 33 + (tid & 31)] = vm[u];
+        Ns[r * 33 + (tid & 31)] = vn[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int i0 = (tid >> 4) * 2, j0 = (tid & 15) * 2;  // a 2 x 2 patch of the tile per thread
+  double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+  for (int k = 0; k < B; k++) {
+    const double m0 = Ms[k * 33 + i0], m1 = Ms[k * 33 + i0 + 1], n0 = Ns[k * 33 + j0], n1 = Ns[k * 33 + j0 + 1];
+    a00 += m0 * n0;
+    a01 += m0 * n1;
+    a10 += m1 * n0;
+    a11 += m1 * n1;
+  }
+  double* Cb = mode == 0 ? D + (size_t)jb.p * BB : (mode == 1 ? D + (size_t)jb.q * BB : Knext + (size_t)jb.knew * BB);
+  const int gi = 32 * ti + i0, gj = 32 * tj + j0;
+  if (mode == 2) {
+    Cb[(size_t)gi * B + gj] = -a00;
+    Cb[(size_t)gi * B + gj + 1] = -a01;
+    Cb[(size_t)(gi + 1) * B + gj] = -a10;
+    Cb[(size_t)(gi + 1) * B + gj + 1] = -a11;
+  } else {
+    Cb[(size_t)gi * B + gj] -= a00;
+    Cb[(size_t)gi * B + gj + 1] -= a01;   // (entries above the diagonal of a diagonal tile are never read)
+    Cb[(size_t)(gi + 1) * B + gj] -= a10;
+    Cb[(size_t)(gi + 1) * B + gj + 1] -= a11;
+  }
+}
+
+// right-hand sides of the neighbours: side = blockIdx.y: 0: b_p -= U1^T z_e; 1: b_q -= U2^T z_e.  (Two launches, one per
+// side: the q of one job is the p of the next.)  1024 threads = 4 row slices x 256 columns, coalesced along the columns.
+__global__ __launch_bounds__(1024) void bcr_rhs_kernel(const BcrJob* __restrict__ jobs, int B, int side, const double* __restrict__ U,
+                                                       const double* __restrict__ yy, double* __restrict__ bb,
+                                                       const int* __restrict__ ok) {
+  __shared__ double part[4][BCR_MAXB];
+  if (!*ok) return;
+  const BcrJob jb = jobs[blockIdx.x];
+  const int tgt = side == 0 ? jb.p : jb.q;
+  if (tgt < 0) return;
+  const double* Um = U + ((size_t)2 * jb.u + side) * B * B;
+  const double* z = yy + (size_t)jb.e * B;
+  const int c = threadIdx.x & 255, sl = threadIdx.x >> 8;
+  double s = 0.0;
+  if (c < B)
+    for (int r = sl; r < B; r += 4) s += Um[(size_t)r * B + c] * z[r];
+  part[sl][c] = s;
+  __syncthreads();
+  if (sl == 0 && c < B) bb[(size_t)tgt * B + c] -= (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+
+// solution of an eliminated block: y_e <- z_e - U1 x_p - U2 x_q, then L_e^T x_e = y_e (x_e overwrites b_e)
+__global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __restrict__ jobs, int B, double* __restrict__ D,
+                                                               const double* __restrict__ U, double* __restrict__ bb,
+                                                               double* __restrict__ yy, double* __restrict__ dinv,
+                                                               const int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  if (!*ok) return;
+  const BcrJob jb = jobs[blockIdx.x];
+  const size_t BB = (size_t)B * B;
+  const double* U1 = U + (size_t)2 * jb.u * BB;
+  const double* U2 = U1 + BB;
+  const double* xp = bb + (size_t)jb.p * B;
+  const double* xq = jb.q >= 0 ? bb + (size_t)jb.q * B : nullptr;
+  double* y = yy + (size_t)jb.e * B;
+  {  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < B; r += CBF_THREADS / 64) {
+      double s = 0.0;
+      for (int c = lane; c < B; c += 64) {
+        s += U1[(size_t)r * B + c] * xp[c];
+        if (xq) s += U2[(size_t)r * B + c] * xq[c];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) y[r] -= s;
+    }
+  }
+  __syncthreads();
+  CbfView v = {D + (size_t)jb.e * BB, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)jb.e * B, y, dinv + (size_t)jb.e * B};
+  cbf_backward<false>(v, B, sh);
+}
+
+__global__ void bcr_gather_kernel(const double* __restrict__ bb, int n, double* __restrict__ b, const int* __restrict__ ok) {
+  if (!*ok) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = bb[i];
+}
+
+// S (band storage, n unknowns, half bandwidth bw) x = b by block cyclic reduction; b <- x
+int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
+  const int B = (bw + 1 + 31) / 32 * 32, nblk = (n + B - 1) / B;
+  const size_t BB = (size_t)B * B;
+  // levels on the host: active block lists, jobs
+  std::vector<std::vector<BcrJob>> levels;
+  std::vector<int> active(nblk), ncoup;
+  for (int i = 0; i < nblk; i++) active[i] = i;
+  int n_u = 0;
+  while (active.size() > 1) {
+    const int m = (int)active.size();
+    std::vector<BcrJob> jobs;
+    std::vector<int> next;
+    for (int j = 0; j < m; j++) {
+      if (j & 1) {
+        BcrJob jb;
+        jb.e = active[j];
+        jb.p = active[j - 1];
+        jb.q = j + 1 < m ? active[j + 1] : -1;
+        jb.kp = j - 1;
+        jb.kq = j;
+        jb.knew = j + 1 < m ? (j - 1) / 2 : -1;
+        jb.u = n_u++;
+        jobs.push_back(jb);
+      } else {
+        next.push_back(active[j]);
+      }
+    }
+    ncoup.push_back(m - 1);
+    levels.push_back(jobs);
+    active = next;
+  }
+  const int last = active[0];
+  size_t n_k = 0, n_jobs = 0;
+  for (size_t l = 0; l < levels.size(); l++) {
+    n_k += (size_t)ncoup[l];
+    n_jobs += levels[l].size();
+  }
+  // scratch: D | K (all levels) | U | bb | yy | dinv | jobs
+  size_t max_nj = 1;
+  for (auto& lv : levels) max_nj = std::max(max_nj, lv.size());
+  const size_t linv_doubles = max_nj * (size_t)(B / 32) * 1024;
+  const size_t doubles = (size_t)nblk * BB + n_k * BB + (size_t)2 * n_u * BB + 3 * (size_t)nblk * B + linv_doubles + 16;
+  const size_t job_bytes = (n_jobs + 1) * sizeof(BcrJob);
+  void* ws = nullptr;
+  int rc = vsl_ctx_dscratch(ctx, sizeof(double) * doubles + job_bytes + 256, &ws);
+  if (rc) return rc;
+  double* D = (double*)ws;
+  double* K0 = D + (size_t)nblk * BB;
+  double* U = K0 + n_k * BB;
+  double* bb = U + (size_t)2 * n_u * BB;
+  double* yy = bb + (size_t)nblk * B;
+  double* dinv = yy + (size_t)nblk * B;
+  double* Linv = dinv + (size_t)nblk * B;
+  BcrJob* jobs_dev = (BcrJob*)(((uintptr_t)(Linv + linv_doubles + 16) + 63) & ~(uintptr_t)63);
+  std::vector<BcrJob> flat;
+  std::vector<size_t> job_off, k_off;
+  {
+    size_t ko = 0;
+    for (size_t l = 0; l < levels.size(); l++) {
+      job_off.push_back(flat.size());
+      k_off.push_back(ko);
+      flat.insert(flat.end(), levels[l].begin(), levels[l].end());
+      ko += (size_t)ncoup[l];
+    }
+  }
+  const int one = 1;
+  VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipMemcpyAsync(jobs_dev, flat.data(), flat.size() * sizeof(BcrJob), hipMemcpyHostToDevice, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` and `one` are on this stack frame
+  hipStream_t q = ctx->stream;
+  hipLaunchKernelGGL(bcr_extract_kernel, dim3(16, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, D, K0, bb);
+  const int tiles = B / 32;
+  for (size_t l = 0; l < levels.size(); l++) {
+    const int nj = (int)levels[l].size();
+    const BcrJob* jl = jobs_dev + job_off[l];
+    double* Kl = K0 + k_off[l] * BB;
+    double* Kn = l + 1 < levels.size() ? K0 + k_off[l + 1] * BB : nullptr;
+    hipLaunchKernelGGL(bcr_chol_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jl, B, D, bb, yy, dinv, ok_dev);
+    hipLaunchKernelGGL(bcr_dinv_kernel, dim3(nj, tiles), dim3(64), 0, q, jl, B, D, dinv, Linv, ok_dev);
+    hipLaunchKernelGGL(bcr_trsm_kernel, dim3(nj, 2 * tiles), dim3(256), 0, q, jl, B, D, Linv, Kl, U, ok_dev);
+    for (int mode = 0; mode < 3; mode++)
+      if (mode != 2 || Kn) hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles), dim3(256), 0, q, jl, B, mode, U, D, Kn, ok_dev);
+    hipLaunchKernelGGL(bcr_rhs_kernel, dim3(nj), dim3(1024), 0, q, jl, B, 0, U, yy, bb, ok_dev);
+    hipLaunchKernelGGL(bcr_rhs_kernel, dim3(nj), dim3(1024), 0, q, jl, B, 1, U, yy, bb, ok_dev);
+  }
+  hipLaunchKernelGGL(bcr_last_kernel, dim3(1), dim3(CBF_THREADS), 0, q, last, B, D, bb, yy, dinv, ok_dev);
+  for (size_t l = levels.size(); l-- > 0;) {
+    const int nj = (int)levels[l].size();
+    hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, U, bb, yy, dinv, ok_dev);
+  }
+  hipLaunchKernelGGL(bcr_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, q, bb, n, b, ok_dev);
+  VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }

@@ -23,6 +23,7 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "ba_schur_atomics") ctx->ba_schur_atomics = value != 0;
   else if (k == "ba_force_dense") ctx->ba_force_dense = value != 0;
   else if (k == "chol_no_fused") ctx->chol_no_fused = value != 0;
+  else if (k == "chol_no_bcr") ctx->chol_no_bcr = value != 0;
   else if (k == "chol_one_ended") ctx->chol_one_ended = value != 0;
   else if (k == "select_bucket_cap") ctx->select_bucket_cap = value < 0 ? 0 : value;
   else return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_ctx_set_diagnostic: unknown knob '%s'", name);

@@ -58,6 +58,7 @@ struct vsl_ctx {
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
+  bool chol_no_bcr = false;             // diagnostic: long narrow bands by the (two-ended) band Cholesky instead of block cyclic reduction
   bool chol_one_ended = false;          // diagnostic: narrow-band Cholesky by one workgroup from the top only (no two-ended split)
   bool chol_no_fused = false;           // diagnostic: band Cholesky as one launch per panel step instead of the fused single-launch kernel
   bool ba_force_dense = false;          // diagnostic: dense reduced camera system even where the band form applies
