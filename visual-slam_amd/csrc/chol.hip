@@ -249,6 +249,8 @@ struct CbfView {
   double* b;       // right-hand side / solution of the full system
   double* y;       // per view: intermediate vector and 1 / pivot, by view index
   double* dinv;
+  const double* pend0 = nullptr;  // plain view only: right-hand-side updates still to be subtracted when an entry is
+  const double* pend1 = nullptr;  //   staged (block cyclic reduction: two slots per block)
 };
 
 // SEP (compile time): the step's window reaches the separator rows of a reversed view, whose mutual entries and
@@ -336,12 +338,13 @@ __device__ __forceinline__ void cbf_stage(const CbfView& v, double (*W)[CH_NB + 
           if (cc < nb) ptr[u] = cbf_at<REV, SEP>(v, k + nb + r - CH_NB, k + cc);
         } else if (cc < nb) {
           ptr[u] = cbf_rhs<REV, SEP>(v, k + cc);
+          if (!REV && v.pend0) val[u] = -(v.pend0[k + cc] + v.pend1[k + cc]);
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < 8; u++)
-      if (ptr[u]) val[u] = *ptr[u];
+      if (ptr[u]) val[u] += *ptr[u];
 #pragma unroll
     for (int u = 0; u < 8; u++)
       if (ok[u]) W[row[u]][c[u]] = val[u];
@@ -827,7 +830,8 @@ struct BcrJob {
 
 // band storage -> dense blocks: D[i] (lower triangle, identity-padded past n), C[i] = block (i + 1, i), b[i]
 __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, int bws, const double* __restrict__ b, int B,
-                                   int nblk, double* __restrict__ D, double* __restrict__ C, double* __restrict__ bb) {
+                                   int nblk, double* __restrict__ D, double* __restrict__ C, double* __restrict__ bb,
+                                   double* __restrict__ pend) {
   const int blk = blockIdx.y;
   const size_t BB = (size_t)B * B;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * B; idx += gridDim.x * blockDim.x) {
@@ -846,26 +850,35 @@ __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, 
     }
   }
   if (blockIdx.x == 0)
-    for (int r = threadIdx.x; r < B; r += blockDim.x) bb[(size_t)blk * B + r] = blk * B + r < n ? b[blk * B + r] : 0.0;
+    for (int r = threadIdx.x; r < B; r += blockDim.x) {
+      bb[(size_t)blk * B + r] = blk * B + r < n ? b[blk * B + r] : 0.0;
+      pend[((size_t)2 * blk) * B + r] = 0.0;
+      pend[((size_t)2 * blk + 1) * B + r] = 0.0;
+    }
 }
 
 // dense Cholesky of the blocks jobs[].e of one level + z = L^-1 b (in y), by the single-workgroup band kernel
 __global__ __launch_bounds__(CBF_THREADS) void bcr_chol_kernel(const BcrJob* __restrict__ jobs, int B, double* __restrict__ D,
                                                                double* __restrict__ bb, double* __restrict__ yy,
-                                                               double* __restrict__ dinv, int* __restrict__ ok) {
+                                                               double* __restrict__ dinv, const double* __restrict__ pend,
+                                                               int* __restrict__ ok) {
   __shared__ CbfShared sh;
   const int e = jobs[blockIdx.x].e;
-  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B};
+  // the right-hand-side updates this block received from eliminated neighbours (two slots: from the neighbour above and
+  // from the one below, each written by one workgroup per level) are subtracted where the panel's entries are staged
+  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B,
+               pend + ((size_t)2 * e) * B, pend + ((size_t)2 * e + 1) * B};
   if (!cbf_factor<false>(v, B, sh) && threadIdx.x == 0) *ok = 0;
 }
 
 // the last remaining block: the whole solve
 __global__ __launch_bounds__(CBF_THREADS) void bcr_last_kernel(int e, int B, double* __restrict__ D, double* __restrict__ bb,
                                                                double* __restrict__ yy, double* __restrict__ dinv,
-                                                               int* __restrict__ ok) {
+                                                               const double* __restrict__ pend, int* __restrict__ ok) {
   __shared__ CbfShared sh;
   if (!*ok) return;
-  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B};
+  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B,
+               pend + ((size_t)2 * e) * B, pend + ((size_t)2 * e + 1) * B};
   if (!cbf_factor<false>(v, B, sh)) {
     if (threadIdx.x == 0) *ok = 0;
     return;
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(64) void bcr_dinv_kernel(const BcrJob* __restrict__
     for (int p = 0; p < rr; p++) t -= lane_bcast(r[p], rr) * x[p];
     x[rr] = (rr < lane) ? 0.0 : t * di[rr];
   }
-  double* out = Linv + ((size_t)blockIdx.x * (B / 32) + blk) * 1024;
+  double* out = Linv + ((size_t)jb.u * (B / 32) + blk) * 1024;
   if (threadIdx.x < 32) {
 #pragma unroll
     for (int rr = 0; rr < 32; rr++) out[rr * 32 + lane] = x[rr];
@@ -906,7 +919,8 @@ __global__ __launch_bounds__(64) void bcr_dinv_kernel(const BcrJob* __restrict__
 // already solved by all 256 threads, its 32 x 32 diagonal part by one thread per column.
 __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ D,
                                                        const double* __restrict__ Linv, const double* __restrict__ K,
-                                                       double* __restrict__ U, const int* __restrict__ ok) {
+                                                       double* __restrict__ U, const double* __restrict__ yy,
+                                                       double* __restrict__ pend, const int* __restrict__ ok) {
   if (!*ok) return;
   __shared__ double Us[BCR_MAXB * 33];
   __shared__ double Lp[32 * (BCR_MAXB + 1)];
@@ -917,7 +931,7 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
   const int c0 = 32 * (second ? tile - tiles : tile);
   const size_t BB = (size_t)B * B;
   const double* L = D + (size_t)jb.e * BB;
-  const double* Li = Linv + (size_t)blockIdx.x * (B / 32) * 1024;
+  const double* Li = Linv + (size_t)jb.u * (B / 32) * 1024;
   __shared__ double Ls[32 * 33];
   const double* R = K + (size_t)(second ? jb.kq : jb.kp) * BB;
   double* Uo = U + ((size_t)2 * jb.u + (second ? 1 : 0)) * BB;
@@ -985,14 +999,32 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
     __syncthreads();
   }
   for (int r = tid >> 5; r < B; r += 8) Uo[(size_t)r * B + c0 + (tid & 31)] = Us[r * 33 + (tid & 31)];
+  // right-hand side of the neighbour: (U^T z_e) for these 32 columns, accumulated in the neighbour's pending slot
+  // (slot 1 of p: written by the eliminated block below it; slot 0 of q: by the one above; one writer per level)
+  {
+    __shared__ double part[8][33];
+    const double* z = yy + (size_t)jb.e * B;
+    double sacc = 0.0;
+    for (int r = grp; r < B; r += 8) sacc += Us[r * 33 + col] * z[r];
+    part[grp][col] = sacc;
+    __syncthreads();
+    if (tid < 32) {
+      const int tgt = second ? jb.q : jb.p;
+      double t = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) t += part[g][tid];
+      pend[((size_t)2 * tgt + (second ? 0 : 1)) * B + c0 + tid] += t;
+    }
+  }
 }
 
 // C (B x B) = C - M^T N   (mode 0: D_p -= U1^T U1, lower tiles only; mode 1: D_q -= U2^T U2, lower tiles only) or
 // K(q, p) = -U2^T U1 (mode 2, all tiles): one 32 x 32 tile per workgroup, the two 32-column slabs of M and N in LDS
-__global__ __launch_bounds__(256) void bcr_gemm_kernel(const BcrJob* __restrict__ jobs, int B, int mode, const double* __restrict__ U,
+__global__ __launch_bounds__(256) void bcr_gemm_kernel(const BcrJob* __restrict__ jobs, int B, int mode0, const double* __restrict__ U,
                                                        double* __restrict__ D, double* __restrict__ Knext,
                                                        const int* __restrict__ ok) {
   if (!*ok) return;
+  const int mode = mode0 + 2 * (int)blockIdx.z;  // one launch does the D_p updates (z = 0) and the new couplings (z = 1)
   __shared__ double Ms[BCR_MAXB * 33];
   __shared__ double Ns[BCR_MAXB * 33];
   const BcrJob jb = jobs[blockIdx.x];
@@ -1048,33 +1080,16 @@ __global__ __launch_bounds__(256) void bcr_gemm_kernel(const BcrJob* __restrict_
   }
 }
 
-// right-hand sides of the neighbours: side = blockIdx.y: 0: b_p -= U1^T z_e; 1: b_q -= U2^T z_e.  (Two launches, one per
-// side: the q of one job is the p of the next.)  1024 threads = 4 row slices x 256 columns, coalesced along the columns.
-__global__ __launch_bounds__(1024) void bcr_rhs_kernel(const BcrJob* __restrict__ jobs, int B, int side, const double* __restrict__ U,
-                                                       const double* __restrict__ yy, double* __restrict__ bb,
-                                                       const int* __restrict__ ok) {
-  __shared__ double part[4][BCR_MAXB];
-  if (!*ok) return;
-  const BcrJob jb = jobs[blockIdx.x];
-  const int tgt = side == 0 ? jb.p : jb.q;
-  if (tgt < 0) return;
-  const double* Um = U + ((size_t)2 * jb.u + side) * B * B;
-  const double* z = yy + (size_t)jb.e * B;
-  const int c = threadIdx.x & 255, sl = threadIdx.x >> 8;
-  double s = 0.0;
-  if (c < B)
-    for (int r = sl; r < B; r += 4) s += Um[(size_t)r * B + c] * z[r];
-  part[sl][c] = s;
-  __syncthreads();
-  if (sl == 0 && c < B) bb[(size_t)tgt * B + c] -= (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
-}
-
-// solution of an eliminated block: y_e <- z_e - U1 x_p - U2 x_q, then L_e^T x_e = y_e (x_e overwrites b_e)
-__global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __restrict__ jobs, int B, double* __restrict__ D,
-                                                               const double* __restrict__ U, double* __restrict__ bb,
-                                                               double* __restrict__ yy, double* __restrict__ dinv,
+// solution of an eliminated block: t = z_e - U1 x_p - U2 x_q, then L_e^T x_e = t panel by panel from the bottom:
+// x_p = Linv_pp^T (t_p - sum over the rows below of L[r][p]^T x_r) -- the 32 x 32 triangular part through the
+// precomputed inverse of the diagonal block (no serial 32-step chain), the rest a column-sliced dot product.
+__global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ D,
+                                                               const double* __restrict__ U, const double* __restrict__ Linv,
+                                                               double* __restrict__ bb, const double* __restrict__ yy,
                                                                const int* __restrict__ ok) {
-  __shared__ CbfShared sh;
+  __shared__ double ts[BCR_MAXB];              // t, then x
+  __shared__ double part[CBF_THREADS / 32][33];
+  __shared__ double wv[32];
   if (!*ok) return;
   const BcrJob jb = jobs[blockIdx.x];
   const size_t BB = (size_t)B * B;
@@ -1082,23 +1097,46 @@ __global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __r
   const double* U2 = U1 + BB;
   const double* xp = bb + (size_t)jb.p * B;
   const double* xq = jb.q >= 0 ? bb + (size_t)jb.q * B : nullptr;
-  double* y = yy + (size_t)jb.e * B;
-  {  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < B; r += CBF_THREADS / 64) {
-      double s = 0.0;
-      for (int c = lane; c < B; c += 64) {
-        s += U1[(size_t)r * B + c] * xp[c];
-        if (xq) s += U2[(size_t)r * B + c] * xq[c];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      if (lane == 0) y[r] -= s;
+  const double* z = yy + (size_t)jb.e * B;
+  const double* L = D + (size_t)jb.e * BB;
+  const double* Li = Linv + (size_t)jb.u * (B / 32) * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum
+  for (int r = wave; r < B; r += CBF_THREADS / 64) {
+    double sacc = 0.0;
+    for (int c = lane; c < B; c += 64) {
+      sacc += U1[(size_t)r * B + c] * xp[c];
+      if (xq) sacc += U2[(size_t)r * B + c] * xq[c];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    if (lane == 0) ts[r] = z[r] - sacc;
   }
   __syncthreads();
-  CbfView v = {D + (size_t)jb.e * BB, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)jb.e * B, y, dinv + (size_t)jb.e * B};
-  cbf_backward<false>(v, B, sh);
+  const int col = tid & 31, sl = tid >> 5;  // CBF_THREADS / 32 row slices x 32 columns
+  constexpr int NS = CBF_THREADS / 32;
+  for (int p0 = B - 32; p0 >= 0; p0 -= 32) {
+    double sacc = 0.0;
+    for (int r = p0 + 32 + sl; r < B; r += NS) sacc += L[(size_t)r * B + p0 + col] * ts[r];
+    part[sl][col] = sacc;
+    __syncthreads();
+    if (tid < 32) {
+      double t = 0.0;
+#pragma unroll
+      for (int g = 0; g < NS; g++) t += part[g][tid];
+      wv[tid] = ts[p0 + tid] - t;
+    }
+    __syncthreads();
+    if (tid < 32) {  // x_c = sum_k Linv[k][c] w_k  (k >= c: the inverse is lower triangular)
+      double x = 0.0;
+      const double* Lb = Li + (size_t)(p0 >> 5) * 1024;
+#pragma unroll 8
+      for (int k = 0; k < 32; k++) x += Lb[k * 32 + tid] * wv[k];
+      ts[p0 + tid] = x;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < B; r += CBF_THREADS) bb[(size_t)jb.e * B + r] = ts[r];
 }
 
 __global__ void bcr_gather_kernel(const double* __restrict__ bb, int n, double* __restrict__ b, const int* __restrict__ ok) {
@@ -1148,11 +1186,11 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
   // scratch: D | K (all levels) | U | bb | yy | dinv | jobs
   size_t max_nj = 1;
   for (auto& lv : levels) max_nj = std::max(max_nj, lv.size());
-  const size_t linv_doubles = max_nj * (size_t)(B / 32) * 1024;
-  const size_t doubles = (size_t)nblk * BB + n_k * BB + (size_t)2 * n_u * BB + 3 * (size_t)nblk * B + linv_doubles + 16;
+  const size_t linv_doubles = ((size_t)n_u + 1) * (size_t)(B / 32) * 1024;  // per eliminated block (+ the last one), kept for the back-substitution
+  const size_t doubles = (size_t)nblk * BB + n_k * BB + (size_t)2 * n_u * BB + 5 * (size_t)nblk * B + linv_doubles + 16;
   const size_t job_bytes = (n_jobs + 1) * sizeof(BcrJob);
   void* ws = nullptr;
-  int rc = vsl_ctx_dscratch(ctx, sizeof(double) * doubles + job_bytes + 256, &ws);
+  int rc = vsl_ctx_dscratch(ctx, sizeof(double) * doubles + 256, &ws);
   if (rc) return rc;
   double* D = (double*)ws;
   double* K0 = D + (size_t)nblk * BB;
@@ -1160,8 +1198,20 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
   double* bb = U + (size_t)2 * n_u * BB;
   double* yy = bb + (size_t)nblk * B;
   double* dinv = yy + (size_t)nblk * B;
-  double* Linv = dinv + (size_t)nblk * B;
-  BcrJob* jobs_dev = (BcrJob*)(((uintptr_t)(Linv + linv_doubles + 16) + 63) & ~(uintptr_t)63);
+  double* pend = dinv + (size_t)nblk * B;  // [nblk][2][B]
+  double* Linv = pend + (size_t)2 * nblk * B;
+  // the job lists depend on (n, bw) only: uploaded once and kept (an upload per solve needs a host synchronisation in
+  // the middle of an otherwise asynchronous LM iteration)
+  if (ctx->bcr_jobs_cap < job_bytes) {
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->bcr_jobs) (void)hipFree(ctx->bcr_jobs);
+    ctx->bcr_jobs = nullptr;
+    ctx->bcr_jobs_cap = 0;
+    ctx->bcr_key_n = ctx->bcr_key_bw = -1;
+    VSL_HIP(ctx, hipMalloc(&ctx->bcr_jobs, 2 * job_bytes));
+    ctx->bcr_jobs_cap = 2 * job_bytes;
+  }
+  BcrJob* jobs_dev = (BcrJob*)ctx->bcr_jobs;
   std::vector<BcrJob> flat;
   std::vector<size_t> job_off, k_off;
   {
@@ -1173,30 +1223,32 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
       ko += (size_t)ncoup[l];
     }
   }
-  const int one = 1;
+  static const int one = 1;
   VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  VSL_HIP(ctx, hipMemcpyAsync(jobs_dev, flat.data(), flat.size() * sizeof(BcrJob), hipMemcpyHostToDevice, ctx->stream));
-  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` and `one` are on this stack frame
+  if (ctx->bcr_key_n != n || ctx->bcr_key_bw != bw) {
+    VSL_HIP(ctx, hipMemcpyAsync(jobs_dev, flat.data(), flat.size() * sizeof(BcrJob), hipMemcpyHostToDevice, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is on this stack frame
+    ctx->bcr_key_n = n;
+    ctx->bcr_key_bw = bw;
+  }
   hipStream_t q = ctx->stream;
-  hipLaunchKernelGGL(bcr_extract_kernel, dim3(16, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, D, K0, bb);
+  hipLaunchKernelGGL(bcr_extract_kernel, dim3(16, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, D, K0, bb, pend);
   const int tiles = B / 32;
   for (size_t l = 0; l < levels.size(); l++) {
     const int nj = (int)levels[l].size();
     const BcrJob* jl = jobs_dev + job_off[l];
     double* Kl = K0 + k_off[l] * BB;
     double* Kn = l + 1 < levels.size() ? K0 + k_off[l + 1] * BB : nullptr;
-    hipLaunchKernelGGL(bcr_chol_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jl, B, D, bb, yy, dinv, ok_dev);
+    hipLaunchKernelGGL(bcr_chol_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jl, B, D, bb, yy, dinv, pend, ok_dev);
     hipLaunchKernelGGL(bcr_dinv_kernel, dim3(nj, tiles), dim3(64), 0, q, jl, B, D, dinv, Linv, ok_dev);
-    hipLaunchKernelGGL(bcr_trsm_kernel, dim3(nj, 2 * tiles), dim3(256), 0, q, jl, B, D, Linv, Kl, U, ok_dev);
-    for (int mode = 0; mode < 3; mode++)
-      if (mode != 2 || Kn) hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles), dim3(256), 0, q, jl, B, mode, U, D, Kn, ok_dev);
-    hipLaunchKernelGGL(bcr_rhs_kernel, dim3(nj), dim3(1024), 0, q, jl, B, 0, U, yy, bb, ok_dev);
-    hipLaunchKernelGGL(bcr_rhs_kernel, dim3(nj), dim3(1024), 0, q, jl, B, 1, U, yy, bb, ok_dev);
+    hipLaunchKernelGGL(bcr_trsm_kernel, dim3(nj, 2 * tiles), dim3(256), 0, q, jl, B, D, Linv, Kl, U, yy, pend, ok_dev);
+    hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles, Kn ? 2 : 1), dim3(256), 0, q, jl, B, 0, U, D, Kn, ok_dev);
+    hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles, 1), dim3(256), 0, q, jl, B, 1, U, D, Kn, ok_dev);
   }
-  hipLaunchKernelGGL(bcr_last_kernel, dim3(1), dim3(CBF_THREADS), 0, q, last, B, D, bb, yy, dinv, ok_dev);
+  hipLaunchKernelGGL(bcr_last_kernel, dim3(1), dim3(CBF_THREADS), 0, q, last, B, D, bb, yy, dinv, pend, ok_dev);
   for (size_t l = levels.size(); l-- > 0;) {
     const int nj = (int)levels[l].size();
-    hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, U, bb, yy, dinv, ok_dev);
+    hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, U, Linv, bb, yy, ok_dev);
   }
   hipLaunchKernelGGL(bcr_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, q, bb, n, b, ok_dev);
   VSL_CHECK_LAUNCH(ctx);

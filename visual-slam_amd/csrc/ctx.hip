@@ -74,6 +74,7 @@ extern "C" int vsl_ctx_destroy(vsl_ctx* ctx) {
   }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+  if (ctx->bcr_jobs) (void)hipFree(ctx->bcr_jobs);
   if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
   if (ctx->hpinned) (void)hipHostFree(ctx->hpinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

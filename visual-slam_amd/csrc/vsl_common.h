@@ -47,6 +47,10 @@ struct vsl_ctx {
   size_t dscratch_cap = 0;
   void* hpinned = nullptr;
   size_t hpinned_cap = 0;
+  // job lists of the block-cyclic-reduction solver (chol.hip), kept on the device while (n, bandwidth) stay the same
+  void* bcr_jobs = nullptr;
+  size_t bcr_jobs_cap = 0;
+  int bcr_key_n = -1, bcr_key_bw = -1;
   // device arena lent to vsl_bundle_adjust calls on this context (one allocation reused across solves)
   void* ba_arena = nullptr;
   size_t ba_arena_cap = 0;
