@@ -970,16 +970,21 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
         if (tid < p0) Lp[(rr0 + u) * (B + 1) + tid] = v[u];
     }
     __syncthreads();
-    double acc[4];
+    {  // T_p = R_p - L[p, 0:p0] U[0:p0]: one 16 x 16 tile per wavefront on the matrix unit (two chains); as four rows
+       // per thread on the vector ALU this product was LDS-bound (five LDS reads per four multiply-adds)
+      const int wv = tid >> 6, lane = tid & 63, ti = wv >> 1, tj = wv & 1, kq = lane >> 4, l16 = lane & 15;
+      v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+      const double* lrow = Lp + (16 * ti + l16) * (B + 1) + kq;
+      const double* ucol = Us + kq * 33 + 16 * tj + l16;
+      int k0 = 0;
+      for (; k0 + 8 <= p0; k0 += 8) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[k0], ucol[k0 * 33], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[k0 + 4], ucol[(k0 + 4) * 33], acc2, 0, 0, 0);
+      }
+      for (; k0 < p0; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[k0], ucol[k0 * 33], acc, 0, 0, 0);
 #pragma unroll
-    for (int a = 0; a < 4; a++) acc[a] = Us[(p0 + 4 * grp + a) * 33 + col];
-    for (int k = 0; k < p0; k++) {
-      const double u = Us[k * 33 + col];
-#pragma unroll
-      for (int a = 0; a < 4; a++) acc[a] -= Lp[(4 * grp + a) * (B + 1) + k] * u;
+      for (int qq = 0; qq < 4; qq++) Us[(p0 + 16 * ti + kq + 4 * qq) * 33 + 16 * tj + l16] -= acc[qq] + acc2[qq];
     }
-#pragma unroll
-    for (int a = 0; a < 4; a++) Us[(p0 + 4 * grp + a) * 33 + col] = acc[a];
     __syncthreads();
     // the 32 x 32 diagonal part: U_p = Linv_pp T_p, a dense product (all threads)
     for (int idx = tid; idx < 1024; idx += 256) Ls[(idx >> 5) * 33 + (idx & 31)] = Li[(size_t)(p0 >> 5) * 1024 + idx];
@@ -1101,23 +1106,56 @@ __global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __r
   const double* L = D + (size_t)jb.e * BB;
   const double* Li = Linv + (size_t)jb.u * (B / 32) * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum
-  for (int r = wave; r < B; r += CBF_THREADS / 64) {
-    double sacc = 0.0;
-    for (int c = lane; c < B; c += 64) {
-      sacc += U1[(size_t)r * B + c] * xp[c];
-      if (xq) sacc += U2[(size_t)r * B + c] * xq[c];
-    }
+  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum; four rows at a time so that
+  // their loads are in flight together (B <= 256: four 64-column chunks per row)
+  {
+    double xpv[4], xqv[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-    if (lane == 0) ts[r] = z[r] - sacc;
+    for (int j = 0; j < 4; j++) {
+      const int c = lane + 64 * j;
+      xpv[j] = c < B ? xp[c] : 0.0;
+      xqv[j] = (xq && c < B) ? xq[c] : 0.0;
+    }
+    for (int r0 = 4 * wave; r0 < B; r0 += 4 * (CBF_THREADS / 64)) {
+      double a1[4][4], a2[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int r = r0 + u, c = lane + 64 * j;
+          const bool in = r < B && c < B;
+          a1[u][j] = in ? U1[(size_t)r * B + c] : 0.0;
+          a2[u][j] = (in && xq) ? U2[(size_t)r * B + c] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) sacc += a1[u][j] * xpv[j] + a2[u][j] * xqv[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (lane == 0 && r0 + u < B) ts[r0 + u] = z[r0 + u] - sacc;
+      }
+    }
   }
   __syncthreads();
   const int col = tid & 31, sl = tid >> 5;  // CBF_THREADS / 32 row slices x 32 columns
   constexpr int NS = CBF_THREADS / 32;
   for (int p0 = B - 32; p0 >= 0; p0 -= 32) {
     double sacc = 0.0;
-    for (int r = p0 + 32 + sl; r < B; r += NS) sacc += L[(size_t)r * B + p0 + col] * ts[r];
+    {  // the rows below the panel, NS apart per slice: at most ceil(224 / 24) = 10 per thread, all loaded before use
+      double lv[11];
+#pragma unroll
+      for (int u = 0; u < 11; u++) {
+        const int r = p0 + 32 + sl + NS * u;
+        lv[u] = r < B ? L[(size_t)r * B + p0 + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 11; u++) {
+        const int r = p0 + 32 + sl + NS * u;
+        if (r < B) sacc += lv[u] * ts[r];
+      }
+    }
     part[sl][col] = sacc;
     __syncthreads();
     if (tid < 32) {
