@@ -361,10 +361,100 @@ __device__ __forceinline__ void cbf_stage(const CbfView& v, double (*W)[CH_NB + 
 #define CBF_TPASS
 #endif
 
+// The panel in W (rows x 32: diagonal block, the rows below it, the right-hand side as the last row) is factored in
+// place: four sub-steps of eight columns.  On return W holds the panel of L (and the solved right-hand-side row),
+// sh.dinv_s the reciprocal pivots; sh.fail_s is set if a pivot was not positive.  Ends with a workgroup barrier.
+template <int NTHR = CBF_THREADS>
+__device__ __forceinline__ void cbf_panel_factor(double (*W)[CH_NB + 1], int rows, CbfShared& sh CBF_TARGS) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // The 8 x 8 diagonal sub-block of a sub-step is factored by wavefront 0 ALONE and published through LDS (every
+  // wavefront factoring it redundantly -- ~400 dependent instructions -- cost three wavefronts' worth of issue slots
+  // per SIMD and sub-step: 19k of the 86k cycles of a panel step).  For sub-steps 1..3 wavefront 0 does it inside the
+  // previous sub-step's update phase, right after the tile that completes that sub-block, so no barrier is added.
+  auto factor8 = [&](int j0) {  // wavefront 0 only; lanes 0..7 = the rows of the sub-block
+    double dr[CBF_SUB];
+#pragma unroll
+    for (int c = 0; c < CBF_SUB; c++) dr[c] = lane < CBF_SUB ? W[j0 + lane][j0 + c] : (lane == c ? 1.0 : 0.0);
+    bool good = true;
+#pragma unroll
+    for (int c = 0; c < CBF_SUB; c++) {
+      const double d = lane_bcast(dr[c], c);
+      if (!(d > 0.0) || !isfinite(d)) good = false;  // wave-uniform
+      // 1 / sqrt(d) by the hardware estimate and two Newton steps, sqrt(d) = d / sqrt(d): the IEEE sqrt and divide
+      // expansions are ~100 dependent fp64 instructions (~1000 cycles) per pivot, and the 32 pivots of a panel are
+      // sequential -- measured 47k of the 100k cycles of a panel step
+      double iv = __builtin_amdgcn_rsq(d);
+      iv = iv * (1.5 - 0.5 * d * iv * iv);
+      iv = iv * (1.5 - 0.5 * d * iv * iv);
+      if (lane == 0) sh.inv_s[c] = iv;
+      dr[c] = (lane == c) ? d * iv : dr[c] * iv;  // lanes > c: l(lane, c)
+#pragma unroll
+      for (int q = c + 1; q < CBF_SUB; q++) dr[q] -= dr[c] * lane_bcast(dr[c], q);  // meaningful for lanes >= q
+    }
+    if (lane < CBF_SUB) {
+#pragma unroll
+      for (int c = 0; c < CBF_SUB; c++) sh.Ld_s[lane][c] = dr[c];  // l(lane, c) for c <= lane (the rest is never read)
+    }
+    if (!good && lane == 0) sh.fail_s = 1;
+  };
+  if (wave == 0) factor8(0);
+  __syncthreads();
+  CBF_STAMP(4)
+#pragma unroll 1
+  for (int j0 = 0; j0 < CH_NB; j0 += CBF_SUB) {
+    const bool act = tid < rows && tid >= j0;
+    // x L_d^T = a: this row's entries in the sub-panel (for a row of the diagonal sub-block: that row of L_d)
+    double x[CBF_SUB];
+#pragma unroll
+    for (int c = 0; c < CBF_SUB; c++) {
+      double t = act ? W[tid][j0 + c] : 0.0;
+#pragma unroll
+      for (int q = 0; q < c; q++) t -= x[q] * sh.Ld_s[c][q];
+      x[c] = t * sh.inv_s[c];
+    }
+    CBF_STAMP(5)
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < CBF_SUB; c++)
+        if (tid >= j0 + CBF_SUB || c <= tid - j0) W[tid][j0 + c] = x[c];
+    }
+    if (tid < CBF_SUB) sh.dinv_s[j0 + tid] = sh.inv_s[tid];
+    __syncthreads();
+    CBF_STAMP(6)
+    // the remaining panel columns lose X . L_d^T: W[r][cc] -= sum_q W[r][j0 + q] W[cc][j0 + q] for rows r >= j0 + 8 and
+    // columns cc in [j0 + 8, 32) -- a rank-8 update in 16 x 16 tiles on the matrix unit (two v_mfma_f64_16x16x4_f64 per
+    // tile; as one row per thread with broadcast LDS reads of the factor rows this phase was LDS-bound: 17k of the
+    // 87k cycles of a panel step).  Entries above the diagonal of the diagonal block receive garbage; nothing reads them.
+    // Tile 0 (wavefront 0's first) holds the next 8 x 8 diagonal sub-block.
+    if (j0 + CBF_SUB < CH_NB) {
+      const int r_first = (j0 + CBF_SUB) & ~15, c_first = j0 + CBF_SUB < 16 ? 0 : 16;
+      const int n_rt = (rows - r_first + 15) >> 4, n_ct = (CH_NB - c_first) >> 4;
+      const int kq = lane >> 4, l16 = lane & 15;
+      for (int t = wave; t < n_rt * n_ct; t += NTHR / 64) {
+        const int rt = t / n_ct, ct = t - rt * n_ct;
+        const int R0 = r_first + 16 * rt, C0 = c_first + 16 * ct;
+        const int ra = min(R0 + l16, rows - 1), rb = C0 + l16;
+        v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][j0 + kq], W[rb][j0 + kq], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][j0 + 4 + kq], W[rb][j0 + 4 + kq], acc, 0, 0, 0);
+        const int cc = C0 + l16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int r = R0 + kq + 4 * q;
+          if (r < rows && r >= j0 + CBF_SUB && cc >= j0 + CBF_SUB) W[r][cc] -= acc[q];
+        }
+        if (t == 0) factor8(j0 + CBF_SUB);  // wavefront 0 (t == wave == 0): its own LDS writes above are ordered before these reads
+      }
+    }
+    CBF_STAMP(7)
+    __syncthreads();
+    CBF_STAMP(8)
+  }
+}
 // One panel step of the view: factorisation of columns [k, k + 32), forward substitution, window update.
 // Returns false (workgroup-uniform) if a pivot is not positive.
 template <bool REV, bool SEP>
-__device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
+__device__ __forceinline__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
   double(*W)[CH_NB + 1] = sh.W;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = v.n, bw = v.bw;
@@ -376,89 +466,7 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
     cbf_stage<REV, SEP, true>(v, W, k, nb, m, true);
     __syncthreads();
     CBF_STAMP(0)
-    // The 8 x 8 diagonal sub-block of a sub-step is factored by wavefront 0 ALONE and published through LDS (every
-    // wavefront factoring it redundantly -- ~400 dependent instructions -- cost three wavefronts' worth of issue slots
-    // per SIMD and sub-step: 19k of the 86k cycles of a panel step).  For sub-steps 1..3 wavefront 0 does it inside the
-    // previous sub-step's update phase, right after the tile that completes that sub-block, so no barrier is added.
-    auto factor8 = [&](int j0) {  // wavefront 0 only; lanes 0..7 = the rows of the sub-block
-      double dr[CBF_SUB];
-#pragma unroll
-      for (int c = 0; c < CBF_SUB; c++) dr[c] = lane < CBF_SUB ? W[j0 + lane][j0 + c] : (lane == c ? 1.0 : 0.0);
-      bool good = true;
-#pragma unroll
-      for (int c = 0; c < CBF_SUB; c++) {
-        const double d = lane_bcast(dr[c], c);
-        if (!(d > 0.0) || !isfinite(d)) good = false;  // wave-uniform
-        // 1 / sqrt(d) by the hardware estimate and two Newton steps, sqrt(d) = d / sqrt(d): the IEEE sqrt and divide
-        // expansions are ~100 dependent fp64 instructions (~1000 cycles) per pivot, and the 32 pivots of a panel are
-        // sequential -- measured 47k of the 100k cycles of a panel step
-        double iv = __builtin_amdgcn_rsq(d);
-        iv = iv * (1.5 - 0.5 * d * iv * iv);
-        iv = iv * (1.5 - 0.5 * d * iv * iv);
-        if (lane == 0) sh.inv_s[c] = iv;
-        dr[c] = (lane == c) ? d * iv : dr[c] * iv;  // lanes > c: l(lane, c)
-#pragma unroll
-        for (int q = c + 1; q < CBF_SUB; q++) dr[q] -= dr[c] * lane_bcast(dr[c], q);  // meaningful for lanes >= q
-      }
-      if (lane < CBF_SUB) {
-#pragma unroll
-        for (int c = 0; c < CBF_SUB; c++) sh.Ld_s[lane][c] = dr[c];  // l(lane, c) for c <= lane (the rest is never read)
-      }
-      if (!good && lane == 0) sh.fail_s = 1;
-    };
-    if (wave == 0) factor8(0);
-    __syncthreads();
-    CBF_STAMP(4)
-#pragma unroll 1
-    for (int j0 = 0; j0 < CH_NB; j0 += CBF_SUB) {
-      const bool act = tid < rows && tid >= j0;
-      // x L_d^T = a: this row's entries in the sub-panel (for a row of the diagonal sub-block: that row of L_d)
-      double x[CBF_SUB];
-#pragma unroll
-      for (int c = 0; c < CBF_SUB; c++) {
-        double t = act ? W[tid][j0 + c] : 0.0;
-#pragma unroll
-        for (int q = 0; q < c; q++) t -= x[q] * sh.Ld_s[c][q];
-        x[c] = t * sh.inv_s[c];
-      }
-      CBF_STAMP(5)
-      if (act) {
-#pragma unroll
-        for (int c = 0; c < CBF_SUB; c++)
-          if (tid >= j0 + CBF_SUB || c <= tid - j0) W[tid][j0 + c] = x[c];
-      }
-      if (tid < CBF_SUB) sh.dinv_s[j0 + tid] = sh.inv_s[tid];
-      __syncthreads();
-      CBF_STAMP(6)
-      // the remaining panel columns lose X . L_d^T: W[r][cc] -= sum_q W[r][j0 + q] W[cc][j0 + q] for rows r >= j0 + 8 and
-      // columns cc in [j0 + 8, 32) -- a rank-8 update in 16 x 16 tiles on the matrix unit (two v_mfma_f64_16x16x4_f64 per
-      // tile; as one row per thread with broadcast LDS reads of the factor rows this phase was LDS-bound: 17k of the
-      // 87k cycles of a panel step).  Entries above the diagonal of the diagonal block receive garbage; nothing reads them.
-      // Tile 0 (wavefront 0's first) holds the next 8 x 8 diagonal sub-block.
-      if (j0 + CBF_SUB < CH_NB) {
-        const int r_first = (j0 + CBF_SUB) & ~15, c_first = j0 + CBF_SUB < 16 ? 0 : 16;
-        const int n_rt = (rows - r_first + 15) >> 4, n_ct = (CH_NB - c_first) >> 4;
-        const int kq = lane >> 4, l16 = lane & 15;
-        for (int t = wave; t < n_rt * n_ct; t += CBF_THREADS / 64) {
-          const int rt = t / n_ct, ct = t - rt * n_ct;
-          const int R0 = r_first + 16 * rt, C0 = c_first + 16 * ct;
-          const int ra = min(R0 + l16, rows - 1), rb = C0 + l16;
-          v4d_t acc = {0.0, 0.0, 0.0, 0.0};
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][j0 + kq], W[rb][j0 + kq], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][j0 + 4 + kq], W[rb][j0 + 4 + kq], acc, 0, 0, 0);
-          const int cc = C0 + l16;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int r = R0 + kq + 4 * q;
-            if (r < rows && r >= j0 + CBF_SUB && cc >= j0 + CBF_SUB) W[r][cc] -= acc[q];
-          }
-          if (t == 0) factor8(j0 + CBF_SUB);  // wavefront 0 (t == wave == 0): its own LDS writes above are ordered before these reads
-        }
-      }
-      CBF_STAMP(7)
-      __syncthreads();
-      CBF_STAMP(8)
-    }
+    cbf_panel_factor(W, rows, sh CBF_TPASS);
     CBF_STAMP(1)
     if (sh.fail_s) return false;  // workgroup-uniform
     // write the factored rows back to the band (coalesced), y_k, and b of the window rows
@@ -547,7 +555,7 @@ __device__ bool cbf_step(const CbfView& v, int k, CbfShared& sh CBF_TARGS) {
 // Panel steps k in [0, k_end) of the view (k_end a multiple of 32, or the view's n): factorisation and forward
 // substitution.  Returns false (workgroup-uniform) if a pivot is not positive.
 template <bool REV>
-__device__ bool cbf_factor(const CbfView& v, int k_end, CbfShared& sh) {
+__device__ __forceinline__ bool cbf_factor(const CbfView& v, int k_end, CbfShared& sh) {
   if (threadIdx.x == 0) sh.fail_s = 0;
   __syncthreads();
 #ifdef CBF_TIMING
@@ -571,7 +579,7 @@ __device__ bool cbf_factor(const CbfView& v, int k_end, CbfShared& sh) {
 // Backward substitution L^T x = y over the view's panels [0, k_end), last panel first; x overwrites the right-hand side.
 // The solution entries beyond k_end (the separator, for a chunk) must already be in place (in b: no scratch here).
 template <bool REV>
-__device__ void cbf_backward(const CbfView& v, int k_end, CbfShared& sh) {
+__device__ __forceinline__ void cbf_backward(const CbfView& v, int k_end, CbfShared& sh) {
   double(*W)[CH_NB + 1] = sh.W;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31;
   const int n = v.n, bw = v.bw;
@@ -857,8 +865,101 @@ __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, 
     }
 }
 
+// Dense B x B block (B <= 256) with its trailing matrix in REGISTERS: the 16 x 16 tiles of the lower triangle are
+// dealt to the 12 wavefronts once (<= 12 tiles = 96 VGPRs each, in the accumulator layout of v_mfma_f64_16x16x4_f64) and
+// stay there -- a panel step updates them with the matrix unit straight from the panel in LDS, and the tiles of the next
+// panel's two tile columns are written into the LDS window when their turn comes.  No global round trip between the
+// steps (the band kernel on such a block spent 88k of its 389k cycles staging panels and 102k in the window update's
+// load -> MFMA -> store chain); global traffic is one read of the block and one write of its factor.
+// y = L^-1 (b - pending updates) rides along as the window's last row; L (lower), 1 / pivots and y go to global memory.
+#define BCR_REG_THREADS 512  // 8 wavefronts = 2 per SIMD: 256 VGPRs each, room for the tiles beside the panel factorisation
+template <int SLOTS>  // tiles per wavefront: 14 for B <= 224 (105 tiles), 17 for B <= 256 (136 tiles)
+__device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ Dg, const double* __restrict__ bg, const double* __restrict__ pend0,
+                                   const double* __restrict__ pend1, double* __restrict__ yg, double* __restrict__ dinvg,
+                                   CbfShared& sh) {
+  double(*W)[CH_NB + 1] = sh.W;
+  double* bvec = sh.xw;  // B <= 256 entries of the (updated) right-hand side
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l16 = lane & 15;
+  const int NT = B >> 4, ntiles = NT * (NT + 1) / 2;
+  if (tid == 0) sh.fail_s = 0;
+  for (int r = tid; r < B; r += BCR_REG_THREADS) bvec[r] = bg[r] - (pend0[r] + pend1[r]);
+  // tile id = wave + 12 * slot -> (ti, tj), tj <= ti, row-major over the lower triangle; the table lives in LDS (two
+  // more registers per slot would push the kernel into scratch)
+  unsigned short* tile_of = (unsigned short*)sh.red;  // ti | tj << 8, 0xffff = no tile
+  for (int id = tid; id < SLOTS * (BCR_REG_THREADS / 64); id += BCR_REG_THREADS) {
+    int ti = (int)((__fsqrt_rn(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > id) ti--;
+    while ((ti + 1) * (ti + 2) / 2 <= id) ti++;
+    tile_of[id] = id < ntiles ? (unsigned short)(ti | ((id - ti * (ti + 1) / 2) << 8)) : (unsigned short)0xffff;
+  }
+  __syncthreads();
+  double acc[SLOTS][4];  // (plain doubles: an array of ext-vectors stayed in scratch memory)
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; sl++) {
+    const unsigned t = tile_of[wave + (BCR_REG_THREADS / 64) * sl];
+    const int ti = t & 255, tj = t >> 8;
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[sl][q] = t != 0xffffu ? Dg[(size_t)(16 * ti + kq + 4 * q) * B + 16 * tj + l16] : 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k < B; k += CH_NB) {
+    const int m = B - k - CH_NB, rows = CH_NB + m + 1, tk = k >> 4;  // tk: first tile column of the panel
+    // the panel into the window: the owners of tile columns tk, tk + 1 write their tiles (rows from matrix row k)
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; sl++) {
+      const unsigned t = tile_of[wave + (BCR_REG_THREADS / 64) * sl];
+      const int ti = t & 255, tj = t >> 8;
+      if (t != 0xffffu && (tj == tk || tj == tk + 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) W[16 * ti - k + kq + 4 * q][16 * (tj - tk) + l16] = acc[sl][q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid < CH_NB) W[rows - 1][tid] = bvec[k + tid];
+    __syncthreads();
+    cbf_panel_factor<BCR_REG_THREADS>(W, rows, sh);
+    if (sh.fail_s) return false;  // workgroup-uniform (cbf_panel_factor ends with a barrier)
+    // the factored panel, y and the reciprocal pivots to global memory; right-hand side of the rows below
+    for (int idx = tid; idx < (CH_NB + m) * CH_NB; idx += BCR_REG_THREADS) {
+      const int r = idx >> 5, c = idx & 31;
+      if (r >= CH_NB || c <= r) Dg[(size_t)(k + r) * B + k + c] = W[r][c];
+    }
+    if (tid < CH_NB) {
+      yg[k + tid] = W[rows - 1][tid];
+      dinvg[k + tid] = sh.dinv_s[tid];
+    }
+    if (tid < m) {
+      double dot = 0.0;
+#pragma unroll
+      for (int c = 0; c < CH_NB; c++) dot += W[CH_NB + tid][c] * W[rows - 1][c];
+      bvec[k + CH_NB + tid] -= dot;
+    }
+    // trailing tiles: acc -= P_i P_j^T, P = the solved panel rows (W row of matrix row r is r - k)
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; sl++) {
+      const unsigned t = tile_of[wave + (BCR_REG_THREADS / 64) * sl];
+      const int ti = t & 255, tj = t >> 8;
+      if (t != 0xffffu && tj >= tk + 2) {
+        const int ra = 16 * ti - k + l16, rb = 16 * tj - k + l16;
+        v4d_t a1 = {0.0, 0.0, 0.0, 0.0}, a2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c0 = 0; c0 < CH_NB / 2; c0 += 4) {
+          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][c0 + kq], W[rb][c0 + kq], a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[ra][CH_NB / 2 + c0 + kq], W[rb][CH_NB / 2 + c0 + kq], a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[sl][q] -= a1[q] + a2[q];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one tile at a time: hoisting every slot's 16 operand loads costs 400 registers
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
 // dense Cholesky of the blocks jobs[].e of one level + z = L^-1 b (in y), by the single-workgroup band kernel
-__global__ __launch_bounds__(CBF_THREADS) void bcr_chol_kernel(const BcrJob* __restrict__ jobs, int B, double* __restrict__ D,
+template <int SLOTS>
+__global__ __launch_bounds__(BCR_REG_THREADS) void bcr_chol_kernel(const BcrJob* __restrict__ jobs, int B, double* __restrict__ D,
                                                                double* __restrict__ bb, double* __restrict__ yy,
                                                                double* __restrict__ dinv, const double* __restrict__ pend,
                                                                int* __restrict__ ok) {
@@ -866,23 +967,30 @@ __global__ __launch_bounds__(CBF_THREADS) void bcr_chol_kernel(const BcrJob* __r
   const int e = jobs[blockIdx.x].e;
   // the right-hand-side updates this block received from eliminated neighbours (two slots: from the neighbour above and
   // from the one below, each written by one workgroup per level) are subtracted where the panel's entries are staged
-  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B,
-               pend + ((size_t)2 * e) * B, pend + ((size_t)2 * e + 1) * B};
-  if (!cbf_factor<false>(v, B, sh) && threadIdx.x == 0) *ok = 0;
+  const bool good = bcr_chol_registers<SLOTS>(B, D + (size_t)e * B * B, bb + (size_t)e * B, pend + ((size_t)2 * e) * B,
+                                              pend + ((size_t)2 * e + 1) * B, yy + (size_t)e * B, dinv + (size_t)e * B, sh);
+  if (!good && threadIdx.x == 0) *ok = 0;
 }
 
 // the last remaining block: the whole solve
-__global__ __launch_bounds__(CBF_THREADS) void bcr_last_kernel(int e, int B, double* __restrict__ D, double* __restrict__ bb,
+template <int SLOTS>
+__global__ __launch_bounds__(BCR_REG_THREADS) void bcr_last_kernel(int e, int B, double* __restrict__ D, double* __restrict__ bb,
                                                                double* __restrict__ yy, double* __restrict__ dinv,
                                                                const double* __restrict__ pend, int* __restrict__ ok) {
   __shared__ CbfShared sh;
   if (!*ok) return;
-  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B,
-               pend + ((size_t)2 * e) * B, pend + ((size_t)2 * e + 1) * B};
-  if (!cbf_factor<false>(v, B, sh)) {
-    if (threadIdx.x == 0) *ok = 0;
-    return;
-  }
+  const bool good = bcr_chol_registers<SLOTS>(B, D + (size_t)e * B * B, bb + (size_t)e * B, pend + ((size_t)2 * e) * B,
+                                              pend + ((size_t)2 * e + 1) * B, yy + (size_t)e * B, dinv + (size_t)e * B, sh);
+  if (!good && threadIdx.x == 0) *ok = 0;
+}
+
+// ... and its backward substitution (a launch of its own: cbf_backward is written for CBF_THREADS threads)
+__global__ __launch_bounds__(CBF_THREADS) void bcr_last_back_kernel(int e, int B, double* __restrict__ D, double* __restrict__ bb,
+                                                                    double* __restrict__ yy, double* __restrict__ dinv,
+                                                                    const int* __restrict__ ok) {
+  __shared__ CbfShared sh;
+  if (!*ok) return;
+  CbfView v = {D + (size_t)e * B * B, B, B, B, B - 1, 0, 0, nullptr, nullptr, bb + (size_t)e * B, yy + (size_t)e * B, dinv + (size_t)e * B};
   cbf_backward<false>(v, B, sh);
 }
 
@@ -1277,13 +1385,20 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     const BcrJob* jl = jobs_dev + job_off[l];
     double* Kl = K0 + k_off[l] * BB;
     double* Kn = l + 1 < levels.size() ? K0 + k_off[l + 1] * BB : nullptr;
-    hipLaunchKernelGGL(bcr_chol_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jl, B, D, bb, yy, dinv, pend, ok_dev);
+    if (B <= 224)
+      hipLaunchKernelGGL(bcr_chol_kernel<14>, dim3(nj), dim3(BCR_REG_THREADS), 0, q, jl, B, D, bb, yy, dinv, pend, ok_dev);
+    else
+      hipLaunchKernelGGL(bcr_chol_kernel<17>, dim3(nj), dim3(BCR_REG_THREADS), 0, q, jl, B, D, bb, yy, dinv, pend, ok_dev);
     hipLaunchKernelGGL(bcr_dinv_kernel, dim3(nj, tiles), dim3(64), 0, q, jl, B, D, dinv, Linv, ok_dev);
     hipLaunchKernelGGL(bcr_trsm_kernel, dim3(nj, 2 * tiles), dim3(256), 0, q, jl, B, D, Linv, Kl, U, yy, pend, ok_dev);
     hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles, Kn ? 2 : 1), dim3(256), 0, q, jl, B, 0, U, D, Kn, ok_dev);
     hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles, 1), dim3(256), 0, q, jl, B, 1, U, D, Kn, ok_dev);
   }
-  hipLaunchKernelGGL(bcr_last_kernel, dim3(1), dim3(CBF_THREADS), 0, q, last, B, D, bb, yy, dinv, pend, ok_dev);
+  if (B <= 224)
+    hipLaunchKernelGGL(bcr_last_kernel<14>, dim3(1), dim3(BCR_REG_THREADS), 0, q, last, B, D, bb, yy, dinv, pend, ok_dev);
+  else
+    hipLaunchKernelGGL(bcr_last_kernel<17>, dim3(1), dim3(BCR_REG_THREADS), 0, q, last, B, D, bb, yy, dinv, pend, ok_dev);
+  hipLaunchKernelGGL(bcr_last_back_kernel, dim3(1), dim3(CBF_THREADS), 0, q, last, B, D, bb, yy, dinv, ok_dev);
   for (size_t l = levels.size(); l-- > 0;) {
     const int nj = (int)levels[l].size();
     hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, U, Linv, bb, yy, ok_dev);
