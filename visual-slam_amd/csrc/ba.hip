@@ -1518,9 +1518,11 @@ int upload(vsl_ctx* ctx, DevBuf& b, const T* src, size_t n) {
 // host loops of the set-up over ranges of [0, n) on a few threads (the set-up of a 1000-camera solve was ~15 ms of
 // single-threaded loops over 881k observations next to LM iterations of 2.5 ms)
 template <class Fn>
-void host_parallel(int n, Fn fn) {
+void host_parallel(int n, Fn fn, int min_parallel = 1 << 19) {
   const int hw = (int)std::thread::hardware_concurrency();
-  const int nt = n < (1 << 16) ? 1 : std::max(1, std::min(8, hw > 0 ? hw : 1));
+  // (starting the threads costs ~0.4 ms: worth it for the global problems only -- a local window of 157k observations
+  // went from 6.0 to 8.1 ms per solve with them)
+  const int nt = n < min_parallel ? 1 : std::max(1, std::min(8, hw > 0 ? hw : 1));
   if (nt == 1) {
     fn(0, n, 0);
     return;
@@ -1565,7 +1567,7 @@ int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free
             my[(size_t)cb * words + (ca >> 6)] |= 1ull << (ca & 63);
           }
         }
-    });
+    }, 1 << 15);  // ~k^2 = 80 bit operations per landmark: parallel from 32k landmarks
     for (auto& my : priv)
       if (!my.empty())
         for (size_t i = 0; i < adj.size(); i++) adj[i] |= my[i];
