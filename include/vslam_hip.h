@@ -202,7 +202,7 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "match_use_i8" (0/1)            int8 matrix-core matcher where the block-scaled FP4 one would run (<= 2048 features)
  *   "match_no_stagger" (0/1)        matrix-core matcher with every wave of a workgroup in the same phase order
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
- *   "k1_list_cap" (0..256)          per-wave LDS candidate slots of the response kernel (overflow path)
+ *   "k1_list_cap" (0..384)          per-wave LDS candidate slots of the response kernel (overflow path)
  *   "chol_no_fused" (0/1)           band Cholesky as one launch per panel step instead of the single-launch kernel
  *   "chol_no_bcr" (0/1)             long narrow bands by the band Cholesky instead of block cyclic reduction
  *   "chol_one_ended" (0/1)          narrow-band Cholesky eliminated from the top only instead of from both ends
@@ -236,6 +236,12 @@ int vsl_frames_download_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_
  * the first n_images slots produced in its last detect call -- the input size of the selection
  * stage, needed to price its traffic. */
 int vsl_frames_download_candidate_counts(vsl_ctx* ctx, vsl_frames* f, int n_images, int32_t* n_candidates);
+
+/* Diagnostic: the response kernel evaluates sqrt as rsq + one fused correction step; this compares that sequence
+ * with the correctly rounded sqrtf on EVERY float bit pattern in [lo_bits, hi_bits] (non-negative floats) on the
+ * device and returns the number of differing results (0 over [2^-100, FLT_MAX] and at 0 is what the kernel relies
+ * on; the GPU tests run the whole range). */
+int vsl_diag_sqrt_check(vsl_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* n_mismatch);
 
 /* ------------------------------------------------ device-resident map (per-frame tracking) */
 /*

@@ -34,6 +34,16 @@ def test_response_bit_exact(ctx, orc, images, name):
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
+def test_fast_sqrt_is_correctly_rounded_everywhere(ctx):
+    """The response kernel's square root (v_rsq_f32 + one fused correction, detect.hip fast_sqrt_rn) against the
+    correctly rounded sqrtf on EVERY float of [2^-100, FLT_MAX] and at 0 -- 2^31 bit patterns, on the device.  Below
+    2^-100 the kernel takes the library path; there the short sequence must NOT be trusted (the check sees that too)."""
+    lo = (127 - 100) << 23
+    assert ctx.sqrt_check(lo, 0x7F7FFFFF) == 0
+    assert ctx.sqrt_check(0, 0) == 0
+    assert ctx.sqrt_check(1, lo - 1) > 0   # the checker can see a wrong result: tiny inputs are wrong without the branch
+
+
 @pytest.mark.parametrize("name", ["left", "right", "noise", "flat", "grad", "checker", "small"])
 @pytest.mark.parametrize("nf", [1500, 100])
 def test_detect_describe_bit_exact(ctx, orc, images, name, nf):
@@ -133,7 +143,7 @@ def test_response_kernel_list_overflow_path(ctx, orc, images, cap):
     try:
         xy, ang, desc = ctx.detect_describe(img, 1500, True)
     finally:
-        ctx.set_diagnostic("k1_list_cap", 256)
+        ctx.set_diagnostic("k1_list_cap", 384)
     oxy, oang, odesc = orc.detect_describe(img, 1500, True)
     assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
 

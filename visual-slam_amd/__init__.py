@@ -158,6 +158,12 @@ class Context:
     def set_tie_eps(self, eps):
         self._ck(self.L.vsl_ctx_set_tie_eps(self.h, C.c_double(eps)))
 
+    def sqrt_check(self, lo_bits, hi_bits):
+        """Mismatches between the response kernel's square root and sqrtf over the float bit patterns [lo, hi]."""
+        n = C.c_ulonglong(0)
+        self._ck(self.L.vsl_diag_sqrt_check(self.h, C.c_uint32(int(lo_bits)), C.c_uint32(int(hi_bits)), C.byref(n)))
+        return int(n.value)
+
     def set_diagnostic(self, name, value):
         self._ck(self.L.vsl_ctx_set_diagnostic(self.h, name.encode(), C.c_int(int(value))))
 

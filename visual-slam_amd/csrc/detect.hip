@@ -19,14 +19,15 @@
 
 #include "vsl_common.h"
 
-// rows per wave strip; (K1_ROWS + 4) % 3 == 0 (the row loop is unrolled by three).  41 rows: 480 rows = 3 workgroups
+// rows per wave strip; (K1_ROWS + 4) % 6 == 3 (three opening steps, then the row loop unrolled by six).  41 rows: 480 rows = 3 workgroups
 // of 4 x 41 with 2 % idle rows and 4 halo rows per 41 instead of per 32 (measured per 1024 images: 29 rows 0.771 ms,
 // 32: 0.740, 41: 0.712, 44: 0.716)
-#define K1_ROWS 41
-static_assert((K1_ROWS + 4) % 3 == 0, "row loop is unrolled by three");
+#ifndef K1_ROWS
+#define K1_ROWS 60
+#endif
 // goodFeaturesToTrack's qualityLevel as the reference passes it (keypoints.h:138): threshold = max response * 0.01
 #define VSL_QUALITY_LEVEL 0.01
-#define K1_WLIST 256  // LDS candidate slots per wave strip (60 x 41 pixels); overflow goes straight to global memory
+#define K1_WLIST 384  // LDS candidate slots per wave strip (60 x 41 pixels); overflow goes straight to global memory
 #define K1_COLS 60  // owned columns per wave: 64 lanes minus two halo lanes on each side
 
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -93,6 +94,13 @@ __device__ __forceinline__ double dpp_below_f64(double v) {
   return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+__device__ __forceinline__ double dpp_above_f64(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x130, 0xf, 0xf, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x130, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
 // one-instruction maximum of three finite floats (fmaxf chains compile to v_max_f32 pairs with
 // canonicalisation; the responses here are never NaN)
 __device__ __forceinline__ float fmax3(float a, float b, float c) {
@@ -107,39 +115,47 @@ __device__ __forceinline__ float fmax2(float a, float b) {  // no NaN canonicali
   return r;
 }
 
-// Correctly rounded fp32 square root = what sqrtf compiles to under hipcc's default
-// -fhip-fp32-correctly-rounded-divide-sqrt (v_sqrt_f32 is good to 1 ulp; the two exact FMA residuals of
-// the neighbouring floats pick the correctly rounded one), minus that expansion's denormal pre-scaling
-// and inf/zero class test: t = 0 falls through both residual tests (NaN / zero compare false), and the
-// rare denormal-range t (rounding-noise gradients in an otherwise flat patch) takes the library path.
-// xmy = X - Y and bb = b * b are the operands t was formed from (t = fma(0.25, xmy * xmy, bb)): the rare path
-// re-forms t the unfused way.
-__device__ __forceinline__ float sqrt_rn(float t, float xmy, float bb) {
-  float r = __builtin_amdgcn_sqrtf(t);
-  const int rb = __builtin_bit_cast(int, r);
-  const float rm = __builtin_bit_cast(float, rb - 1);
-  const float rp = __builtin_bit_cast(float, rb + 1);
-  const float em = __builtin_fmaf(-rm, r, t);
-  const float ep = __builtin_fmaf(-rp, r, t);
-  r = (0.f >= em) ? rm : r;
-  r = (0.f < ep) ? rp : r;
-  // Rare path (wave-uniform branch), two reasons:
-  //  * 0 < sqrt(t) < 2^-47 (a superset of 0 < t < 2^-96, where the residuals lose bits), tested on the integer the
-  //    correction computed anyway: one unsigned compare (r = 0 wraps to 0xffffffff and is not "tiny");
-  //  * |X - Y| < 2^-62: ((X - Y)/2)^2 is then below FLT_MIN and rounds on the denormal grid, where
-  //    0.25 * fl((X - Y)^2) and fl(((X - Y)/2)^2) can differ by one denormal unit -- the only place where the fused
-  //    form of t is not the unfused sum bit for bit.  (Such X, Y are below 2e-12: flat, noise-level patches.)
-  const bool rare = (unsigned)(rb - 1) < 0x27FFFFFFu || __builtin_fabsf(xmy) < 0x1p-62f;
-  if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {  // keeps the library expansion off the common path
+// Correctly rounded fp32 square root (what sqrtf is under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt) in
+// six issue slots: y = v_rsq_f32(t) (1 ulp), r = t * y (within ~2 ulp of the root), then one Markstein correction
+// r' = fma(fma(-r, r, t), y / 2, r): the residual t - r^2 is exact in the fused multiply-add, the corrected value is
+// within 2^-44 relative of the root before its single rounding.  That this IS the correctly rounded root for every
+// float in [2^-100, 2^128) on gfx950 is not argued but checked exhaustively (tools/probes/sqrt_exhaustive.hip, and
+// tests/test_keypoints_gpu.py::test_fast_sqrt_is_correctly_rounded_everywhere through vsl_diag_sqrt_check): 0
+// mismatches with sqrtf over all 2^31 bit patterns of that range.  v_sqrt_f32 + the two neighbour residuals used before
+// cost two more v_cmp / v_cndmask pairs (4.2 + 3.1 cycles each against 2.3 for an fma).
+//  * t = 0 (flat patches): rsq sees K1_SQRT_FLOOR instead (no infinity), r = 0 * y = 0, residual 0, result 0.
+//  * 0 < t < 2^-100 (cannot arise from the sums above other than through cancellation to the last bits): wave-uniform
+//    branch to the library expansion; a wave that only holds zeros leaves it after one more compare.
+#define K1_SQRT_FLOOR 0x1p-100f
+__device__ __forceinline__ float fast_sqrt_rn(float t) {
+  const float y = __builtin_amdgcn_rsqf(__builtin_fmaxf(t, K1_SQRT_FLOOR));
+  const float r = t * y;
+  const float e = __builtin_fmaf(-r, r, t);
+  return __builtin_fmaf(e, 0.5f * y, r);
+}
+__device__ __forceinline__ float sqrt_rn(float t) {
+  float r = fast_sqrt_rn(t);
+  const bool small = t < K1_SQRT_FLOOR;
+  if (__builtin_amdgcn_ballot_w64(small) != 0ull) {  // keeps the library expansion off the common path
     asm volatile("" ::: "memory");  // not speculatable: stops the compiler from flattening the branch
-    if (rare) {
-      const float d = 0.5f * xmy;
-      float t0 = d * d;
-      t0 = t0 + bb;
-      r = sqrtf(t0);
+    const bool rare = small && t > 0.f;
+    if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
+      asm volatile("" ::: "memory");
+      if (rare) r = sqrtf(t);
     }
   }
   return r;
+}
+
+// diagnostic behind vsl_diag_sqrt_check: compares fast_sqrt_rn with sqrtf on every float bit pattern in [lo, hi]
+__global__ void sqrt_check_kernel(uint32_t lo, uint32_t hi, unsigned long long* bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long n = 0;
+  for (uint64_t b = (uint64_t)lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
+    const float t = __builtin_bit_cast(float, (uint32_t)b);
+    n += __builtin_bit_cast(uint32_t, fast_sqrt_rn(t)) != __builtin_bit_cast(uint32_t, sqrtf(t));
+  }
+  if (n) atomicAdd(bad, n);
 }
 
 __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
@@ -169,13 +185,14 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 // differ on an image whose responses are all negative.)
 // Key = (order-preserving fp32 bits << 32) | pixel index: a descending sort on the key is the
 // reference's order (value descending, equal values by address descending).
-template <bool STORE_RESPONSE>
+template <bool STORE_RESPONSE, int XMODE>
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
                                                                float* __restrict__ response, int32_t* __restrict__ meta,
                                                                uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
                                                                int first, int wlist_cap, int n_images, int tiles_x, int tiles_y) {
   __shared__ uint64_t list[4][K1_WLIST];  // wave-private lists: appended with a scalar counter, no atomics
   __shared__ int wave_n[4], wave_max[4], g_base;
+  __shared__ double xbuf[4][3][66];  // EXPERIMENT: lane exchange through LDS memory
   // XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and the 39 strips of a
   // 752 x 480 image overlap in halo rows and share 128-byte lines between neighbouring column strips.  With the plain
   // (x, y, image) grid every XCD fetched most of every image (FETCH_SIZE, calibrated: 3.75 x the image bytes per
@@ -213,26 +230,33 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const unsigned long long cand_lanes = __builtin_amdgcn_ballot_w64(cand_col);
     const int from_above = ((lane + 1) & 63) << 2;  // ds_bpermute address: the lane above
 
-    // Three generations of row sums / response rows live in registers; the row loop is unrolled by
-    // three with the roles rotated by NAME (no register-to-register moves).
-    struct Gen {
-      double xx, xy, yy;  // fp64 row sums R(x, q)
-      float v;            // response row
+    // Register state of the walk down the strip (roles rotated by NAME, no register-to-register moves):
+    //  * two generations of fp64 row sums R(x, q) and one PAIR sum.  Every fp64 sum here is exact (each product is a
+    //    multiple of 2^-47 below 1; nine of them fit 53 bits), so the order is free and consecutive rows share a pair:
+    //      even step q:  B = R(q-1) + R(q),  A(q-1) = R(q-2) + B        odd step q+1:  A(q) = B + R(q+1)
+    //    -- three fp64 additions per product per two rows instead of four;
+    //  * two response rows (period 2, tied to the parity) and three rows of horizontal 3-maxima H (period 3);
+    //  * the row filters of three consecutive rows (period 3).  The row loop is therefore unrolled by six.
+    struct R3 {
+      double xx, xy, yy;
     };
-    Gen g0 = {0, 0, 0, 0.f}, g1 = g0, g2 = g0;
-    RowF fA = {0.f, 0.f}, fB = fA, fC = fA;  // row filters of three consecutive rows, roles rotated by name like the Gen slots
+    R3 ra = {0, 0, 0}, rb = ra, bs = ra;
+    float va = 0.f, vb = 0.f, hA = 0.f, hB = 0.f, hC = 0.f;
+    RowF fA = {0.f, 0.f}, fB = fA, fC = fA;  // row filters of three consecutive rows
     int prev_ye = -100, pre_row = -100;
     RowRaw pre = {0u, 0u, 0u};
     float vmax = -3.0e38f;
     const int y_end = min(h, y0 + K1_ROWS);
-    // one step: q = row whose row sums are produced into `cur`; `pm1`/`pm2` hold rows q-1 / q-2.
-    // Afterwards cur.v is the response of row q-1, and the candidate row is q-2 (rows q-3, q-2, q-1 =
-    // pm2.v (old), pm1.v (old), cur.v) -- the response slots lag the row-sum slots by one row.
+    // one step: q = row whose row sums are produced (into the slot of row q-2, dead by then).  Afterwards v_dn is the
+    // response of row q-1 and h_dn its horizontal 3-maximum; the candidate row is q-2 (v_mid; H rows q-3, q-2, q-1).
     // STEADY (compile-time): the caller guarantees rows q-1 .. q+1 are inside the image and that the previous
     // step was row q-1, so f0 / f1 / `pre` are already what this step needs -- no reload path, hence no join
     // whose register copies would land on the common path.
-    auto step = [&](auto steady_tag, int q, Gen& pm2, Gen& pm1, Gen& cur, RowF& f0, RowF& f1, RowF& f2) {
+    // EVEN (compile-time): parity of the step index (see above); r2 / r1 hold R(q-2) / R(q-1).
+    auto step = [&](auto steady_tag, auto even_tag, int q, R3& r2, R3& r1, float& v_mid_slot, float& v_dn_slot, float& h_up,
+                    float& h_mid, float& h_dn, RowF& f0, RowF& f1, RowF& f2) {
       constexpr bool STEADY = decltype(steady_tag)::value;
+      constexpr bool EVEN = decltype(even_tag)::value;
       // on entry (steady state) f0 / f1 hold rows ye-1 / ye from the previous step and f2 is the dead slot
       if (STEADY) {
         f2 = rowfilt(pre, s, s2);
@@ -257,46 +281,74 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       // fp64 row sums R(x, q) = (left + centre) + right of the three product images: each product is widened once
       // and its two neighbours' copies are fetched as fp64 (exact either way)
       const double dxx = (double)(dx * dx), dxy = (double)(dx * dy), dyy = (double)(dy * dy);
-      // response rows of the two previous steps, read before `cur` (= the slot of row q-3) is overwritten
-      const float v_up = pm2.v;   // response row q-3
-      const float v_mid = pm1.v;  // response row q-2
-      cur.xx = (dpp_below_f64(dxx) + dxx) + shift_f64(dxx, from_above);
-      cur.xy = (dpp_below_f64(dxy) + dxy) + shift_f64(dxy, from_above);
-      cur.yy = (dpp_below_f64(dyy) + dyy) + shift_f64(dyy, from_above);
+      R3 cur;
+      {
+        constexpr int M0 = XMODE % 3, M1 = (XMODE / 3) % 3, M2 = (XMODE / 9) % 3;
+        if (M0 == 1) xbuf[wave][0][lane + 1] = dxx;
+        if (M1 == 1) xbuf[wave][1][lane + 1] = dxy;
+        if (M2 == 1) xbuf[wave][2][lane + 1] = dyy;
+        asm volatile("" ::: "memory");
+        double lxx, lxy, lyy, uxx, uxy, uyy;
+        if (M0 == 1) { lxx = xbuf[wave][0][lane]; uxx = xbuf[wave][0][lane + 2]; }
+        if (M1 == 1) { lxy = xbuf[wave][1][lane]; uxy = xbuf[wave][1][lane + 2]; }
+        if (M2 == 1) { lyy = xbuf[wave][2][lane]; uyy = xbuf[wave][2][lane + 2]; }
+        asm volatile("" ::: "memory");
+        if (M0 == 0) { lxx = dpp_below_f64(dxx); uxx = shift_f64(dxx, from_above); }
+        if (M1 == 0) { lxy = dpp_below_f64(dxy); uxy = shift_f64(dxy, from_above); }
+        if (M2 == 0) { lyy = dpp_below_f64(dyy); uyy = shift_f64(dyy, from_above); }
+        if (M0 == 2) { lxx = dpp_below_f64(dxx); uxx = dpp_above_f64(dxx); }
+        if (M1 == 2) { lxy = dpp_below_f64(dxy); uxy = dpp_above_f64(dxy); }
+        if (M2 == 2) { lyy = dpp_below_f64(dyy); uyy = dpp_above_f64(dyy); }
+        cur.xx = (lxx + dxx) + uxx;
+        cur.xy = (lxy + dxy) + uxy;
+        cur.yy = (lyy + dyy) + uyy;
+      }
       // response of row y = q - 1 from the row sums of rows q-2, q-1, q
       const int y = q - 1;
-      const double Axx = (pm2.xx + pm1.xx) + cur.xx;
-      const double Axy = (pm2.xy + pm1.xy) + cur.xy;
-      const double Ayy = (pm2.yy + pm1.yy) + cur.yy;
-      // lambda_min = (a + c) - sqrt((a - c)^2 + b^2) with a = X/2, c = Y/2.  Halving is exact, so it commutes
-      // with every rounding: a - c = fl(X - Y)/2, fl((a - c)^2) = fl((X - Y)^2)/4, a + c = fl(X + Y)/2; the two
-      // fused multiply-adds below round exactly the sums the unfused sequence rounds (their products are exact; the
-      // one exception, (X - Y)^2 / 4 in the denormal range, takes sqrt_rn's rare path).
+      double Axx, Axy, Ayy;
+      if (EVEN) {
+        bs.xx = r1.xx + cur.xx;
+        bs.xy = r1.xy + cur.xy;
+        bs.yy = r1.yy + cur.yy;
+        Axx = r2.xx + bs.xx;
+        Axy = r2.xy + bs.xy;
+        Ayy = r2.yy + bs.yy;
+      } else {
+        Axx = bs.xx + cur.xx;
+        Axy = bs.xy + cur.xy;
+        Ayy = bs.yy + cur.yy;
+      }
+      r2 = cur;  // the slot of row q-2 is dead
+      // lambda_min = (a + c) - sqrt((a - c)^2 + b^2) with a = X/2, c = Y/2.  Halving is exact (X, Y are zero or above
+      // 2^-25: never denormal), so a - c = fl(X - Y)/2 and a + c = fl(X + Y)/2: the difference is halved before it is
+      // squared like the oracle does, the sum inside the last fused multiply-add (its product is exact).
       const float X = (float)Axx, b = (float)Axy, Y = (float)Ayy;
-      const float xpy = X + Y, xmy = X - Y;
-      const float bb = b * b;
-      const float t = __builtin_fmaf(0.25f, xmy * xmy, bb);
-      // sqrtf is correctly rounded under hipcc's default flags; __fsqrt_rn is the approximate native sqrt
-      const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t, xmy, bb));
+      const float xpy = X + Y, d = 0.5f * (X - Y);
+      float t = d * d;
+      t = t + b * b;
+      const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t));
       if (own_col && y >= y0 && y < y_end) {
         if (STORE_RESPONSE) resp[y * w + x] = v_dn;
         vmax = fmax2(vmax, v_dn);
       }
-      // candidate test for row yc = q - 2 (rows yc-1, yc, yc+1 = v_up, v_mid, v_dn): v_mid > 0 and no larger
-      // value among its 8 neighbours  <=>  v_mid >= max(neighbours, smallest positive float); the column maxima
-      // of the two neighbouring lanes bring in the six side neighbours
+      // horizontal 3-maximum of the new response row: two v_max_f32 with a DPP source (bound_ctrl:0 feeds 0.0 into
+      // lanes 0 / 63, halo lanes whose H is never used by an owned column)
+      {
+        float m;
+        asm("v_max_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(m) : "v"(v_dn), "v"(v_dn));
+        asm("v_max_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(h_dn) : "v"(v_dn), "v"(m));
+      }
+      // candidate test for row yc = q - 2: v_mid > 0 and no larger value among its 8 neighbours  <=>  v_mid > 0 and
+      // v_mid >= the maximum of the 3 x 3 block (itself included) = max3 of the three H rows.  The sign test waits
+      // inside the branch: rows without any local maximum (most rows) never pay for it.
+      const float v_mid = v_mid_slot;
       const int yc = q - 2;
       if (yc >= y0 && yc < y_end && yc >= 1 && yc < h - 1) {  // scalar
-        const float colmax = fmax3(v_up, v_mid, v_dn);
-        // the neighbours' column maxima folded into the maximum itself (v_max_f32 with a DPP source: one issue slot
-        // each instead of a DPP move plus its share of a v_max3); bound_ctrl:0 feeds 0.0 into lanes 0 / 63 (halo lanes)
-        float m8;
-        asm("v_max_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(m8) : "v"(colmax), "v"(__builtin_bit_cast(float, 1)));
-        asm("v_max_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(m8) : "v"(colmax), "v"(m8));
-        m8 = fmax3(m8, v_up, v_dn);
-        const bool ge = v_mid >= m8;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ge) & cand_lanes;  // the compare's own lane mask
-        if (mask != 0ull) {
+        const float m9 = fmax3(h_up, h_mid, h_dn);
+        const bool ge0 = v_mid >= m9;
+        if ((__builtin_amdgcn_ballot_w64(ge0) & cand_lanes) != 0ull) {
+          const bool ge = ge0 && v_mid > 0.f;
+          const unsigned long long mask = __builtin_amdgcn_ballot_w64(ge) & cand_lanes;
           if (cand_col && ge) {
             const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
             const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
@@ -304,7 +356,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             if (__builtin_expect(p < wlist_cap, 1)) {
               list[wave][p] = key;
-            } else {  // more than K1_WLIST candidates in one 60 x 32 strip (plateaus): rare direct append
+            } else {  // more than K1_WLIST candidates in one 60 x 41 strip (plateaus): rare direct append
               const int g = atomicAdd(&meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND], 1);
               if ((size_t)g < cand_cap) cand[(size_t)slot * cand_cap + g] = key;
             }
@@ -312,32 +364,59 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
           n_wave += __popcll(mask);
         }
       }
-      // the response of row q-1 is stored in the slot of the row sums of row q-1 (pm1) for the next steps
-      // -- but pm1.v currently holds response row q-2, still needed as "v_up" next step; so the response
-      // rows are kept in the slot that is overwritten last: cur (row sums of q) receives response q-1.
-      cur.v = v_dn;
+      v_dn_slot = v_dn;
     };
-    // response slots: after a step, cur.v = resp(q-1); at the next step (q+1) that slot is "pm1" and is
-    // read as v_mid = resp(q-1) = resp((q+1)-2) -- consistent with the reads above.
     const int q_first = y0 - 2, q_last = y_end + 1;
     typedef std::integral_constant<bool, true> Steady;
     typedef std::integral_constant<bool, false> Generic;
-    if (q_first >= 1 && q_last + 1 < h) {  // scalar: a strip whose halo rows are all interior (13 of 15 at 480 rows)
-      step(Generic{}, q_first, g0, g1, g2, fA, fB, fC);
-      step(Steady{}, q_first + 1, g1, g2, g0, fB, fC, fA);
-      step(Steady{}, q_first + 2, g2, g0, g1, fC, fA, fB);
-      for (int q = q_first + 3; q <= q_last; q += 3) {
-        step(Steady{}, q, g0, g1, g2, fA, fB, fC);
-        step(Steady{}, q + 1, g1, g2, g0, fB, fC, fA);
-        step(Steady{}, q + 2, g2, g0, g1, fC, fA, fB);
-      }
+    typedef std::integral_constant<bool, true> Even;
+    typedef std::integral_constant<bool, false> Odd;
+    // step i of the strip (i = q - q_first): parity i % 2, H / row-filter roles i % 3
+#define K1_STEP_E0(T, q) step(T{}, Even{}, q, ra, rb, va, vb, hA, hB, hC, fA, fB, fC)
+#define K1_STEP_O1(T, q) step(T{}, Odd{}, q, rb, ra, vb, va, hB, hC, hA, fB, fC, fA)
+#define K1_STEP_E2(T, q) step(T{}, Even{}, q, ra, rb, va, vb, hC, hA, hB, fC, fA, fB)
+#define K1_STEP_O3(T, q) step(T{}, Odd{}, q, rb, ra, vb, va, hA, hB, hC, fA, fB, fC)
+#define K1_STEP_E4(T, q) step(T{}, Even{}, q, ra, rb, va, vb, hB, hC, hA, fB, fC, fA)
+#define K1_STEP_O5(T, q) step(T{}, Odd{}, q, rb, ra, vb, va, hC, hA, hB, fC, fA, fB)
+    // K1_OPEN opening steps (the first one reloads everything), then the loop unrolled by six starting at role K1_OPEN
+    constexpr int K1_OPEN = (K1_ROWS + 4) % 6;
+    static_assert(K1_OPEN == 3 || K1_OPEN == 4, "opening sequence written for 3 or 4 steps");
+#define K1_STRIP(T)                                \
+  K1_STEP_E0(Generic, q_first);                    \
+  K1_STEP_O1(T, q_first + 1);                      \
+  K1_STEP_E2(T, q_first + 2);                      \
+  if constexpr (K1_OPEN == 3) {                    \
+    for (int q = q_first + 3; q <= q_last; q += 6) { \
+      K1_STEP_O3(T, q);                            \
+      K1_STEP_E4(T, q + 1);                        \
+      K1_STEP_O5(T, q + 2);                        \
+      K1_STEP_E0(T, q + 3);                        \
+      K1_STEP_O1(T, q + 4);                        \
+      K1_STEP_E2(T, q + 5);                        \
+    }                                              \
+  } else {                                         \
+    K1_STEP_O3(T, q_first + 3);                    \
+    for (int q = q_first + 4; q <= q_last; q += 6) { \
+      K1_STEP_E4(T, q);                            \
+      K1_STEP_O5(T, q + 1);                        \
+      K1_STEP_E0(T, q + 2);                        \
+      K1_STEP_O1(T, q + 3);                        \
+      K1_STEP_E2(T, q + 4);                        \
+      K1_STEP_O3(T, q + 5);                        \
+    }                                              \
+  }
+    if (q_first >= 1 && q_last + 1 < h) {  // scalar: a strip whose halo rows are all interior
+      K1_STRIP(Steady)
     } else {
-      for (int q = q_first; q <= q_last; q += 3) {
-        step(Generic{}, q, g0, g1, g2, fA, fB, fC);
-        step(Generic{}, q + 1, g1, g2, g0, fB, fC, fA);
-        step(Generic{}, q + 2, g2, g0, g1, fC, fA, fB);
-      }
+      K1_STRIP(Generic)
     }
+#undef K1_STRIP
+#undef K1_STEP_E0
+#undef K1_STEP_O1
+#undef K1_STEP_E2
+#undef K1_STEP_O3
+#undef K1_STEP_E4
+#undef K1_STEP_O5
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     own_max = vsl_float_to_ordered(vmax);
@@ -801,6 +880,23 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   }
 }
 
+// Diagnostic: the response kernel's square root against the correctly rounded library sqrtf on every float bit
+// pattern in [lo_bits, hi_bits] (both must be non-negative floats); *n_mismatch = number of differing results.
+extern "C" int vsl_diag_sqrt_check(vsl_ctx* ctx, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* n_mismatch) {
+  if (!ctx || !n_mismatch || lo_bits > hi_bits || hi_bits > 0x7f7fffffu)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_diag_sqrt_check: bad range");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  void* d = nullptr;
+  int rc = vsl_ctx_dscratch(ctx, sizeof(unsigned long long), &d);
+  if (rc) return rc;
+  VSL_HIP(ctx, hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(sqrt_check_kernel, dim3(4096), dim3(256), 0, ctx->stream, lo_bits, hi_bits, (unsigned long long*)d);
+  VSL_CHECK_LAUNCH(ctx);
+  VSL_HIP(ctx, hipMemcpyAsync(n_mismatch, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VSL_OK;
+}
+
 int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features) {
   if (n <= 0) return VSL_OK;
   if (num_features < 1 || num_features > f->F)
@@ -820,12 +916,17 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     const int tiles_x = (w + K1_COLS - 1) / K1_COLS, tiles_y = (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS);
     const dim3 k1_grid((unsigned)(tiles_x * tiles_y) * (unsigned)(n >= 8 ? 8 * ((n + 7) / 8) : n));
     const int wcap = min(max(ctx->k1_list_cap, 0), K1_WLIST);
-    if (f->store_response)
-      hipLaunchKernelGGL(min_eig_response_kernel<true>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
-                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
-    else
-      hipLaunchKernelGGL(min_eig_response_kernel<false>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
-                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
+#define K1_LAUNCH(SR, XM) hipLaunchKernelGGL((min_eig_response_kernel<SR, XM>), k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta, f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y)
+    if (f->store_response) K1_LAUNCH(true, 0);
+    else switch (ctx->k1_xmode) {
+      case 13: K1_LAUNCH(false, 13); break;  // lds lds lds
+      case 4: K1_LAUNCH(false, 4); break;    // lds lds cur
+      case 22: K1_LAUNCH(false, 22); break;  // lds lds dpp
+      case 1: K1_LAUNCH(false, 1); break;    // lds cur cur
+      case 18: K1_LAUNCH(false, 18); break;  // cur cur dpp
+      case 26: K1_LAUNCH(false, 26); break;  // dpp dpp dpp
+      default: K1_LAUNCH(false, 0); break;
+    }
     VSL_CHECK_LAUNCH(ctx);
   }
   {
