@@ -143,7 +143,7 @@ def test_response_kernel_list_overflow_path(ctx, orc, images, cap):
     try:
         xy, ang, desc = ctx.detect_describe(img, 1500, True)
     finally:
-        ctx.set_diagnostic("k1_list_cap", 384)
+        ctx.set_diagnostic("k1_list_cap", -1)
     oxy, oang, odesc = orc.detect_describe(img, 1500, True)
     assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
 

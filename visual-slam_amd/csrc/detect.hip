@@ -19,15 +19,16 @@
 
 #include "vsl_common.h"
 
-// rows per wave strip; (K1_ROWS + 4) % 6 == 3 (three opening steps, then the row loop unrolled by six).  41 rows: 480 rows = 3 workgroups
-// of 4 x 41 with 2 % idle rows and 4 halo rows per 41 instead of per 32 (measured per 1024 images: 29 rows 0.771 ms,
-// 32: 0.740, 41: 0.712, 44: 0.716)
+// rows per wave strip; (K1_ROWS + 4) % 6 is 3 or 4 (that many opening steps, then the row loop unrolled by six).  Every
+// strip recomputes 4 halo rows, so taller strips waste less; 60 rows: 480 rows = 8 strips = 2 workgroups of 4 waves with
+// no idle wave, and 1024 images are exactly 13 rounds of 8 workgroups per compute unit (measured per 1024 images,
+// older kernel: 29 rows 0.771 ms, 32: 0.740, 41: 0.712, 44: 0.716; this kernel: 41 rows 0.654, 60 rows 0.638)
 #ifndef K1_ROWS
 #define K1_ROWS 60
 #endif
 // goodFeaturesToTrack's qualityLevel as the reference passes it (keypoints.h:138): threshold = max response * 0.01
 #define VSL_QUALITY_LEVEL 0.01
-#define K1_WLIST 384  // LDS candidate slots per wave strip (60 x 41 pixels); overflow goes straight to global memory
+#define K1_WLIST 384  // LDS candidate slots per wave strip (60 x 60 pixels); overflow goes straight to global memory
 #define K1_COLS 60  // owned columns per wave: 64 lanes minus two halo lanes on each side
 
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -72,20 +73,11 @@ __device__ __forceinline__ float from_lane_above(float v) {  // lane i <- lane i
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-// The same shift through the LDS crossbar (ds_bpermute_b32: no LDS memory, no VALU issue slot).  Measured on
-// gfx950 at 8 waves per SIMD (tools/probes/valu_rate.hip): v_add_f32 / v_fma_f32 2 cycles per wave-instruction;
-// v_mov_b32_dpp, v_cvt_f64_f32, v_cvt_f32_ubyte0, v_add_f64, v_pk_*_f32 and v_max3_f32 4; v_sqrt_f32 8.  K1 is
-// VALU-bound, so each product is widened to fp64 ONCE and its neighbours' copies are fetched as fp64: the copy from
-// the lane below by two DPP moves, the copy from the lane above over the otherwise idle LDS pipe (6 ds_bpermute
-// per row step measured best: 0 -> 0.231 ms per 256 images, 4 -> 0.219, 6 -> 0.212, 8 -> 0.219, 10 -> 0.243,
-// all 14 shifts of the step -> 0.295: one ds_bpermute costs about as much LDS time as 2.5 DPP moves cost VALU time).
-// addr = 4 * source lane (lane 0 / 63 wrap around: halo lanes, never used).
-__device__ __forceinline__ double shift_f64(double v, int addr) {
-  const uint64_t b = __builtin_bit_cast(uint64_t, v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)b);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(b >> 32));
-  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
+// K1 is bound by VALU issue slots.  Measured on gfx950 at 8 waves per SIMD (tools/probes/valu_rate.hip, valu_rate2.hip),
+// cycles per wave-instruction per SIMD: v_add_f32 / v_fma_f32 / v_mov_b32 / integer add 2.3; every DPP form (a move or
+// an ALU operation with a DPP source), v_cvt_*, v_cmp_*, v_add_f64, v_pk_*_f32 and v_max3_f32 4.2; v_sqrt_f32 /
+// v_rsq_f32 8.2.  So each product is widened to fp64 ONCE and its neighbours' copies are fetched as fp64 -- through LDS
+// memory where the LDS pipe has room, by two DPP moves per direction otherwise (see the row step).
 // the fp64 value of the lane below as two DPP moves
 __device__ __forceinline__ double dpp_below_f64(double v) {
   const uint64_t b = __builtin_bit_cast(uint64_t, v);
@@ -94,6 +86,7 @@ __device__ __forceinline__ double dpp_below_f64(double v) {
   return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+// ... and of the lane above
 __device__ __forceinline__ double dpp_above_f64(double v) {
   const uint64_t b = __builtin_bit_cast(uint64_t, v);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x130, 0xf, 0xf, true);
@@ -166,9 +159,8 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
   }
 }
 
-// K1 + K2a fused.  grid = (ceil(w/60), ceil(h/(4*K1_ROWS)), n_images), block = 256: wave v of a block owns the
-// K1_ROWS-row strip (blockIdx.y*4 + v) of the 60-column strip blockIdx.x (every strip recomputes 4 halo
-// rows, so taller strips waste less -- see K1_ROWS).
+// K1 + K2a fused.  One workgroup of 256 threads per tile (ceil(w/60) x ceil(h/(4*K1_ROWS)) tiles per image, 1-D grid, see
+// below): wave v owns the K1_ROWS-row strip (tile_y*4 + v) of the 60-column strip tile_x.
 // One image column per lane; rows
 // are walked top to bottom with the row-filter results, the fp64 row sums and three response rows held
 // in registers; column neighbours come from DPP lane shifts.  Nothing but the image is read and -- in
@@ -185,14 +177,15 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 // differ on an image whose responses are all negative.)
 // Key = (order-preserving fp32 bits << 32) | pixel index: a descending sort on the key is the
 // reference's order (value descending, equal values by address descending).
-template <bool STORE_RESPONSE, int XMODE>
+template <bool STORE_RESPONSE>
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
                                                                float* __restrict__ response, int32_t* __restrict__ meta,
                                                                uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
                                                                int first, int wlist_cap, int n_images, int tiles_x, int tiles_y) {
   __shared__ uint64_t list[4][K1_WLIST];  // wave-private lists: appended with a scalar counter, no atomics
   __shared__ int wave_n[4], wave_max[4], g_base;
-  __shared__ double xbuf[4][3][66];  // EXPERIMENT: lane exchange through LDS memory
+  __shared__ double xbuf[4][2][66];  // lane exchange of two of the three products: slot lane + 1 of the wave's row (slots 0 / 65 are
+                                     // read by the halo lanes 0 / 63 only, whose sums are never used)
   // XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and the 39 strips of a
   // 752 x 480 image overlap in halo rows and share 128-byte lines between neighbouring column strips.  With the plain
   // (x, y, image) grid every XCD fetched most of every image (FETCH_SIZE, calibrated: 3.75 x the image bytes per
@@ -228,7 +221,6 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     const bool own_col = lane >= 2 && lane < 2 + K1_COLS && x < w;
     const bool cand_col = own_col && x >= 1 && x < w - 1;
     const unsigned long long cand_lanes = __builtin_amdgcn_ballot_w64(cand_col);
-    const int from_above = ((lane + 1) & 63) << 2;  // ds_bpermute address: the lane above
 
     // Register state of the walk down the strip (roles rotated by NAME, no register-to-register moves):
     //  * two generations of fp64 row sums R(x, q) and one PAIR sum.  Every fp64 sum here is exact (each product is a
@@ -281,27 +273,24 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       // fp64 row sums R(x, q) = (left + centre) + right of the three product images: each product is widened once
       // and its two neighbours' copies are fetched as fp64 (exact either way)
       const double dxx = (double)(dx * dx), dxy = (double)(dx * dy), dyy = (double)(dy * dy);
+      // Lane exchange.  dxx and dxy go through LDS memory: one 8-byte write into the wave's own row, the two neighbours'
+      // copies come back with one ds_read2_b64 (no VALU slot; LDS operations of one wave execute in order, so the
+      // wave-private rows need no barrier -- the compiler barriers keep the reads between this step's and the next
+      // step's writes).  dyy takes four DPP moves: the LDS pipe would saturate with all three (measured per 1024
+      // images: DPP below + ds_bpermute above for all three 0.653 ms, LDS memory for all three 0.641, this mix 0.636,
+      // DPP both ways for all three 0.712; tools/probes/valu_rate2.hip: a ds_write_b64 + ds_read2_b64 pair costs 14
+      // CU-cycles of LDS time, four ds_bpermute_b32 24, a DPP move 4.2 VALU cycles).
       R3 cur;
       {
-        constexpr int M0 = XMODE % 3, M1 = (XMODE / 3) % 3, M2 = (XMODE / 9) % 3;
-        if (M0 == 1) xbuf[wave][0][lane + 1] = dxx;
-        if (M1 == 1) xbuf[wave][1][lane + 1] = dxy;
-        if (M2 == 1) xbuf[wave][2][lane + 1] = dyy;
+        xbuf[wave][0][lane + 1] = dxx;
+        xbuf[wave][1][lane + 1] = dxy;
         asm volatile("" ::: "memory");
-        double lxx, lxy, lyy, uxx, uxy, uyy;
-        if (M0 == 1) { lxx = xbuf[wave][0][lane]; uxx = xbuf[wave][0][lane + 2]; }
-        if (M1 == 1) { lxy = xbuf[wave][1][lane]; uxy = xbuf[wave][1][lane + 2]; }
-        if (M2 == 1) { lyy = xbuf[wave][2][lane]; uyy = xbuf[wave][2][lane + 2]; }
+        const double lxx = xbuf[wave][0][lane], uxx = xbuf[wave][0][lane + 2];
+        const double lxy = xbuf[wave][1][lane], uxy = xbuf[wave][1][lane + 2];
         asm volatile("" ::: "memory");
-        if (M0 == 0) { lxx = dpp_below_f64(dxx); uxx = shift_f64(dxx, from_above); }
-        if (M1 == 0) { lxy = dpp_below_f64(dxy); uxy = shift_f64(dxy, from_above); }
-        if (M2 == 0) { lyy = dpp_below_f64(dyy); uyy = shift_f64(dyy, from_above); }
-        if (M0 == 2) { lxx = dpp_below_f64(dxx); uxx = dpp_above_f64(dxx); }
-        if (M1 == 2) { lxy = dpp_below_f64(dxy); uxy = dpp_above_f64(dxy); }
-        if (M2 == 2) { lyy = dpp_below_f64(dyy); uyy = dpp_above_f64(dyy); }
         cur.xx = (lxx + dxx) + uxx;
         cur.xy = (lxy + dxy) + uxy;
-        cur.yy = (lyy + dyy) + uyy;
+        cur.yy = (dpp_below_f64(dyy) + dyy) + dpp_above_f64(dyy);
       }
       // response of row y = q - 1 from the row sums of rows q-2, q-1, q
       const int y = q - 1;
@@ -913,20 +902,16 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     if (f->detect_meta_dirty)
       hipLaunchKernelGGL(detect_init_kernel, dim3((f->max_images + 255) / 256), dim3(256), 0, ctx->stream, f->meta, 0, f->max_images);
     f->detect_meta_dirty = true;  // until the selection kernel (which resets the counters) is in the queue
-    const int tiles_x = (w + K1_COLS - 1) / K1_COLS, tiles_y = (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS);
+    const int tiles_y = (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS);
+    const int tiles_x = (w + K1_COLS - 1) / K1_COLS;
     const dim3 k1_grid((unsigned)(tiles_x * tiles_y) * (unsigned)(n >= 8 ? 8 * ((n + 7) / 8) : n));
-    const int wcap = min(max(ctx->k1_list_cap, 0), K1_WLIST);
-#define K1_LAUNCH(SR, XM) hipLaunchKernelGGL((min_eig_response_kernel<SR, XM>), k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta, f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y)
-    if (f->store_response) K1_LAUNCH(true, 0);
-    else switch (ctx->k1_xmode) {
-      case 13: K1_LAUNCH(false, 13); break;  // lds lds lds
-      case 4: K1_LAUNCH(false, 4); break;    // lds lds cur
-      case 22: K1_LAUNCH(false, 22); break;  // lds lds dpp
-      case 1: K1_LAUNCH(false, 1); break;    // lds cur cur
-      case 18: K1_LAUNCH(false, 18); break;  // cur cur dpp
-      case 26: K1_LAUNCH(false, 26); break;  // dpp dpp dpp
-      default: K1_LAUNCH(false, 0); break;
-    }
+    const int wcap = ctx->k1_list_cap < 0 ? K1_WLIST : min(ctx->k1_list_cap, K1_WLIST);
+    if (f->store_response)
+      hipLaunchKernelGGL(min_eig_response_kernel<true>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
+    else
+      hipLaunchKernelGGL(min_eig_response_kernel<false>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
     VSL_CHECK_LAUNCH(ctx);
   }
   {

@@ -18,7 +18,6 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "match_use_i8") ctx->match_use_i8 = value != 0;
   else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
-  else if (k == "k1_xmode") ctx->k1_xmode = value;
   else if (k == "exact_list_cap") ctx->exact_list_cap = value;
   else if (k == "ba_schur_entries") ctx->ba_schur_entries = value != 0;
   else if (k == "ba_schur_atomics") ctx->ba_schur_atomics = value != 0;

@@ -69,8 +69,7 @@ struct vsl_ctx {
   bool ba_schur_atomics = false;        // diagnostic: large-system Schur complement by fp64 atomics (one wavefront per landmark) instead of the per-block gather
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
-  int k1_xmode = 22;               // diagnostic: lane-exchange mode of the response kernel per product (base 3: 0 DPP + ds_bpermute, 1 LDS memory, 2 DPP both ways)
-  int k1_list_cap = 384;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
+  int k1_list_cap = -1;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
 
 int vsl_fail(vsl_ctx* ctx, int code, const char* fmt, ...);
