@@ -57,9 +57,12 @@ def test_detect_describe_bit_exact(ctx, orc, images, name, nf):
         assert len(xy) > 1000
 
 
-@pytest.mark.parametrize("w,h", [(40, 40), (41, 57), (59, 40), (60, 64), (61, 65), (121, 49), (333, 251), (640, 480), (753, 481)])
+@pytest.mark.parametrize("w,h", [(40, 40), (41, 57), (59, 40), (60, 64), (61, 65), (121, 49), (333, 251), (640, 480), (753, 481),
+                                 # heights around the response kernel's 60-row strips and 240-row workgroups, widths around its 60-column strips
+                                 (97, 59), (97, 60), (97, 61), (97, 119), (97, 120), (97, 121), (120, 239), (119, 240), (180, 241),
+                                 (61, 301)])
 def test_odd_image_sizes(ctx, orc, w, h):
-    # strip / tile edges of the response kernel (60 columns x 16 rows per wave, 4 waves per workgroup), the
+    # strip / tile edges of the response kernel (60 columns x 60 rows per wave, 4 waves per workgroup), the
     # reflect-101 border rows and the row prefetch at the bottom edge, images smaller than one tile
     rng = np.random.default_rng(w * 1000 + h)
     base = rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8)).astype(np.float32)
