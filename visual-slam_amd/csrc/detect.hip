@@ -493,7 +493,7 @@ __device__ __forceinline__ int block_scan(bool p, int* wave_tot, int& total) {
   return off + within;
 }
 
-// Static LDS: sized for up to SEL_MAX_CELLS 8x8-px cells (752x480 needs 5640); gfx950 lets one
+// Static LDS: sized for up to SEL_MAX_CELLS 8x8-px cells (752x480 needs 96 x 62 = 5952 with the empty ring); gfx950 lets one
 // workgroup own (almost) all 160 KiB of its CU's LDS.
 #define SEL_MAX_CELLS 6144
 // the key array is padded by one key per 32 (bank-conflict relief for the strided layouts of the sort)
@@ -556,7 +556,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   const uint64_t* __restrict__ cand = cand_all + (size_t)slot * cand_cap;
   const int n_cand_raw = meta[(size_t)slot * VSL_META_STRIDE + VSL_META_NCAND];
   const int n_cand = min(n_cand_raw, (int)cand_cap);
-  const int gw = (w + 7) / 8, gh = (h + 7) / 8, cells = gw * gh;
+  // 8 x 8-px cells with a ring of empty cells around the image: every 3 x 3 neighbourhood is nine fixed offsets, no
+  // clamping, so its nine list heads / eighteen accepted slots are independent loads issued together
+  const int gw = (w + 7) / 8 + 2, gh = (h + 7) / 8 + 2, cells = gw * gh;
   // LDS carve-up (all regions 8-byte aligned)
   uint64_t* keys = (uint64_t*)smem;                 // SEL_CHUNK sorted keys
   SelShared* sh = (SelShared*)(keys + SEL_KEYS_PADDED);
@@ -761,21 +763,23 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
         const uint32_t pix = (uint32_t)(keys[SEL_PHYS(r)] & 0xFFFFFFFFull);
         py = (int)(pix / (uint32_t)w);
         px = (int)(pix - (uint32_t)py * (uint32_t)w);
-        cx = px >> 3;
-        cy = py >> 3;
+        cx = (px >> 3) + 1;
+        cy = (py >> 3) + 1;
         cell = cy * gw + cx;
         alive = true;
-        for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); yy++)
-          for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); xx++) {
+        uint32_t a18[18];
 #pragma unroll
-            for (int sidx = 0; sidx < 2; sidx++) {
-              const uint32_t a = acc[2 * (yy * gw + xx) + sidx];
-              if (a != SEL_EMPTY) {
-                const int dx = px - (int)(a & 0xFFFF), dy = py - (int)(a >> 16);
-                if (dx * dx + dy * dy < 64) alive = false;
-              }
-            }
-          }
+        for (int k = 0; k < 9; k++) {
+          const int c2 = cell + (k / 3 - 1) * gw + (k % 3 - 1);
+          a18[2 * k] = acc[2 * c2];
+          a18[2 * k + 1] = acc[2 * c2 + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+          const uint32_t a = a18[k];
+          const int dx = px - (int)(a & 0xFFFF), dy = py - (int)(a >> 16);  // (an empty slot is 0xFFFF, 0xFFFF: far away)
+          if (a != SEL_EMPTY && dx * dx + dy * dy < 64) alive = false;
+        }
       }
       cxy[tid] = (uint32_t)px | ((uint32_t)py << 16);
       state[tid] = alive ? 0 : 2;
@@ -788,18 +792,21 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       int nb = 0;
       int blk[SEL_MAX_BLOCKERS];
       if (alive) {
-        for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); yy++)
-          for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); xx++)
-            for (int u = head[yy * gw + xx]; u >= 0; u = next[u]) {
-              if (u < tid) {
-                const uint32_t q = cxy[u];
-                const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
-                if (dx * dx + dy * dy < 64) {
-                  if (nb < SEL_MAX_BLOCKERS) blk[nb] = u;
-                  nb++;
-                }
+        int h9[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) h9[k] = head[cell + (k / 3 - 1) * gw + (k % 3 - 1)];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+          for (int u = h9[k]; u >= 0; u = next[u]) {
+            if (u < tid) {
+              const uint32_t q = cxy[u];
+              const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
+              if (dx * dx + dy * dy < 64) {
+                if (nb < SEL_MAX_BLOCKERS) blk[nb] = u;
+                nb++;
               }
             }
+          }
       }
       bool undecided = alive;
       while (__ballot(undecided) != 0ull) {
@@ -814,9 +821,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
                 blocked = blocked || (su == 0);
               }
           } else {  // crowded neighbourhood: walk the cell lists again
-            for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); yy++)
-              for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); xx++)
-                for (int u = head[yy * gw + xx]; u >= 0; u = next[u]) {
+            for (int k = 0; k < 9; k++)
+                for (int u = head[cell + (k / 3 - 1) * gw + (k % 3 - 1)]; u >= 0; u = next[u]) {
                   if (u < tid) {
                     const uint32_t q = cxy[u];
                     const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
@@ -891,7 +897,7 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
   if (num_features < 1 || num_features > f->F)
     return vsl_fail(ctx, VSL_ERR_INVALID, "num_features %d not in [1, %d]", num_features, f->F);
   static_assert(sizeof(SelShared) <= 2048, "SelShared fits its LDS slot");
-  const int cells = ((f->w + 7) / 8) * ((f->h + 7) / 8);
+  const int cells = ((f->w + 7) / 8 + 2) * ((f->h + 7) / 8 + 2);  // with the ring of empty cells (select_kernel)
   const bool grid_global = cells > SEL_MAX_CELLS;
   if (grid_global && !f->sel_grid) {
     VSL_HIP(ctx, hipMalloc((void**)&f->sel_grid, sizeof(uint32_t) * 3 * (size_t)cells * f->max_images));
