@@ -11,7 +11,7 @@ detectKeypointsAndDescriptors on 2B images (K1 response, K2 selection, K3+K4 ori
 matchDescriptors(left, right, 70, 1.2) on B pairs (K5); outputs stay in HBM.  The batch is split over S HIP
 streams (default 2 x 512 stereo frames): the selection kernel is one latency-bound workgroup per image and leaves
 most of each CU's issue slots free, so the other stream's response / describe kernels run underneath it.
-One STEP = `--passes` passes (default 14, ~55 ms), so that the driver's 20 timed steps cover > 1 s of sustained
+One STEP = `--passes` passes (default 18, ~62 ms), so that the driver's 20 timed steps cover > 1 s of sustained
 clocks.  `value` = frames of all passes / time, inputs resident in HBM (the contract's definition).
 
 Next to it, at N = 1, the STREAMING mode measures the same hot path fed from the host (`value_incl_upload`):
@@ -172,8 +172,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="distinct stereo frames resident in HBM per GPU (one pass)")
-    ap.add_argument("--passes", type=int, default=14,
-                    help="passes over the resident batch per step (14 x 1024 frames ~ 55 ms: 20 steps > 1 s of sustained clocks)")
+    ap.add_argument("--passes", type=int, default=18,
+                    help="passes over the resident batch per step (18 x 1024 frames ~ 62 ms: 20 steps > 1.2 s of sustained clocks)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batch is split over (512 frames = 1024 images per launch)")
     ap.add_argument("--scenes", type=int, default=64,
@@ -327,7 +327,13 @@ def main():
         # Pass 1: one stream at a time (kernel durations in isolation -> roofline); pass 2: all streams active
         # as in the timed region (durations stretch because kernels of different streams share the CUs).
         def staged(fn):
+            # (the phases before this one end in host work: let the clocks ramp again -- ~50 ms after idle -- before the
+            # profiled passes, as the timed region does; without it the first launches read ~15 % long)
+            t_ramp = time.perf_counter()
+            while time.perf_counter() - t_ramp < 0.12:
+                fn()
             for _, c, _ in units:
+                c.synchronize()
                 c.set_profiling(True)
                 c.reset_profiling()
             for _ in range(max(1, args.profile_steps)):

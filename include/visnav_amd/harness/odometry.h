@@ -13,6 +13,8 @@
 //   optimize() + the merge-back of its result src/slam.cpp:1510-1571, :1379-1412
 //   alignSVD / align_svd (ATE)                src/slam.cpp:1618-1722
 #pragma once
+#include <cstdlib>
+#include <cstdio>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -354,7 +356,19 @@ class Odometry {
       auto t4 = Clk::now();
       localize(fcidl, img_left, kdl, md);
       auto t5 = Clk::now();
+      const size_t lm_before = landmarks.size();
       add_new_landmarks(fcidl, fcidr, kdl, kdr, calib_cam, md_stereo, md, landmarks, next_landmark_id);
+      if (std::getenv("VISNAV_AMD_TRACE_FRAMES")) {
+        unsigned long long hl = 1469598103934665603ull, hr = hl, hm = hl;
+        for (const auto& d : kdl.corner_descriptors) hl = (hl ^ (unsigned long long)(d.to_string().substr(0, 64).size() + d.count())) * 1099511628211ull;
+        for (const auto& d : kdr.corner_descriptors) hr = (hr ^ (unsigned long long)d.count()) * 1099511628211ull;
+        for (const auto& m : md_stereo.matches) hm = (hm ^ (unsigned long long)(m.first * 4099 + m.second)) * 1099511628211ull;
+        if (std::getenv("VISNAV_AMD_TRACE_DESC") && (int)fcidl.frame_id == std::atoi(std::getenv("VISNAV_AMD_TRACE_DESC")))
+          for (size_t i = 0; i < kdl.corner_descriptors.size(); i++)
+            std::fprintf(stderr, "DESC %zu %.1f %.1f %.17g %s\n", i, kdl.corners[i][0], kdl.corners[i][1], kdl.corner_angles[i], kdl.corner_descriptors[i].to_string().c_str());
+        std::fprintf(stderr, "  keyframe %d: kp L %zu R %zu (hash %llx %llx) stereo matches %zu (hash %llx) inliers %zu, landmarks %zu -> %zu\n", (int)fcidl.frame_id,
+                     kdl.corners.size(), kdr.corners.size(), hl, hr, md_stereo.matches.size(), hm, md_stereo.inliers.size(), lm_before, landmarks.size());
+      }
       Camera cam_left, cam_right;
       cam_left.T_w_c = current_pose;
       const bool graph_needed = opt.enable_relocalization || opt.enable_loop_closure;
@@ -460,6 +474,11 @@ class Odometry {
     }
     last_inliers = (int)md.inliers.size();
     last_matches = (int)md.matches.size();
+    if (std::getenv("VISNAV_AMD_TRACE_FRAMES")) {  // one line per frame: where two runs part ways
+      const double* t = current_pose.data() + 4;
+      std::fprintf(stderr, "frame %d matches %d inliers %d landmarks %zu pose %.12f %.12f %.12f\n", (int)current_frame, last_matches,
+                   last_inliers, landmarks.size(), t[0], t[1], t[2]);
+    }
     frame_poses.push_back(current_pose);
     current_frame++;
     vel = se3_mul(se3_inv(last_pose), current_pose);  // src/slam.cpp:1300-1301, :1454-1455
@@ -569,6 +588,12 @@ class Odometry {
     auto work = [this, fid, ba_options] {
       const std::set<FrameCamId> fixed_cameras = {FrameCamId(fid, 0), FrameCamId(fid, 1)};
       bundle_adjustment(corners_opt, ba_options, fixed_cameras, calib_cam_opt, cameras_opt, landmarks_opt);
+      if (std::getenv("VISNAV_AMD_TRACE_FRAMES")) {
+        double h = 0;
+        for (const auto& kv : cameras_opt) h += kv.second.T_w_c.data()[4] * 1.7 + kv.second.T_w_c.data()[5];
+        for (const auto& kv : landmarks_opt) h += kv.second.p[0] + kv.second.p[2] * 0.3;
+        std::fprintf(stderr, "  local BA after frame %d: %zu cameras %zu landmarks checksum %.15g\n", (int)fid, cameras_opt.size(), landmarks_opt.size(), h);
+      }
       opt_finished = true;
       opt_running = false;
     };

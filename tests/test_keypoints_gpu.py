@@ -44,6 +44,21 @@ def test_fast_sqrt_is_correctly_rounded_everywhere(ctx):
     assert ctx.sqrt_check(1, lo - 1) > 0   # the checker can see a wrong result: tiny inputs are wrong without the branch
 
 
+@pytest.mark.parametrize("seed,side", [(29, 0), (29, 1), (40, 1), (43, 0), (0, 1)])
+def test_single_image_calls_do_not_depend_on_timing(ctx, orc, synth, seed, side):
+    """Regression.  The response kernel forms its horizontal 3-maxima with DPP sources, and a DPP source lane that an
+    exec-mask restore re-enabled a few instructions earlier reads as 0: the row above a strip (where the strip-maximum
+    update is masked off for every lane) lost its neighbours' responses and the strip's first row (rows 60, 120, ...)
+    emitted false local maxima, some of which displaced real corners.  Only ONE-image launches showed it (a lone wave
+    per SIMD issues back to back; in a batch the other waves' instructions space the two out), which is how it passed
+    the batch tests and surfaced as a 1-in-4 flake of the headless pipeline.  These frames failed 5-6 times of 6."""
+    img = synth.stereo_pair(seed)[side]
+    oxy, oang, odesc = orc.detect_describe(img, 1500, True)
+    for it in range(8):
+        xy, ang, desc = ctx.detect_describe(img, 1500, True)
+        assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc), it
+
+
 @pytest.mark.parametrize("name", ["left", "right", "noise", "flat", "grad", "checker", "small"])
 @pytest.mark.parametrize("nf", [1500, 100])
 def test_detect_describe_bit_exact(ctx, orc, images, name, nf):

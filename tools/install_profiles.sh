@@ -17,7 +17,7 @@ python - $R <<'PY'
 import csv, glob, statistics, re, sys
 R = sys.argv[1]
 f = glob.glob('gpurun_out/refresh/kt1/*/*_kernel_trace.csv')[0]
-lines = ["rocprofv3 --kernel-trace of `python3 bench.py --streams 1 --batch 512 --passes 14 --steps 20 --warmup 5 --cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0` (tools/refresh_profiles.sh):",
+lines = ["rocprofv3 --kernel-trace of `python3 bench.py --streams 1 --batch 512 --passes 18 --steps 20 --warmup 5 --cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0` (tools/refresh_profiles.sh):",
          "per-launch kernel durations in microseconds, 512 stereo frames = 1024 images per launch; the HIP events of bench.py cover the LAST 5 passes."]
 d = {}
 for r in csv.DictReader(open(f)):

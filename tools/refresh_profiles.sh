@@ -9,7 +9,7 @@ set -e
 R=$PWD
 ROUND=${1:-r02}
 O=$R/gpurun_out/refresh
-rm -rf $O && mkdir -p $O
+rm -rf $O && mkdir -p $O  # (clear the LOCAL gpurun_out/refresh too before a new run: gpurun merges, it does not delete)
 cd /tmp && export TMPDIR=/tmp
 LITE="--cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0 --gen-workers 1"
 # (no forked generator workers under the profiler: the frames are generated once here and cached under /tmp)
@@ -24,8 +24,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib/write -- $R/tools/pro
 python3 $R/tools/pmc_summary.py $O $R/profiles/${ROUND}_pmc_traffic.json 512 > $O/pmc_summary.log 2>&1
 echo bench; (cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench.err)
 # kernel durations: one stream (the isolated durations the roofline uses) and the default two-stream run
-# (as long as the default run -- 14 passes x 20 steps after 5 warm-up steps -- so that the trace sees the sustained clocks the bench line's stage times see)
-echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 14 --steps 20 --warmup 5 $LITE > $O/kt1.log 2>&1
+# (as long as the default run -- 18 passes x 20 steps after 5 warm-up steps -- so that the trace sees the sustained clocks the bench line's stage times see)
+echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 18 --steps 20 --warmup 5 $LITE > $O/kt1.log 2>&1
 echo kt2; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 $R/bench.py --passes 8 --steps 6 --warmup 2 $LITE > $O/kt2.log 2>&1
 # per-frame kernels: SQ counters of the bench launch (what binds K1 / describe / select / match)
 echo fsq; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --output-format csv -d $O/fsq -- python3 $R/bench.py $PMCARGS > $O/fsq.log 2>&1

@@ -191,8 +191,8 @@ static hipError_t dalloc(T** p, size_t n) {
 int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_pairs, vsl_frames** out) {
   if (!ctx || !out) return VSL_ERR_INVALID;
   *out = nullptr;
-  if (max_images <= 0 || w < 40 || h < 40 || F <= 0 || max_pairs < 0 || (int64_t)w * h >= (1ll << 31) ||
-      F >= (1 << 22))
+  if (max_images <= 0 || w < 40 || h < 40 || w > 65535 || h > 65535 || F <= 0 || max_pairs < 0 || (int64_t)w * h >= (1ll << 31) ||
+      F >= (1 << 22))  // (corner candidates carry their position as y << 16 | x)
     return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_frames_create: bad sizes images=%d w=%d h=%d F=%d pairs=%d", max_images, w, h, F, max_pairs);
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   vsl_frames* f = new (std::nothrow) vsl_frames;

@@ -175,7 +175,8 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 // candidates", a superset), and the selection kernel drops those at or below the threshold once the
 // maximum is known.  (A response image whose maximum is <= 0 yields no corners here; OpenCV could only
 // differ on an image whose responses are all negative.)
-// Key = (order-preserving fp32 bits << 32) | pixel index: a descending sort on the key is the
+// Key = (order-preserving fp32 bits << 32) | y << 16 | x (ordered like the pixel index y * w + x, and the selection
+// kernel gets the position back without a division): a descending sort on the key is the
 // reference's order (value descending, equal values by address descending).
 template <bool STORE_RESPONSE>
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
@@ -316,16 +317,20 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       float t = d * d;
       t = t + b * b;
       const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t));
+      float h_tmp;
+      // horizontal 3-maximum of the new response row: two v_max_f32 with a DPP source (bound_ctrl:0 feeds 0.0 into
+      // lanes 0 / 63, halo lanes whose H is never used by an owned column).  ONE volatile block placed BEFORE the
+      // exec-masked maximum update below, with its own wait states: a DPP source lane that was disabled a few
+      // instructions earlier reads as 0 -- with the update in front, the row above a strip (where that update is masked
+      // off for every lane) intermittently lost its neighbours' responses and the strip's first row emitted false local
+      // maxima (found on a rendered frame where one of them displaced a real corner: 184 of 200 runs).
+      asm volatile("s_nop 4\n\tv_max_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                   "v_max_f32_dpp %1, %2, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1"
+                   : "=&v"(h_tmp), "=&v"(h_dn)
+                   : "v"(v_dn));
       if (own_col && y >= y0 && y < y_end) {
         if (STORE_RESPONSE) resp[y * w + x] = v_dn;
         vmax = fmax2(vmax, v_dn);
-      }
-      // horizontal 3-maximum of the new response row: two v_max_f32 with a DPP source (bound_ctrl:0 feeds 0.0 into
-      // lanes 0 / 63, halo lanes whose H is never used by an owned column)
-      {
-        float m;
-        asm("v_max_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(m) : "v"(v_dn), "v"(v_dn));
-        asm("v_max_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(h_dn) : "v"(v_dn), "v"(m));
       }
       // candidate test for row yc = q - 2: v_mid > 0 and no larger value among its 8 neighbours  <=>  v_mid > 0 and
       // v_mid >= the maximum of the 3 x 3 block (itself included) = max3 of the three H rows.  The sign test waits
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
           const unsigned long long mask = __builtin_amdgcn_ballot_w64(ge) & cand_lanes;
           if (cand_col && ge) {
             const uint32_t ob = (uint32_t)vsl_float_to_ordered(v_mid) ^ 0x80000000u;
-            const uint64_t key = ((uint64_t)ob << 32) | (uint32_t)(yc * w + x);
+            const uint64_t key = ((uint64_t)ob << 32) | ((uint32_t)yc << 16) | (uint32_t)x;
             const int p = n_wave + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             if (__builtin_expect(p < wlist_cap, 1)) {
@@ -464,7 +469,8 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
 #define SEL_CHUNK 8192
 #define SEL_EMPTY 0xFFFFFFFFu
 #define SEL_BINS 1024      // response bins of the counting sort (= threads of the workgroup)
-#define SEL_MAX_BLOCKERS 6  // blockers of a candidate kept in registers (more: the cell lists are walked again)
+#define SEL_MAX_BLOCKERS 6  // blockers of a candidate kept in registers, 10 bits each in one 64-bit word (more: the cell lists are walked again)
+static_assert(SEL_THREADS <= 1024 && SEL_MAX_BLOCKERS * 10 <= 64, "blocker packing");
 
 struct SelShared {
   int wave_tot[16];
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   const int n_cand = min(n_cand_raw, (int)cand_cap);
   // 8 x 8-px cells with a ring of empty cells around the image: every 3 x 3 neighbourhood is nine fixed offsets, no
   // clamping, so its nine list heads / eighteen accepted slots are independent loads issued together
-  const int gw = (w + 7) / 8 + 2, gh = (h + 7) / 8 + 2, cells = gw * gh;
+  const int gw = (w + 7) / 8 + 2, gh = (h + 7) / 8 + 2, cells = (gw * gh + 1) & ~1;  // (even: the arrays behind stay 8-byte aligned)
   // LDS carve-up (all regions 8-byte aligned)
   uint64_t* keys = (uint64_t*)smem;                 // SEL_CHUNK sorted keys
   SelShared* sh = (SelShared*)(keys + SEL_KEYS_PADDED);
@@ -567,8 +573,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
   volatile uint32_t* acc = GRID_GLOBAL ? (volatile uint32_t*)(grid_scratch + (size_t)slot * cells * 3) : (volatile uint32_t*)(sh + 1);
   volatile int* head = (volatile int*)(acc + 2 * (size_t)cells);
   int* next = GRID_GLOBAL ? (int*)(sh + 1) : (int*)(head + cells);  // SEL_THREADS
-  uint32_t* cxy = (uint32_t*)(next + SEL_THREADS);  // SEL_THREADS: batch candidate position
-  int* state = (int*)(cxy + SEL_THREADS);           // SEL_THREADS: 0 undecided, 1 accepted, 2 rejected
+  // batch member u: node[u] = (position x | y << 16, next member of its cell's list) -- one 8-byte read per list step
+  unsigned long long* node = (unsigned long long*)next;  // SEL_THREADS (the space of `next` and the array after it)
+  int* state = next + 2 * SEL_THREADS;              // SEL_THREADS: 0 undecided, 1 accepted, 2 rejected
   const int tid = threadIdx.x;
 
   for (int i = tid; i < 2 * cells; i += SEL_THREADS) acc[i] = SEL_EMPTY;
@@ -605,19 +612,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
     bcount[tid] = 0;
     if (tid == 0) sh->n_chunk = 0;
     __syncthreads();
-    int mine = 0;
     for (int i = tid; i < n_cand; i += SEL_THREADS) {
       const unsigned long long key = cand[i];
       if (key > floor_key) {
-        mine++;
         // a provisional candidate above the image maximum cannot exist; the clamp keeps a corrupted list in range
         const uint32_t kb = min((uint32_t)(key >> 32) >> bshift, bin_top);
         atomicAdd(&bcount[bin_top - kb], 1);
       }
     }
-    if (mine) atomicAdd(&sh->n_chunk, mine);
     __syncthreads();
-    remaining = sh->n_chunk;
     // exclusive prefix of the bin counts (bin 0 first = descending keys) and the fullest bin
     const int c = bcount[tid];
     int x = c;
@@ -630,14 +633,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
     int cmax = c;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
-    __syncthreads();  // everyone has read n_chunk
     if (lane == 63) sh->wave_tot[wv] = x;
     if (lane == 0) sh->hist[wv] = cmax;
     __syncthreads();
     int off = 0, fullest = 0;
+    remaining = 0;  // number of surviving keys = the total of the bin counts (no per-thread atomic on one LDS word)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       off += k < wv ? sh->wave_tot[k] : 0;
+      remaining += sh->wave_tot[k];
       fullest = max(fullest, sh->hist[k]);
     }
     bstart[tid] = off + x - c;
@@ -761,8 +765,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
       bool alive = false;
       if (r < n_chunk) {
         const uint32_t pix = (uint32_t)(keys[SEL_PHYS(r)] & 0xFFFFFFFFull);
-        py = (int)(pix / (uint32_t)w);
-        px = (int)(pix - (uint32_t)py * (uint32_t)w);
+        py = (int)(pix >> 16);
+        px = (int)(pix & 0xFFFFu);
         cx = (px >> 3) + 1;
         cy = (py >> 3) + 1;
         cell = cy * gw + cx;
@@ -771,38 +775,49 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
 #pragma unroll
         for (int k = 0; k < 9; k++) {
           const int c2 = cell + (k / 3 - 1) * gw + (k % 3 - 1);
-          a18[2 * k] = acc[2 * c2];
-          a18[2 * k + 1] = acc[2 * c2 + 1];
+          // both slots of a cell in one 8-byte read (the LDS pipe, not the instruction count, is what this phase waits for)
+          const unsigned long long two = *(volatile const unsigned long long*)&acc[2 * c2];
+          a18[2 * k] = (uint32_t)two;
+          a18[2 * k + 1] = (uint32_t)(two >> 32);
         }
+        int near = 0;  // branch-free: eighteen short-circuit tests compile to eighteen exec-mask branches
 #pragma unroll
         for (int k = 0; k < 18; k++) {
           const uint32_t a = a18[k];
-          const int dx = px - (int)(a & 0xFFFF), dy = py - (int)(a >> 16);  // (an empty slot is 0xFFFF, 0xFFFF: far away)
-          if (a != SEL_EMPTY && dx * dx + dy * dy < 64) alive = false;
+          const int dx = px - (int)(a & 0xFFFF), dy = py - (int)(a >> 16);
+          const unsigned d2 = (unsigned)(dx * dx) + (unsigned)(dy * dy);  // (an empty slot decodes to 65535, 65535: masked below)
+          near |= (int)(a != SEL_EMPTY) & (int)(d2 < 64u);
         }
+        alive = near == 0;
       }
-      cxy[tid] = (uint32_t)px | ((uint32_t)py << 16);
       state[tid] = alive ? 0 : 2;
-      if (alive) next[tid] = atomicExch((int*)&head[cell], tid);
+      {
+        const int nxt = alive ? atomicExch((int*)&head[cell], tid) : -1;
+        node[tid] = ((unsigned long long)(uint32_t)nxt << 32) | ((uint32_t)px | ((uint32_t)py << 16));
+      }
       __syncthreads();
       // Blockers = higher-ranked survivors of this batch within the minimum distance.  A candidate is
       // decided once all of them are: rejected if one was accepted, accepted otherwise.  The lowest
       // undecided rank never waits, so free-running polling of the LDS state words terminates; no
       // workgroup barrier per dependency level (all 16 waves are resident and keep being scheduled).
       int nb = 0;
-      int blk[SEL_MAX_BLOCKERS];
+      unsigned long long blk = 0ull;  // the last SEL_MAX_BLOCKERS blockers, 10 bits each (batch-local ranks): a register ARRAY
+                                      // indexed by nb costs six compare / select pairs per insertion
       if (alive) {
         int h9[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) h9[k] = head[cell + (k / 3 - 1) * gw + (k % 3 - 1)];
 #pragma unroll
         for (int k = 0; k < 9; k++)
-          for (int u = h9[k]; u >= 0; u = next[u]) {
-            if (u < tid) {
-              const uint32_t q = cxy[u];
+          for (int u = h9[k]; u >= 0;) {
+            const unsigned long long nd = node[u];
+            const int uu = u;
+            u = (int)(nd >> 32);
+            if (uu < tid) {
+              const uint32_t q = (uint32_t)nd;
               const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
               if (dx * dx + dy * dy < 64) {
-                if (nb < SEL_MAX_BLOCKERS) blk[nb] = u;
+                blk = (blk << 10) | (unsigned long long)(unsigned)uu;
                 nb++;
               }
             }
@@ -816,15 +831,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const uint64_t* __r
 #pragma unroll
             for (int k = 0; k < SEL_MAX_BLOCKERS; k++)
               if (k < nb) {
-                const int su = ((volatile int*)state)[blk[k]];
+                const int su = ((volatile int*)state)[(int)(blk >> (10 * k)) & 1023];
                 rej = rej || (su == 1);
                 blocked = blocked || (su == 0);
               }
           } else {  // crowded neighbourhood: walk the cell lists again
             for (int k = 0; k < 9; k++)
-                for (int u = head[cell + (k / 3 - 1) * gw + (k % 3 - 1)]; u >= 0; u = next[u]) {
+                for (int u = head[cell + (k / 3 - 1) * gw + (k % 3 - 1)], un = -1; u >= 0; u = un) {
+                  const unsigned long long nd = node[u];
+                  un = (int)(nd >> 32);
                   if (u < tid) {
-                    const uint32_t q = cxy[u];
+                    const uint32_t q = (uint32_t)nd;
                     const int dx = px - (int)(q & 0xFFFF), dy = py - (int)(q >> 16);
                     if (dx * dx + dy * dy < 64) {
                       const int su = ((volatile int*)state)[u];
