@@ -476,7 +476,7 @@ class Odometry {
     last_matches = (int)md.matches.size();
     if (std::getenv("VISNAV_AMD_TRACE_FRAMES")) {  // one line per frame: where two runs part ways
       const double* t = current_pose.data() + 4;
-      std::fprintf(stderr, "frame %d matches %d inliers %d landmarks %zu pose %.12f %.12f %.12f\n", (int)current_frame, last_matches,
+      std::fprintf(stderr, "frame %d matches %d inliers %d landmarks %zu pose %.17g %.17g %.17g\n", (int)current_frame, last_matches,
                    last_inliers, landmarks.size(), t[0], t[1], t[2]);
     }
     frame_poses.push_back(current_pose);
