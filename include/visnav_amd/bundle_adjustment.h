@@ -5,6 +5,8 @@
 // arrays of vsl_ba_problem, call the MI355X solver, and write poses / landmark positions back in
 // place -- the contract of the Ceres version (parameter blocks are the containers' own storage).
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -111,6 +113,22 @@ inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_
     check(vsl_bundle_adjust_intrinsics(ctx(), &prob, &opt, intr.data(), &sum), "bundle_adjustment (optimize_intrinsics)");
     for (int k = 0; k < 2; k++)
       for (int j = 0; j < 8; j++) calib_cam.intrinsics[k]->data()[j] = intr[8 * k + j];
+  } else if (std::getenv("VISNAV_AMD_BA_SELFCHECK")) {  // diagnostic: the same problem solved twice must give the same bits
+    const std::vector<double> poses0 = poses, points0 = points;
+    check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
+    const std::vector<double> poses1 = poses, points1 = points;
+    const int it1 = sum.iterations;
+    poses = poses0;
+    points = points0;
+    prob.poses = poses.data();
+    prob.points = points.data();
+    check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
+    double dmax = 0;
+    size_t nd = 0;
+    for (size_t i = 0; i < poses.size(); i++) if (poses[i] != poses1[i]) { nd++; dmax = std::max(dmax, std::fabs(poses[i] - poses1[i])); }
+    for (size_t i = 0; i < points.size(); i++) if (points[i] != points1[i]) { nd++; dmax = std::max(dmax, std::fabs(points[i] - points1[i])); }
+    std::fprintf(stderr, "  BA selfcheck: %d cameras %d landmarks %d observations, iterations %d / %d, %zu values differ (max %.3g)\n", prob.n_cams, prob.n_lms,
+                 prob.n_obs, it1, (int)sum.iterations, nd, dmax);
   } else
     check(vsl_bundle_adjust(ctx(), &prob, &opt, &sum), "bundle_adjustment");
   for (size_t c = 0; c < cam_ptr.size(); c++) {

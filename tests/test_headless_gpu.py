@@ -126,6 +126,12 @@ def test_loop_closing_stages_and_global_ba(loop_sequence):
     assert closed["ate_rmse_m"] < 0.85 * open_loop["ate_rmse_m"], (closed["ate_rmse_m"], open_loop["ate_rmse_m"])
     fused = _run(d, *common, "--force-loop", "170:0", "--fused")
     assert fused["ate_rmse_m"] == closed["ate_rmse_m"] and fused["keyframes"] == closed["keyframes"]
+    # the whole pipeline -- loop closing, pose graph, global BA and the local BAs after them included -- gives the same BYTES
+    # run after run (the pose graph's normal equations used to be summed with fp64 atomics: trajectories agreed to ~1e-9)
+    t1, t2 = d / "closed_a.csv", d / "closed_b.csv"
+    _run(d, *common, "--force-loop", "170:0", "--traj", str(t1))
+    _run(d, *common, "--force-loop", "170:0", "--traj", str(t2))
+    assert t1.read_bytes() == t2.read_bytes()
 
 
 def test_headless_pipeline_on_the_reference_s_real_frames(tmp_path, vsl):

@@ -6,8 +6,9 @@
 //
 // One thread per edge evaluates the residual and both 6x6 Jacobian blocks with forward-mode dual numbers
 // (12 partials: what ceres::AutoDiffCostFunction<., 6, 7, 7> followed by the SE3 plus-Jacobian computes), the
-// normal equations of the (at most a few thousand) keyframes are accumulated densely with fp64 atomics and
-// solved by the blocked Cholesky of chol.hip.  This runs once per loop closure: simplicity over throughput.
+// normal equations of the (at most a few thousand) keyframes are accumulated densely -- one thread owns one ROW of H and
+// walks the node's incident edges in edge order (lists built once per solve on the host): no atomics, results do not
+// depend on timing -- and solved by the blocked Cholesky of chol.hip.  This runs once per loop closure.
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -216,18 +217,25 @@ __global__ __launch_bounds__(64) void pgo_linearize_kernel(int n_edges, const do
 }
 
 // squared column norms of the (robustified) Jacobian, for the Jacobi scaling
-__global__ void pgo_colsq_kernel(int n_edges, const int* __restrict__ edge_a, const int* __restrict__ edge_b,
+// incidence lists: node i's entries inc[inc_off[i] .. inc_off[i + 1]) = 2 * edge + side (0: the node is edge_a, 1: edge_b),
+// ascending.  One thread per (free node, column): squared column norm of the Jacobian, summed in list order.
+__global__ void pgo_colsq_kernel(int n_nodes, const int* __restrict__ inc_off, const int* __restrict__ inc,
                                  const int* __restrict__ free_idx, const double* __restrict__ Ja, const double* __restrict__ Jb,
                                  double* __restrict__ colsq) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_edges * 12) return;
-  const int e = t / 12, rc = t - e * 12, x = rc / 6, c = rc - x * 6;
-  const int node = free_idx[x ? edge_b[e] : edge_a[e]];
-  if (node < 0) return;
-  const double* J = (x ? Jb : Ja) + 36 * (size_t)e;
+  if (t >= n_nodes * 6) return;
+  const int node = t / 6, c = t - node * 6;
+  const int nx = free_idx[node];
+  if (nx < 0) return;
   double s = 0;
-  for (int i = 0; i < 6; i++) s += J[6 * i + c] * J[6 * i + c];
-  unsafeAtomicAdd(&colsq[6 * node + c], s);
+  for (int k = inc_off[node]; k < inc_off[node + 1]; k++) {
+    const int e = inc[k] >> 1, x = inc[k] & 1;
+    const double* J = (x ? Jb : Ja) + 36 * (size_t)e;
+    double q = 0;
+    for (int i = 0; i < 6; i++) q += J[6 * i + c] * J[6 * i + c];
+    s += q;
+  }
+  colsq[6 * nx + c] = s;
 }
 
 __global__ void pgo_scale_kernel(int n, const double* __restrict__ colsq, double* __restrict__ scale) {
@@ -236,34 +244,44 @@ __global__ void pgo_scale_kernel(int n, const double* __restrict__ colsq, double
 }
 
 // H (n x n, scaled) += J^T J, g += J^T r: one thread per (edge, block x, column c)
-__global__ void pgo_build_kernel(int n_edges, int n, const int* __restrict__ edge_a, const int* __restrict__ edge_b,
+// One thread per (free node, row c of its 6 x 6 block row): row 6 nx + c of the scaled normal equations and entry
+// 6 nx + c of the gradient, accumulated over the node's incident edges in list order.  The thread is the only writer
+// of its row (H and g are zeroed before the launch).
+__global__ void pgo_build_kernel(int n_nodes, int n, const int* __restrict__ inc_off, const int* __restrict__ inc,
+                                 const int* __restrict__ edge_a, const int* __restrict__ edge_b,
                                  const int* __restrict__ free_idx, const double* __restrict__ r, const double* __restrict__ Ja,
                                  const double* __restrict__ Jb, const double* __restrict__ scale, double* __restrict__ H,
                                  double* __restrict__ g) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_edges * 12) return;
-  const int e = t / 12, rc = t - e * 12, x = rc / 6, c = rc - x * 6;
-  const int nx = free_idx[x ? edge_b[e] : edge_a[e]];
+  if (t >= n_nodes * 6) return;
+  const int node = t / 6, c = t - node * 6;
+  const int nx = free_idx[node];
   if (nx < 0) return;
-  const double* Jx = (x ? Jb : Ja) + 36 * (size_t)e;
-  const double* re = r + 6 * (size_t)e;
   const double sx = scale[6 * nx + c];
-  double col[6], gv = 0;
-  for (int i = 0; i < 6; i++) {
-    col[i] = Jx[6 * i + c];
-    gv += col[i] * re[i];
-  }
-  unsafeAtomicAdd(&g[6 * nx + c], sx * gv);
-  for (int y = 0; y < 2; y++) {
-    const int ny = free_idx[y ? edge_b[e] : edge_a[e]];
-    if (ny < 0) continue;
-    const double* Jy = (y ? Jb : Ja) + 36 * (size_t)e;
-    for (int c2 = 0; c2 < 6; c2++) {
-      double hv = 0;
-      for (int i = 0; i < 6; i++) hv += col[i] * Jy[6 * i + c2];
-      unsafeAtomicAdd(&H[(size_t)(6 * nx + c) * n + 6 * ny + c2], sx * scale[6 * ny + c2] * hv);
+  double* __restrict__ Hrow = H + (size_t)(6 * nx + c) * n;
+  double gacc = 0;
+  for (int k = inc_off[node]; k < inc_off[node + 1]; k++) {
+    const int e = inc[k] >> 1, x = inc[k] & 1;
+    const double* Jx = (x ? Jb : Ja) + 36 * (size_t)e;
+    const double* re = r + 6 * (size_t)e;
+    double col[6], gv = 0;
+    for (int i = 0; i < 6; i++) {
+      col[i] = Jx[6 * i + c];
+      gv += col[i] * re[i];
+    }
+    gacc += sx * gv;
+    for (int y = 0; y < 2; y++) {
+      const int ny = free_idx[y ? edge_b[e] : edge_a[e]];
+      if (ny < 0) continue;
+      const double* Jy = (y ? Jb : Ja) + 36 * (size_t)e;
+      for (int c2 = 0; c2 < 6; c2++) {
+        double hv = 0;
+        for (int i = 0; i < 6; i++) hv += col[i] * Jy[6 * i + c2];
+        Hrow[6 * ny + c2] += sx * scale[6 * ny + c2] * hv;
+      }
     }
   }
+  g[6 * nx + c] = gacc;
 }
 
 // A = H + diag(clamp(H_ii)) / radius, b = -g; gabs[i] = |g_i / scale_i|
@@ -389,7 +407,7 @@ static int pgo_validate(vsl_ctx* ctx, const vsl_pgo_problem* p) {
 namespace {
 struct PgoState {
   int N = 0, E = 0, n = 0;
-  Buf poses, cand, free_idx, edge_a, edge_b, meas, r, Ja, Jb, cost, colsq, scale, H, g, A, b, gabs, part, part2, scalars, flag;
+  Buf poses, cand, free_idx, edge_a, edge_b, inc_off, inc, meas, r, Ja, Jb, cost, colsq, scale, H, g, A, b, gabs, part, part2, scalars, flag;
 };
 
 int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
@@ -406,6 +424,8 @@ int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
   PGO_ALLOC(st.free_idx, 4 * N);
   PGO_ALLOC(st.edge_a, 4 * E);
   PGO_ALLOC(st.edge_b, 4 * E);
+  PGO_ALLOC(st.inc_off, 4 * (N + 1));
+  PGO_ALLOC(st.inc, 8 * E);
   PGO_ALLOC(st.meas, 48 * E);
   PGO_ALLOC(st.r, 48 * E);
   PGO_ALLOC(st.Ja, 288 * E);
@@ -425,12 +445,28 @@ int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
   hipStream_t s = ctx->stream;
   if (N) VSL_HIP(ctx, hipMemcpyAsync(st.poses.p, p->poses, 56 * N, hipMemcpyHostToDevice, s));
   if (N) VSL_HIP(ctx, hipMemcpyAsync(st.free_idx.p, free_idx.data(), 4 * N, hipMemcpyHostToDevice, s));
+  // incidence lists in edge order (a counting sort over the nodes keeps the edge indices ascending inside a list)
+  std::vector<int> inc_off(N + 1, 0), inc(2 * E);
+  for (size_t e = 0; e < E; e++) {
+    inc_off[p->edge_a[e] + 1]++;
+    inc_off[p->edge_b[e] + 1]++;
+  }
+  for (size_t i = 0; i < N; i++) inc_off[i + 1] += inc_off[i];
+  {
+    std::vector<int> cur(inc_off.begin(), inc_off.end() - 1);
+    for (size_t e = 0; e < E; e++) {
+      inc[cur[p->edge_a[e]]++] = 2 * (int)e;
+      inc[cur[p->edge_b[e]]++] = 2 * (int)e + 1;
+    }
+  }
+  VSL_HIP(ctx, hipMemcpyAsync(st.inc_off.p, inc_off.data(), 4 * (N + 1), hipMemcpyHostToDevice, s));
+  if (E) VSL_HIP(ctx, hipMemcpyAsync(st.inc.p, inc.data(), 8 * E, hipMemcpyHostToDevice, s));
   if (E) {
     VSL_HIP(ctx, hipMemcpyAsync(st.edge_a.p, p->edge_a, 4 * E, hipMemcpyHostToDevice, s));
     VSL_HIP(ctx, hipMemcpyAsync(st.edge_b.p, p->edge_b, 4 * E, hipMemcpyHostToDevice, s));
     VSL_HIP(ctx, hipMemcpyAsync(st.meas.p, p->edge_meas, 48 * E, hipMemcpyHostToDevice, s));
   }
-  VSL_HIP(ctx, hipStreamSynchronize(s));  // free_idx is a local
+  VSL_HIP(ctx, hipStreamSynchronize(s));  // free_idx and the incidence lists are locals
   return VSL_OK;
 }
 
@@ -444,18 +480,18 @@ int pgo_linearize(vsl_ctx* ctx, PgoState& st, const vsl_ba_options* opt, bool fi
                        st.Ja.as<double>(), st.Jb.as<double>(), st.cost.as<double>());
   if (first && n > 0) {
     VSL_HIP(ctx, hipMemsetAsync(st.colsq.p, 0, 8 * (size_t)n, s));
-    if (E > 0)
-      hipLaunchKernelGGL(pgo_colsq_kernel, dim3((E * 12 + 255) / 256), dim3(256), 0, s, E, st.edge_a.as<int>(), st.edge_b.as<int>(),
+    if (st.N > 0)
+      hipLaunchKernelGGL(pgo_colsq_kernel, dim3((st.N * 6 + 255) / 256), dim3(256), 0, s, st.N, st.inc_off.as<int>(), st.inc.as<int>(),
                          st.free_idx.as<int>(), st.Ja.as<double>(), st.Jb.as<double>(), st.colsq.as<double>());
     hipLaunchKernelGGL(pgo_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, st.colsq.as<double>(), st.scale.as<double>());
   }
   if (n > 0) {
     VSL_HIP(ctx, hipMemsetAsync(st.H.p, 0, 8 * (size_t)n * n, s));
     VSL_HIP(ctx, hipMemsetAsync(st.g.p, 0, 8 * (size_t)n, s));
-    if (E > 0)
-      hipLaunchKernelGGL(pgo_build_kernel, dim3((E * 12 + 255) / 256), dim3(256), 0, s, E, n, st.edge_a.as<int>(), st.edge_b.as<int>(),
-                         st.free_idx.as<int>(), st.r.as<double>(), st.Ja.as<double>(), st.Jb.as<double>(), st.scale.as<double>(),
-                         st.H.as<double>(), st.g.as<double>());
+    if (st.N > 0)
+      hipLaunchKernelGGL(pgo_build_kernel, dim3((st.N * 6 + 255) / 256), dim3(256), 0, s, st.N, n, st.inc_off.as<int>(), st.inc.as<int>(),
+                         st.edge_a.as<int>(), st.edge_b.as<int>(), st.free_idx.as<int>(), st.r.as<double>(), st.Ja.as<double>(),
+                         st.Jb.as<double>(), st.scale.as<double>(), st.H.as<double>(), st.g.as<double>());
   }
   hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.cost.as<double>(), E, st.scalars.as<double>(), 0);
   VSL_CHECK_LAUNCH(ctx);
