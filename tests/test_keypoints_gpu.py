@@ -46,10 +46,10 @@ def test_fast_sqrt_is_correctly_rounded_everywhere(ctx):
 
 @pytest.mark.parametrize("seed,side", [(29, 0), (29, 1), (40, 1), (43, 0), (0, 1)])
 def test_single_image_calls_do_not_depend_on_timing(ctx, orc, synth, seed, side):
-    """Regression.  The response kernel forms its horizontal 3-maxima with DPP sources, and a DPP source lane that an
-    exec-mask restore re-enabled a few instructions earlier reads as 0: the row above a strip (where the strip-maximum
-    update is masked off for every lane) lost its neighbours' responses and the strip's first row (rows 60, 120, ...)
-    emitted false local maxima, some of which displaced real corners.  Only ONE-image launches showed it (a lone wave
+    """Regression.  The response kernel forms its horizontal 3-maxima with DPP sources written in inline assembly; a VGPR
+    written by a VALU instruction must be two wait states old before a DPP operation reads it, and the compiler does not
+    see DPP reads inside inline assembly.  Without the explicit wait states the kernel read stale neighbours at some lanes
+    and emitted false local maxima, some of which displaced real corners.  Only ONE-image launches showed it (a lone wave
     per SIMD issues back to back; in a batch the other waves' instructions space the two out), which is how it passed
     the batch tests and surfaced as a 1-in-4 flake of the headless pipeline.  These frames failed 5-6 times of 6."""
     img = synth.stereo_pair(seed)[side]

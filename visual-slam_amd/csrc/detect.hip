@@ -319,13 +319,14 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
       const float v_dn = __builtin_fmaf(0.5f, xpy, -sqrt_rn(t));
       float h_tmp;
       // horizontal 3-maximum of the new response row: two v_max_f32 with a DPP source (bound_ctrl:0 feeds 0.0 into
-      // lanes 0 / 63, halo lanes whose H is never used by an owned column).  ONE volatile block placed BEFORE the
-      // exec-masked maximum update below, with its own wait states: a DPP source lane that was disabled a few
-      // instructions earlier reads as 0 -- with the update in front, the row above a strip (where that update is masked
-      // off for every lane) intermittently lost its neighbours' responses and the strip's first row emitted false local
-      // maxima (found on a rendered frame where one of them displaced a real corner: 184 of 200 runs).
-      asm volatile("s_nop 4\n\tv_max_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                   "v_max_f32_dpp %1, %2, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1"
+      // lanes 0 / 63, halo lanes whose H is never used by an owned column).  The two wait states in front are NOT optional:
+      // v_dn comes straight out of a v_fma, a VALU write of a VGPR must be two wait states old before a DPP operation
+      // reads it (the ISA's list of manually inserted wait states), and the compiler's hazard recogniser does not see a
+      // DPP read inside inline assembly.  Without them one-image launches (a lone wave per SIMD issues back to back; in a
+      // batch the other waves' instructions space the two out) read stale neighbours at some lanes, emitted false local
+      // maxima, and some of those displaced real corners: wrong on 5 of 120 synthetic frames, 5-6 runs of 6.
+      asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                   "v_max_f32_dpp %1, %2, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
                    : "=&v"(h_tmp), "=&v"(h_dn)
                    : "v"(v_dn));
       if (own_col && y >= y0 && y < y_end) {
