@@ -915,7 +915,7 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
   if (num_features < 1 || num_features > f->F)
     return vsl_fail(ctx, VSL_ERR_INVALID, "num_features %d not in [1, %d]", num_features, f->F);
   static_assert(sizeof(SelShared) <= 2048, "SelShared fits its LDS slot");
-  const int cells = ((f->w + 7) / 8 + 2) * ((f->h + 7) / 8 + 2);  // with the ring of empty cells (select_kernel)
+  const int cells = (((f->w + 7) / 8 + 2) * ((f->h + 7) / 8 + 2) + 1) & ~1;  // with the ring of empty cells, even (as select_kernel counts them)
   const bool grid_global = cells > SEL_MAX_CELLS;
   if (grid_global && !f->sel_grid) {
     VSL_HIP(ctx, hipMalloc((void**)&f->sel_grid, sizeof(uint32_t) * 3 * (size_t)cells * f->max_images));
