@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--gen-workers", type=int, default=8, help="processes generating the synthetic frames (before GPU init)")
     ap.add_argument("--cpu-frames", type=int, default=600, help="stereo frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--diag", action="append", default=[], help="name=value knob for vsl_ctx_set_diagnostic (repeatable; tuning experiments)")
     ap.add_argument("--clock-ramp-ms", type=float, default=80.0,
                     help="set-up: run passes for this long before the warm-up steps (the chip's clock ramps up from idle)")
     ap.add_argument("--stream-seconds", type=float, default=1.5,
@@ -251,6 +252,8 @@ def main():
     for u in range(S):
         stream = torch.cuda.Stream()
         ctx = vsl.Context(local_rank, stream=stream.cuda_stream)
+        for kv in args.diag:  # tuning / diagnostic knobs of the library (vsl_ctx_set_diagnostic), e.g. --diag k1_extra_lds=8192
+            ctx.set_diagnostic(kv.split("=")[0], int(kv.split("=")[1]))
         frames = vsl.Frames(ctx, n_img, W, H, NUM_FEATURES, max_pairs=Bu)
         frames.upload(0, ring[u * Bu:(u + 1) * Bu].reshape(n_img, H, W))
         units.append((stream, ctx, frames))
