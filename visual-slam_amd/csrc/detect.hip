@@ -26,6 +26,7 @@
 #ifndef K1_ROWS
 #define K1_ROWS 60
 #endif
+#define K1_ROWS_SMALL 29  // strips of launches of fewer than 8 images (17 strips of a 480-row image instead of 8)
 // goodFeaturesToTrack's qualityLevel as the reference passes it (keypoints.h:138): threshold = max response * 0.01
 #define VSL_QUALITY_LEVEL 0.01
 #define K1_WLIST 384  // LDS candidate slots per wave strip (60 x 60 pixels); overflow goes straight to global memory
@@ -178,7 +179,7 @@ __global__ void detect_init_kernel(int32_t* meta, int first, int n) {
 // Key = (order-preserving fp32 bits << 32) | y << 16 | x (ordered like the pixel index y * w + x, and the selection
 // kernel gets the position back without a division): a descending sort on the key is the
 // reference's order (value descending, equal values by address descending).
-template <bool STORE_RESPONSE>
+template <bool STORE_RESPONSE, int ROWS>
 __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __restrict__ images,
                                                                float* __restrict__ response, int32_t* __restrict__ meta,
                                                                uint64_t* __restrict__ cand, size_t cand_cap, int w, int h,
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row bookkeeping below stays scalar
   const int xs = bx * K1_COLS;
-  const int y0 = (by * 4 + wave) * K1_ROWS;
+  const int y0 = (by * 4 + wave) * ROWS;
   int n_wave = 0;  // wave-uniform
   int own_max = INT32_MIN;  // ordered bits of the largest response of this wave's strip
   if (y0 < h) {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
     int prev_ye = -100, pre_row = -100;
     RowRaw pre = {0u, 0u, 0u};
     float vmax = -3.0e38f;
-    const int y_end = min(h, y0 + K1_ROWS);
+    const int y_end = min(h, y0 + ROWS);
     // one step: q = row whose row sums are produced (into the slot of row q-2, dead by then).  Afterwards v_dn is the
     // response of row q-1 and h_dn its horizontal 3-maximum; the candidate row is q-2 (v_mid; H rows q-3, q-2, q-1).
     // STEADY (compile-time): the caller guarantees rows q-1 .. q+1 are inside the image and that the previous
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void min_eig_response_kernel(const uint8_t* __
 #define K1_STEP_E4(T, q) step(T{}, Even{}, q, ra, rb, va, vb, hB, hC, hA, fB, fC, fA)
 #define K1_STEP_O5(T, q) step(T{}, Odd{}, q, rb, ra, vb, va, hC, hA, hB, fC, fA, fB)
     // K1_OPEN opening steps (the first one reloads everything), then the loop unrolled by six starting at role K1_OPEN
-    constexpr int K1_OPEN = (K1_ROWS + 4) % 6;
+    constexpr int K1_OPEN = (ROWS + 4) % 6;
     static_assert(K1_OPEN == 3 || K1_OPEN == 4, "opening sequence written for 3 or 4 steps");
 #define K1_STRIP(T)                                \
   K1_STEP_E0(Generic, q_first);                    \
@@ -926,15 +927,22 @@ int vsl_launch_detect(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_fea
     if (f->detect_meta_dirty)
       hipLaunchKernelGGL(detect_init_kernel, dim3((f->max_images + 255) / 256), dim3(256), 0, ctx->stream, f->meta, 0, f->max_images);
     f->detect_meta_dirty = true;  // until the selection kernel (which resets the counters) is in the queue
-    const int tiles_y = (h + 4 * K1_ROWS - 1) / (4 * K1_ROWS);
+    // strips of K1_ROWS rows for batches; short strips for launches of a few images (the tracking loop's one-image calls):
+    // a lone wave per SIMD issues one instruction per ~7 cycles, so such a launch is as long as its longest wave
+    const bool small = n < 8 && !f->store_response;
+    const int rows = small ? K1_ROWS_SMALL : K1_ROWS;
+    const int tiles_y = (h + 4 * rows - 1) / (4 * rows);
     const int tiles_x = (w + K1_COLS - 1) / K1_COLS;
     const dim3 k1_grid((unsigned)(tiles_x * tiles_y) * (unsigned)(n >= 8 ? 8 * ((n + 7) / 8) : n));
     const int wcap = ctx->k1_list_cap < 0 ? K1_WLIST : min(ctx->k1_list_cap, K1_WLIST);
     if (f->store_response)
-      hipLaunchKernelGGL(min_eig_response_kernel<true>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+      hipLaunchKernelGGL((min_eig_response_kernel<true, K1_ROWS>), k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+                         f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
+    else if (small)
+      hipLaunchKernelGGL((min_eig_response_kernel<false, K1_ROWS_SMALL>), k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
                          f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
     else
-      hipLaunchKernelGGL(min_eig_response_kernel<false>, k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
+      hipLaunchKernelGGL((min_eig_response_kernel<false, K1_ROWS>), k1_grid, dim3(256), 0, ctx->stream, f->images, f->response, f->meta,
                          f->cand, f->cand_cap, w, h, first, wcap, n, tiles_x, tiles_y);
     VSL_CHECK_LAUNCH(ctx);
   }
