@@ -222,6 +222,13 @@ int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_
   ok = ok && dalloc(&f->matches, P * F * 2) == hipSuccess;
   ok = ok && dalloc(&f->match_count, P) == hipSuccess;
   ok = ok && dalloc(&f->exact_list, M * VSL_EXACT_CAP) == hipSuccess;
+  // keypoint lists by 64 x 64 tile for the batched describe kernel (16-byte image segments, <= 1024 tiles in LDS counters)
+  if (w % 16 == 0 && F < (1 << 20) && ((w + 63) / 64) * ((h + 63) / 64) <= 1024) {
+    f->tiles_x = (w + 63) / 64;
+    f->tiles = f->tiles_x * ((h + 63) / 64);
+    ok = ok && dalloc(&f->tile_off, M * (size_t)(f->tiles + 1)) == hipSuccess;
+    ok = ok && dalloc(&f->tile_ent, M * F) == hipSuccess;
+  }
   ok = ok && dalloc(&f->tie_count, 1) == hipSuccess;
   ok = ok && dalloc(&f->tie_rec, (size_t)f->tie_cap * 4) == hipSuccess;
   if (!ok) {
@@ -248,7 +255,7 @@ extern "C" int vsl_frames_destroy(vsl_frames* f) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {f->images, f->response, f->meta, f->cand, f->kp_xy, f->kp_count,
                   f->kp_moments, f->kp_angle, f->kp_desc, f->pair_slots, f->best_key, f->second_key,
-                  f->matches, f->match_count, f->tie_count, f->tie_rec, f->sel_grid, f->exact_list};
+                  f->matches, f->match_count, f->tie_count, f->tie_rec, f->sel_grid, f->exact_list, f->tile_off, f->tile_ent};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;

@@ -68,6 +68,7 @@ struct vsl_ctx {
   bool ba_force_dense = false;          // diagnostic: dense reduced camera system even where the band form applies
   bool ba_schur_atomics = false;        // diagnostic: large-system Schur complement by fp64 atomics (one wavefront per landmark) instead of the per-block gather
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
+  bool describe_no_tiles = false;      // diagnostic: batched describe launches by the per-keypoint-window kernel instead of the shared-tile one
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = -1;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
@@ -125,6 +126,9 @@ struct vsl_frames {
   int32_t* matches = nullptr;      // [max_pairs][F][2]
   int32_t* match_count = nullptr;  // [max_pairs]
   uint32_t* exact_list = nullptr;  // [max_images][VSL_EXACT_CAP]: (keypoint << 8) | bit, see describe.hip
+  int32_t* tile_off = nullptr;     // [max_images][tiles + 1]: keypoints of an image by 64 x 64 tile (describe.hip), null when the tile kernel does not apply
+  uint32_t* tile_ent = nullptr;    // [max_images][F]: (keypoint << 12) | (y in tile << 6) | x in tile, tile-major
+  int tiles_x = 0, tiles = 0;
   uint32_t* sel_grid = nullptr;    // [max_images][cells][3]: selection grid of images too large for LDS (lazy)
   // rBRIEF near-tie records (see describe.hip)
   int32_t* tie_count = nullptr;    // [1]
