@@ -269,6 +269,66 @@ def test_generic_describe_kernel_matches_fast_one(ctx, orc, images):
         ctx.set_diagnostic("no_such_knob", 1)
 
 
+# The shared-tile describe kernel serves launches of >= 96 images; the knob sends every launch through it, so the
+# single-image oracle comparisons cover it (widths that are multiples of 16 -- other widths keep the window kernel).
+@pytest.fixture()
+def tile_ctx(ctx):
+    ctx.set_diagnostic("describe_tile_min_images", 1)
+    try:
+        yield ctx
+    finally:
+        ctx.set_diagnostic("describe_tile_min_images", 96)
+
+
+@pytest.mark.parametrize("name", ["left", "right", "noise", "flat", "grad", "checker"])
+@pytest.mark.parametrize("nf", [1500, 100])
+def test_tile_describe_kernel_bit_exact(tile_ctx, orc, images, name, nf):
+    img = images[name]
+    xy, ang, desc = tile_ctx.detect_describe(img, nf, True)
+    oxy, oang, odesc = orc.detect_describe(img, nf, True)
+    assert np.array_equal(xy, oxy)
+    assert np.array_equal(ang.view(np.uint64), oang.view(np.uint64))
+    assert np.array_equal(desc, odesc)
+    xy, ang, desc = tile_ctx.detect_describe(img, nf, False)
+    oxy, oang, odesc = orc.detect_describe(img, nf, False)
+    assert np.array_equal(xy, oxy) and not ang.any() and np.array_equal(desc, odesc)
+
+
+@pytest.mark.parametrize("w,h", [(48, 48), (64, 64), (128, 128), (144, 129), (256, 127), (400, 257), (1024, 70), (80, 700)])
+def test_tile_describe_kernel_image_sizes(tile_ctx, orc, w, h):
+    # one tile, exactly one tile, tile edges at the image edge, a partial last tile in either direction, strips
+    rng = np.random.default_rng(w * 1000 + h)
+    base = rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8)).astype(np.float32)
+    img = np.kron(base, np.ones((8, 8), np.float32))[:h, :w]
+    img = np.clip(img + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+    xy, ang, desc = tile_ctx.detect_describe(img, 1500, True)
+    oxy, oang, odesc = orc.detect_describe(img, 1500, True)
+    assert len(xy) > 0 or min(w, h) < 64  # (the detector keeps clear of the border: nothing on the smallest ones)
+    assert np.array_equal(xy, oxy) and np.array_equal(ang, oang) and np.array_equal(desc, odesc)
+
+
+def test_tile_describe_kernel_corners_at_the_border(ctx, orc, images):
+    # corners whose window leaves the image (the staged tile carries the clamped pixels), every tile corner and
+    # every image corner, many corners on one tile (more than one batch of 64 per wave), duplicates
+    img = images["left"]
+    h, w = img.shape
+    rng = np.random.default_rng(5)
+    pts = [(0, 0), (w - 1, 0), (0, h - 1), (w - 1, h - 1), (127, 127), (128, 128), (127, 128), (128, 127), (w - 1, 255), (640, h - 1)]
+    pts += [(int(x), int(y)) for x, y in zip(rng.integers(0, w, 300), rng.integers(0, h, 300))]
+    pts += [(int(x), int(y)) for x, y in zip(rng.integers(256, 384, 700), rng.integers(128, 256, 700))]
+    pts += [(300, 200)] * 5
+    kp = np.array(pts, np.float64)
+    want = ctx.compute_angles(img, kp, True)
+    ctx.set_diagnostic("describe_tile_min_images", 1)
+    try:
+        got = ctx.compute_angles(img, kp, True)
+    finally:
+        ctx.set_diagnostic("describe_tile_min_images", 96)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    inner = np.array([p for p in pts if 19 <= p[0] < w - 20 and 19 <= p[1] < h - 19], np.float64)
+    assert np.array_equal(ctx.compute_angles(img, inner, True).view(np.uint64), orc.compute_angles(img, inner, True).view(np.uint64))
+
+
 @pytest.mark.parametrize("k", range(16))  # 16 real EuRoC pairs of the reference's data/euroc_V1 (tools/make_golden.py)
 def test_golden_euroc(ctx, k):
     g = np.load(GOLDEN / ("euroc_pair%d.npz" % k))

@@ -17,9 +17,9 @@ import os  # noqa: E402
 if os.environ.get("VSL_SO"):  # a second build of the library (old / experimental kernel) for same-box comparisons
     vsl._SO = Path(os.environ["VSL_SO"]).resolve()
 synth = importlib.import_module("visual_slam_amd.synth")
-Bu = 512
+Bu = int(os.environ.get("BU", "512"))  # stereo frames per launch
 base = np.concatenate([synth.stereo_pair_variants(10 + s, 4, margin=24) for s in range(16)])  # 64 distinct pairs
-imgs = np.concatenate([base] * (Bu // len(base))).reshape(2 * Bu, 480, 752)
+imgs = np.concatenate([base] * max(1, Bu // len(base)))[:Bu].reshape(2 * Bu, 480, 752)
 ctx = vsl.Context(0)
 for a in sys.argv[1:]:
     if "=" in a:
@@ -47,9 +47,9 @@ ctx.synchronize()
 st = {k: ms / n for k, (ms, n) in ctx.stage_ms().items() if n}
 nk, nm = fr.counts(2 * Bu, Bu)
 chk = 0
-for s in (0, 1, 77, 500):
+for s in (0, 1, 77 % (2 * Bu), 500 % (2 * Bu)):
     xy, ang, d = fr.keypoints(s)
     chk = zlib.crc32(xy.tobytes() + d.tobytes(), chk)
-chk = zlib.crc32(fr.matches(5).tobytes() + nm.tobytes(), chk)
+chk = zlib.crc32(fr.matches(min(5, Bu - 1)).tobytes() + nm.tobytes(), chk)
 print("stages ms/launch:", {k: round(v, 4) for k, v in st.items()}, "sum %.4f" % sum(st.values()),
       "| candidates/img %.0f kp %.1f matches %.1f crc %08x" % (fr.candidate_counts(2 * Bu).mean(), nk.mean(), nm.mean(), chk), flush=True)

@@ -223,9 +223,10 @@ int vsl_frames_alloc(vsl_ctx* ctx, int max_images, int w, int h, int F, int max_
   ok = ok && dalloc(&f->match_count, P) == hipSuccess;
   ok = ok && dalloc(&f->exact_list, M * VSL_EXACT_CAP) == hipSuccess;
   // keypoint lists by 64 x 64 tile for the batched describe kernel (16-byte image segments, <= 1024 tiles in LDS counters)
-  if (w % 16 == 0 && F < (1 << 20) && ((w + 63) / 64) * ((h + 63) / 64) <= 1024) {
-    f->tiles_x = (w + 63) / 64;
-    f->tiles = f->tiles_x * ((h + 63) / 64);
+  const int tiles_x = (w + (1 << VSL_TILE_LX) - 1) >> VSL_TILE_LX, tiles_y = (h + (1 << VSL_TILE_LY) - 1) >> VSL_TILE_LY;
+  if (w % 16 == 0 && F < (1 << (32 - VSL_TILE_LX - VSL_TILE_LY)) && tiles_x * tiles_y <= 1024) {
+    f->tiles_x = tiles_x;
+    f->tiles = tiles_x * tiles_y;
     ok = ok && dalloc(&f->tile_off, M * (size_t)(f->tiles + 1)) == hipSuccess;
     ok = ok && dalloc(&f->tile_ent, M * F) == hipSuccess;
   }

@@ -22,6 +22,12 @@
 #define VSL_META_NCAND_LAST 4
 #define VSL_META_NEXACT_LAST 5
 #define VSL_EXACT_CAP 16384 // capacity of that per-image list
+#ifndef VSL_TILE_LX
+#define VSL_TILE_LX 7  // log2 width / height of the keypoint tiles of the batched describe kernel (describe.hip)
+#endif
+#ifndef VSL_TILE_LY
+#define VSL_TILE_LY 7
+#endif
 #define VSL_TIE_OVERFLOW_FLAG 0x40000000u  // set in tie_count by exact_bits_kernel when an image's list overflowed
 
 struct vsl_ctx {
@@ -68,7 +74,7 @@ struct vsl_ctx {
   bool ba_force_dense = false;          // diagnostic: dense reduced camera system even where the band form applies
   bool ba_schur_atomics = false;        // diagnostic: large-system Schur complement by fp64 atomics (one wavefront per landmark) instead of the per-block gather
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
-  bool describe_no_tiles = false;      // diagnostic: batched describe launches by the per-keypoint-window kernel instead of the shared-tile one
+  int describe_tile_min_images = 96;   // describe launches of at least this many images use the shared-tile kernel (measured break-even ~64 images; diagnostic: 1 forces it, 0 disables it)
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = -1;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
