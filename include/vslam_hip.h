@@ -202,6 +202,8 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "match_use_i8" (0/1)            int8 matrix-core matcher where the block-scaled FP4 one would run (<= 2048 features)
  *   "match_no_stagger" (0/1)        matrix-core matcher with every wave of a workgroup in the same phase order
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
+ *   "describe_tile_min_images" (default 96) describe launches of at least this many images use the shared-tile
+ *                                   kernel (image widths that are multiples of 16); 1 = always, 0 = never
  *   "k1_list_cap" (0..384, -1 = all)         per-wave LDS candidate slots of the response kernel (overflow path)
  *   "chol_no_fused" (0/1)           band Cholesky as one launch per panel step instead of the single-launch kernel
  *   "chol_no_bcr" (0/1)             long narrow bands by the band Cholesky instead of block cyclic reduction

@@ -14,7 +14,7 @@ import pathlib
 import sys
 from collections import defaultdict
 
-NAMES = {"min_eig_response_kernel": "response", "select_kernel": "select", "describe_fast_kernel": "describe",
+NAMES = {"min_eig_response_kernel": "response", "select_kernel": "select", "describe_tile_kernel": "describe",
          "hamming_mx_kernel": "match"}
 
 

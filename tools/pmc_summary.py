@@ -18,7 +18,8 @@ from collections import defaultdict
 STAGES = {  # stage -> (kernel, read width calibration, write width calibration)
     "response": ("min_eig_response_kernel", "calib_read_b8", "calib_write_b64"),
     "select": ("select_kernel", "calib_read_b32", "calib_write_b64"),
-    "describe": ("describe_fast_kernel", "calib_read_b32", "calib_write_b64"),
+    "describe": ("describe_tile_kernel", "calib_read_b32", "calib_write_b64"),  # launches of >= 96 images (describe_fast_kernel below that)
+    "describe_bin": ("describe_bin_kernel", "calib_read_b32", "calib_write_b64"),
     "describe_exact": ("exact_bits_kernel", "calib_read_b32", "calib_write_b64"),
     "match": ("hamming_mx_kernel", "calib_read_b32", "calib_write_b64"),
     "match_finalize": ("match_finalize_kernel", "calib_read_b32", "calib_write_b64"),
