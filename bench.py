@@ -166,6 +166,52 @@ def streaming_measurement(vsl, units, ring, Bu, slot_pairs, seconds, device, exp
                           "outputs_equal_resident_run": bool(ok)}}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) as a CHILD process -- this process has not touched the GPU -- and exit with its code.
+    The ranks' stdout (rank 0's JSON line) and stderr pass through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_plumbing(args, vdist, rank, world):
+    """--rehearse-plumbing: everything around the hot path (rank set-up, barriers, MAX-over-ranks timing, per-rank
+    list, rank 0's single JSON line) with a step that only sleeps.  Not a measurement: value is null."""
+    backend = os.environ.get("VSL_BENCH_BACKEND", "gloo")
+    if backend != "gloo":
+        raise SystemExit("--rehearse-plumbing runs without a GPU: set VSL_BENCH_BACKEND=gloo")
+    vdist.init(backend)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    vdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))   # rank r is the slower one: the straggler must show in the list
+    own = time.perf_counter() - t0
+    vdist.barrier()
+    elapsed = vdist.max_over_ranks(time.perf_counter() - t0)
+    per_rank = vdist.gather_over_ranks(own)
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the benchmark plumbing -- no GPU work, not a measurement", "value": None,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 4), "rehearsal": True,
+                          "per_rank_ms_per_step": [round(1e3 * t / max(args.steps, 1), 4) for t in per_rank]}), flush=True)
+    vdist.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,14 +239,28 @@ def main():
     ap.add_argument("--no-e2e", dest="e2e", action="store_false",
                     help="skip the single-stream end-to-end run of the headless next_step pipeline")
     ap.add_argument("--e2e-frames", type=int, default=90)
+    ap.add_argument("--rehearse-plumbing", action="store_true",
+                    help="NO GPU work: the launcher / rank / timing / JSON plumbing with a sleeping step (CPU tests of "
+                         "--gpus N; set VSL_BENCH_BACKEND=gloo).  The line says so and carries no value.")
     args = ap.parse_args()
 
+    # --gpus N means N ranks, one per GPU.  Under a launcher (WORLD_SIZE set) the two must agree; without one the
+    # script launches the ranks itself -- BEFORE anything in this process touches the GPU -- and relays rank 0's line.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     vsl = entry.load_package()
     synth = importlib.import_module("visual_slam_amd.synth")
     vdist = importlib.import_module("visual_slam_amd.dist")
     rank, world, local_rank = vdist.env_rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d; launch as: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port <port> bench.py --gpus %d ... "
+                         "(or plain `python bench.py --gpus %d`, which starts the ranks itself)"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    if args.rehearse_plumbing:
+        return rehearse_plumbing(args, vdist, rank, world)
     B, S, P = args.batch, args.streams, max(1, args.passes)
     if S < 1 or B % S:
         raise SystemExit("--batch must be a multiple of --streams")
@@ -214,7 +274,12 @@ def main():
     t_gen = time.perf_counter()
     # (cached under /tmp: profiler passes re-run this script many times, and a process that rocprofv3 has already
     # attached the GPU runtime to must not fork workers -- tools/refresh_profiles.sh passes --gen-workers 1)
-    cache = Path("/tmp") / ("vsl_bench_frames_r%d_s%d_b%d_m%d.npy" % (rank, n_scenes, B, SYNTH_MARGIN))
+    # The name carries a hash of the generator's source and of the seed list: a file written by an older synth.py or
+    # for other seeds is never reused.
+    import hashlib
+    seeds = vdist.stream_seeds(rank, n_scenes)
+    gen_id = hashlib.sha256((ROOT / "visual-slam_amd" / "synth.py").read_bytes() + repr((seeds, B // n_scenes, SYNTH_MARGIN, W, H)).encode()).hexdigest()[:16]
+    cache = Path("/tmp") / ("vsl_bench_frames_r%d_s%d_b%d_m%d_%s.npy" % (rank, n_scenes, B, SYNTH_MARGIN, gen_id))
     host_frames = None
     if cache.exists():
         try:
@@ -224,7 +289,7 @@ def main():
         except Exception:
             host_frames = None
     if host_frames is None:
-        host_frames = distinct_stereo_frames(vdist.stream_seeds(rank, n_scenes), B // n_scenes, args.gen_workers)
+        host_frames = distinct_stereo_frames(seeds, B // n_scenes, args.gen_workers)
         try:
             np.save(cache, host_frames)
         except Exception:
@@ -285,8 +350,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0     # this rank's own K steps (before waiting for the others)
     barrier()
-    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
+    ddev = "cuda" if backend == "nccl" else "cpu"
+    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, device=ddev)
+    per_rank_s = vdist.gather_over_ranks(own_elapsed, device=ddev)
 
     counts = [frames.counts(n_img, Bu) for _, _, frames in units]
     nk = np.concatenate([c[0] for c in counts])
@@ -304,6 +373,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
             "data": "synthetic",
+            # every rank's own rate over the same K steps (weak scaling: each rank runs the same work; a straggler shows here)
+            "per_rank": {"frames_per_s": [round(B * P * args.steps / t, 1) for t in per_rank_s],
+                         "min": round(B * P * args.steps / max(per_rank_s), 1), "max": round(B * P * args.steps / min(per_rank_s), 1)},
             "config": {"workload": "synthetic 752x480 stereo, 1500 feats/frame (BASELINE configs[1]); "
                                    "independent streams per GPU (configs[3])",
                        "value_is": "kernel pipeline: inputs resident in HBM when the timed region starts, outputs stay "

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../vslam_hip.h"
+#include "device_select.h"
 
 #if __has_include(<pangolin/image/managed_image.h>) && __has_include(<visnav/common_types.h>)
 #include <pangolin/image/managed_image.h>
@@ -33,8 +34,8 @@ inline vsl_ctx* ctx() {
   struct Holder {
     vsl_ctx* c = nullptr;
     Holder() {
-      const char* dev = std::getenv("VISNAV_AMD_DEVICE");
-      if (vsl_ctx_create(dev ? std::atoi(dev) : 0, &c) != VSL_OK) {
+      // the same device rule as the RCCL communicator (device_select.h): VISNAV_AMD_DEVICE, LOCAL_RANK, RANK
+      if (vsl_ctx_create(device_index_for(vsl_device_count()), &c) != VSL_OK) {
         std::fprintf(stderr, "visnav_amd: %s\n", vsl_last_error(nullptr));
         std::abort();
       }

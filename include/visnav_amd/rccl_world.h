@@ -7,22 +7,28 @@
 // observation count) and all-reduces the packed partial reduced camera system once per LM iteration
 // (vsl_global_bundle_adjust, include/vslam_hip.h).  Environment:
 //   VISNAV_AMD_WORLD / VISNAV_AMD_RANK   (default: WORLD_SIZE / RANK of a torchrun-style launcher, else 1 / 0)
-//   VISNAV_AMD_NCCL_ID_FILE              rendezvous: rank 0 writes its ncclUniqueId there (atomically), the others wait
-//                                        for it (default /tmp/visnav_amd_nccl_id.<MASTER_PORT or 0>)
-//   VISNAV_AMD_DEVICE                    GPU of this rank (default LOCAL_RANK, else the rank)
+//   VISNAV_AMD_NCCL_ID_FILE              rendezvous file (default <TMPDIR or /tmp>/visnav_amd.<uid>/nccl_id.<MASTER_PORT or 0>,
+//                                        directory mode 0700)
+//   VISNAV_AMD_DEVICE                    GPU of this rank -- the SAME rule as the solver context (device_select.h:
+//                                        VISNAV_AMD_DEVICE, else LOCAL_RANK, else the rank, modulo the device count), so the
+//                                        communicator and the solver's buffers / stream are on one device
+// Rendezvous protocol (stale-proof: a file left by a crashed or earlier run can never be taken for this run's):
+//   every rank r > 0 draws a random nonce and keeps <file>.hello.<r> in place until it has its id;
+//   rank 0 first removes any old <file> and <file>.hello.*, waits for the world-1 hellos, then publishes
+//   {magic, world, nonces[], ncclUniqueId} atomically (write + rename); rank r accepts the file only if it carries ITS
+//   nonce; rank 0 removes everything once the communicator exists (on every path, the forced one-rank case writes nothing).
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
-#include <unistd.h>
 
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 
 #include "../vslam_hip.h"
+#include "device_select.h"
+#include "file_rendezvous.h"
 
 #define VISNAV_AMD_HAVE_RCCL 1
 
@@ -37,11 +43,23 @@ class RcclWorld {
   }
   int rank() const { return rank_; }
   int world() const { return world_; }
+  int device() const { return device_; }
   bool enabled() const { return comm_ != nullptr; }
 
   // vsl_allreduce_fn: in-place all-reduce of `count` doubles on the solver's stream
   static int allreduce(void* user, double* buf, int64_t count, int op, void* hip_stream) {
     RcclWorld* w = static_cast<RcclWorld*>(user);
+    if (hip_stream != w->checked_stream_) {  // once per stream: the solver's stream must live on the communicator's GPU
+      hipDevice_t sdev = -1;
+      if (hipStreamGetDevice(static_cast<hipStream_t>(hip_stream), &sdev) != hipSuccess || (int)sdev != w->device_) {
+        std::fprintf(stderr,
+                     "visnav_amd: the solver's stream is on device %d but the RCCL communicator of rank %d is on device %d "
+                     "(both follow device_select.h: VISNAV_AMD_DEVICE, LOCAL_RANK, RANK -- was the context created with an explicit index?)\n",
+                     (int)sdev, w->rank_, w->device_);
+        return 2;
+      }
+      w->checked_stream_ = hip_stream;
+    }
     const ncclResult_t r = ncclAllReduce(buf, buf, (size_t)count, ncclDouble, op == 0 ? ncclSum : ncclMax, w->comm_,
                                          static_cast<hipStream_t>(hip_stream));
     if (r != ncclSuccess) {
@@ -62,42 +80,25 @@ class RcclWorld {
     rank_ = env_int("VISNAV_AMD_RANK", "RANK", 0);
     const bool force = std::getenv("VISNAV_AMD_FORCE_RCCL") != nullptr;  // a one-rank communicator (tests on a one-GPU box)
     if (world_ <= 1 && !force) return;
-    int dev = env_int("VISNAV_AMD_DEVICE", "LOCAL_RANK", rank_);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) die("no HIP device");
-    dev %= ndev;
-    if (hipSetDevice(dev) != hipSuccess) die("hipSetDevice failed");
-    std::string path;
-    if (const char* p = std::getenv("VISNAV_AMD_NCCL_ID_FILE")) {
-      path = p;
-    } else {
-      const char* port = std::getenv("MASTER_PORT");
-      path = std::string("/tmp/visnav_amd_nccl_id.") + (port ? port : "0");
-    }
+    device_ = device_index_for(ndev);
+    if (hipSetDevice(device_) != hipSuccess) die("hipSetDevice failed");
     ncclUniqueId id;
-    if (rank_ == 0) {
+    if (world_ <= 1) {
       if (ncclGetUniqueId(&id) != ncclSuccess) die("ncclGetUniqueId failed");
-      const std::string tmp = path + ".tmp";
-      FILE* f = std::fopen(tmp.c_str(), "wb");
-      if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) die("cannot write the rendezvous file");
-      std::fclose(f);
-      if (std::rename(tmp.c_str(), path.c_str()) != 0) die("cannot publish the rendezvous file");
     } else {
-      bool got = false;
-      for (int tries = 0; tries < 6000 && !got; tries++) {  // up to 60 s
-        FILE* f = std::fopen(path.c_str(), "rb");
-        if (f) {
-          got = std::fread(&id, sizeof(id), 1, f) == 1;
-          std::fclose(f);
-        }
-        if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
-      }
-      if (!got) die("timed out waiting for rank 0's ncclUniqueId");
+      const char* p = std::getenv("VISNAV_AMD_NCCL_ID_FILE");
+      const std::string path = p ? std::string(p) : rendezvous_default_path();
+      if (rank_ == 0 && ncclGetUniqueId(&id) != ncclSuccess) die("ncclGetUniqueId failed");
+      std::string err;
+      if (!file_rendezvous(path, rank_, world_, &id, sizeof(id), 120, &err)) die(err.c_str());
+      cleanup_path_ = rank_ == 0 ? path : std::string();
     }
-    if (ncclCommInitRank(&comm_, world_, id, rank_) != ncclSuccess) die("ncclCommInitRank failed");
-    if (rank_ == 0 && world_ > 1) {  // everybody has read the id once the communicator exists
-      std::remove(path.c_str());
-    }
+    const ncclResult_t r = ncclCommInitRank(&comm_, world_, id, rank_);
+    // everybody has read the id once the communicator exists -- removed on failure too
+    if (!cleanup_path_.empty()) file_rendezvous_cleanup(cleanup_path_, world_);
+    if (r != ncclSuccess) die("ncclCommInitRank failed");
   }
   ~RcclWorld() {
     if (comm_) ncclCommDestroy(comm_);
@@ -106,8 +107,10 @@ class RcclWorld {
     std::fprintf(stderr, "visnav_amd: RCCL set-up: %s\n", what);
     std::abort();
   }
-  int rank_ = 0, world_ = 1;
+  int rank_ = 0, world_ = 1, device_ = 0;
   ncclComm_t comm_ = nullptr;
+  void* checked_stream_ = reinterpret_cast<void*>(-1);
+  std::string cleanup_path_;
 };
 
 }  // namespace amd

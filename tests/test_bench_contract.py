@@ -59,3 +59,29 @@ def test_bench_command_line_accepts_the_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def _run_bench(args, env_extra, timeout=300):
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks():
+    # `python bench.py --gpus 2` (no torchrun around it) must produce 2 ranks -- it used to run one
+    # rank and print "n_gpus": 1.  Rehearsed on the CPU: gloo, a sleeping step (--rehearse-plumbing), the real launcher path.
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse-plumbing"], {"VSL_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE line, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["rehearsal"] is True and d["value"] is None
+    assert len(d["per_rank_ms_per_step"]) == 2
+    assert d["per_rank_ms_per_step"][1] > d["per_rank_ms_per_step"][0]          # the planted straggler shows
+    assert d["ms_per_step"] >= max(d["per_rank_ms_per_step"]) - 1e-3            # MAX over ranks
+
+
+def test_gpus_n_that_disagrees_with_the_launcher_fails():
+    r = _run_bench(["--gpus", "8", "--rehearse-plumbing"], {"WORLD_SIZE": "1", "RANK": "0", "VSL_BENCH_BACKEND": "gloo"}, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stdout + r.stderr)

@@ -91,3 +91,69 @@ def test_landmark_ranges_partition(vsl):
     # fewer landmarks than ranks: empty ranges allowed, still a partition
     rs = vdist.landmark_ranges([5, 5], 8)
     assert sum(c for _, c in rs) == 2 and all(c >= 0 for _, c in rs)
+
+
+# ---- host-side rules of the C++ multi-GPU path (include/visnav_amd/device_select.h, file_rendezvous.h) -------------
+
+def _build_rendezvous_test(tmp_path):
+    import subprocess
+    exe = tmp_path / "rendezvous_test"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-I", str(ROOT / "include"),
+                        str(ROOT / "tests/cpp/rendezvous_test.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_solver_context_and_communicator_pick_the_same_device(tmp_path):
+    # RcclWorld bound the communicator to LOCAL_RANK while amd::ctx() defaulted to device 0.  Both
+    # now call device_index_for(): VISNAV_AMD_DEVICE, else LOCAL_RANK, else VISNAV_AMD_RANK / RANK, modulo the count.
+    import subprocess
+    exe = _build_rendezvous_test(tmp_path)
+    base = {k: v for k, v in os.environ.items() if k not in ("VISNAV_AMD_DEVICE", "LOCAL_RANK", "RANK", "VISNAV_AMD_RANK")}
+
+    def pick(n, **env):
+        r = subprocess.run([str(exe), "device", str(n)], capture_output=True, text=True, env=dict(base, **env))
+        assert r.returncode == 0
+        return int(r.stdout)
+
+    assert pick(8) == 0
+    assert pick(8, LOCAL_RANK="1") == 1                       # the torchrun-style launch of the advisor's finding
+    assert pick(8, LOCAL_RANK="3", RANK="11") == 3
+    assert pick(8, RANK="5") == 5
+    assert pick(8, VISNAV_AMD_DEVICE="6", LOCAL_RANK="1") == 6
+    assert pick(1, LOCAL_RANK="3") == 0                       # ranks rehearsing on a one-GPU box
+    assert pick(4, VISNAV_AMD_RANK="6") == 2
+    # and both users of the rule are wired to it (no second copy of the rule in either header)
+    kp = (ROOT / "include/visnav_amd/keypoints.h").read_text()
+    rw = (ROOT / "include/visnav_amd/rccl_world.h").read_text()
+    assert "device_index_for(vsl_device_count())" in kp and 'getenv("VISNAV_AMD_DEVICE")' not in kp
+    assert "device_index_for(ndev)" in rw and "LOCAL_RANK\"" not in rw
+
+
+def test_file_rendezvous_ignores_stale_files(tmp_path):
+    # a rendezvous file of an earlier (crashed / one-rank) run must never be taken for this run's.
+    # Plant a well-formed stale id file and stale hello files, start ranks 1 and 2 BEFORE rank 0, and expect this
+    # run's payload everywhere and a clean directory afterwards.
+    import struct
+    import subprocess
+    import time
+    exe = _build_rendezvous_test(tmp_path)
+    path = tmp_path / "nccl_id"
+    world = 3
+    stale = struct.pack("<QQ", 0x76736c5f6e63636c, world) + struct.pack("<3Q", 0, 111, 222) + b"STALE".ljust(128, b"\0")
+    path.write_bytes(stale)
+    (tmp_path / "nccl_id.hello.1").write_bytes(struct.pack("<Q", 111))
+    (tmp_path / "nccl_id.hello.2").write_bytes(struct.pack("<Q", 222))
+    procs = {}
+    for r in (1, 2):
+        procs[r] = subprocess.Popen([str(exe), "meet", str(path), str(r), str(world), "x"], stdout=subprocess.PIPE,
+                                    stderr=subprocess.PIPE, text=True)
+    time.sleep(0.4)   # the late rank 0: ranks 1, 2 have been staring at the stale file for a while
+    assert all(p.poll() is None for p in procs.values()), "a rank accepted the stale file"
+    procs[0] = subprocess.Popen([str(exe), "meet", str(path), "0", str(world), "fresh-id"], stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+    for r, p in procs.items():
+        out, err = p.communicate(timeout=60)
+        assert p.returncode == 0, err
+        assert out.strip() == "rank %d got fresh-id" % r
+    assert sorted(f.name for f in tmp_path.iterdir() if f.name.startswith("nccl_id")) == []

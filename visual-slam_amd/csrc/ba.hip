@@ -2718,10 +2718,39 @@ extern "C" int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob
     cuts[r] = std::min(std::max(cuts[r], cuts[r - 1]), prob->n_lms);
   }
   cuts[world] = prob->n_lms;
+  // Every rank computes ALL ranges, so decisions about them are identical everywhere (a rank that returned alone
+  // would leave the others waiting in the first all-reduce).  A range emptied by the balancing rule (few, heavy
+  // landmarks) is widened to one landmark; fewer landmarks than ranks is an error on every rank alike.
+  if (prob->n_lms < world)
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_global_bundle_adjust: %d landmarks cannot be split over %d ranks (every rank fails alike)",
+                    prob->n_lms, world);
+  for (int r = 1; r < world; r++) cuts[r] = std::min(std::max(cuts[r], cuts[r - 1] + 1), prob->n_lms - (world - r));
   const int first = cuts[rank], count = cuts[rank + 1] - cuts[rank];
-  if (count < 1) return vsl_fail(ctx, VSL_ERR_INVALID, "rank %d owns no landmarks (%d landmarks over %d ranks)", rank, prob->n_lms, world);
   vsl_ba_session* s = nullptr;
-  if ((rc = vsl_ba_session_create(ctx, prob, opt, first, count, &s))) return rc;
+  rc = vsl_ba_session_create(ctx, prob, opt, first, count, &s);
+  if (world > 1 && allreduce) {
+    // rank-local failures (allocation, a bad range) are agreed on BEFORE the first data collective: MAX of a flag
+    double* flag = nullptr;
+    int frc = vsl_ctx_dscratch(ctx, 64, (void**)&flag);
+    const double mine = (rc || frc) ? 1.0 : 0.0;
+    double any = mine;
+    if (!frc) {
+      if (hipMemcpyAsync(flag, &mine, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) frc = VSL_ERR_HIP;
+    }
+    // (a rank that cannot even stage the flag still enters the collective with whatever the buffer holds: it is
+    // about to fail anyway and must not leave the others hanging)
+    const int arc = allreduce(user, flag, 1, 1, (void*)ctx->stream);
+    if (!arc && !frc && hipMemcpyAsync(&any, flag, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess)
+      (void)hipStreamSynchronize(ctx->stream);
+    if (rc || frc || arc || any != 0.0) {
+      if (s) vsl_ba_session_destroy(s);
+      if (rc) return rc;  // this rank's own message is already in place
+      return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_global_bundle_adjust: set-up failed on %s (all ranks leave together)",
+                      (frc || arc) ? "this rank's status exchange" : "another rank");
+    }
+  } else if (rc) {
+    return rc;
+  }
   rc = vsl_ba_session_solve(s, allreduce, user, world, opt->max_num_iterations, opt->verbosity, prob->poses, prob->points, summary);
   vsl_ba_session_destroy(s);
   return rc;

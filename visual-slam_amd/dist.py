@@ -51,6 +51,18 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(value, device="cpu"):
+    """Every rank's python float, in rank order (the benchmark line lists per-rank times so that a straggler shows)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(x.item()) for x in parts]
+
+
 def stream_seeds(rank, n_streams_per_rank, base=10):
     """Seeds of the synthetic streams a rank owns: disjoint across ranks, stable across world sizes."""
     return [base + 1000 * rank + i for i in range(n_streams_per_rank)]
