@@ -211,6 +211,7 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "ba_force_dense" (0/1)          large bundle adjustment with the dense reduced camera system (no band ordering)
  *   "ba_schur_atomics" (0/1)        large-system Schur complement by fp64 atomics instead of the per-block gather
  *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks
+ *   "bow_keys64" (0/1)              vocabulary transform with 64-bit (id, feature) sort keys where 32 bits would do
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
  *                                   detected at the next synchronisation and the range is redone by the f64 kernel
  *   "select_bucket_cap" (default 128) fullest response bin the selection kernel's counting sort accepts; 0 = always
@@ -472,6 +473,19 @@ int vsl_compute_bow_vector(vsl_ctx* ctx, const vsl_voc* voc, const uint8_t* img,
 int vsl_bow_score_batch(vsl_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int q_nnz,
                         const uint32_t* c_ids, const double* c_vals, const int32_t* c_offsets,
                         int m, double* scores);
+
+/* A device-resident database of BowVectors -- what the reference keeps per keyframe in Camera::bow_vector
+ * (include/visnav/common_types.h:204-221) and scores one pair at a time with voc->score
+ * (loop_closure_utils.h:119, :201; tracking.h:208).  Vectors are appended once (word ids strictly ascending,
+ * *index_out = position); vsl_bowdb_score scores one query against the vectors cand_index[0..m) (null: vectors
+ * 0..m-1) with no candidate bytes crossing PCIe.  Same arithmetic and summation order as vsl_bow_score_batch. */
+typedef struct vsl_bowdb vsl_bowdb;
+int vsl_bowdb_create(vsl_ctx* ctx, int64_t cap_entries, int cap_vectors, vsl_bowdb** out);
+int vsl_bowdb_destroy(vsl_bowdb* db);
+int vsl_bowdb_append(vsl_ctx* ctx, vsl_bowdb* db, const uint32_t* ids, const double* vals, int nnz, int* index_out);
+int vsl_bowdb_info(const vsl_bowdb* db, int* n_vectors, int64_t* n_entries);
+int vsl_bowdb_score(vsl_ctx* ctx, const vsl_bowdb* db, const uint32_t* q_ids, const double* q_vals, int q_nnz,
+                    const int32_t* cand_index, int m, double* scores);
 
 /* Bit-order converters of include/visnav/converter.h:23-33 and :50-61
  * (bitset<256> word layout <-> 32-byte MSB-first row).  Pure host helpers. */

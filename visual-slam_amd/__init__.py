@@ -502,6 +502,57 @@ class Vocabulary:
             pass
 
 
+class BowDatabase:
+    """Device-resident BowVectors (vsl_bowdb_*): append once per keyframe, score a query against any subset."""
+
+    def __init__(self, ctx, cap_entries=1 << 20, cap_vectors=1024):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._ck(ctx.L.vsl_bowdb_create(ctx.h, C.c_int64(int(cap_entries)), int(cap_vectors), C.byref(h)))
+        self.h = h
+
+    def append(self, ids, vals):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        vals = np.ascontiguousarray(vals, np.float64)
+        assert len(ids) == len(vals)
+        idx = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_bowdb_append(self.ctx.h, self.h, ids.ctypes.data_as(u32p), vals.ctypes.data_as(f64p),
+                                                 len(ids), C.byref(idx)))
+        return idx.value
+
+    def info(self):
+        n, e = C.c_int32(), C.c_int64()
+        self.ctx._ck(self.ctx.L.vsl_bowdb_info(self.h, C.byref(n), C.byref(e)))
+        return n.value, e.value
+
+    def score(self, q_ids, q_vals, cand_index=None, m=None):
+        """L1 scores of the query against vectors cand_index (or the first m / all vectors)."""
+        q_ids = np.ascontiguousarray(q_ids, np.uint32)
+        q_vals = np.ascontiguousarray(q_vals, np.float64)
+        if cand_index is not None:
+            cand_index = np.ascontiguousarray(cand_index, np.int32)
+            m = len(cand_index)
+            ip = cand_index.ctypes.data_as(i32p)
+        else:
+            m = self.info()[0] if m is None else int(m)
+            ip = None
+        scores = np.zeros(max(m, 1), np.float64)
+        self.ctx._ck(self.ctx.L.vsl_bowdb_score(self.ctx.h, self.h, q_ids.ctypes.data_as(u32p), q_vals.ctypes.data_as(f64p),
+                                                len(q_ids), ip, m, scores.ctypes.data_as(f64p)))
+        return scores[:m].copy()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.vsl_bowdb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Event:
     """vsl_event: marks a point in one context's stream for another context to wait on (device side)."""
 

@@ -75,6 +75,7 @@ struct vsl_ctx {
   bool ba_schur_atomics = false;        // diagnostic: large-system Schur complement by fp64 atomics (one wavefront per landmark) instead of the per-block gather
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int describe_tile_min_images = 96;   // describe launches of at least this many images use the shared-tile kernel (measured break-even ~64 images; diagnostic: 1 forces it, 0 disables it)
+  bool bow_keys64 = false;              // diagnostic: 64-bit sort keys in the BowVector assembly even where (id, feature) fits 32 bits
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = -1;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };

@@ -257,6 +257,53 @@ def vocabulary_text(seed, k=10, L=3, stop_frac=0.02):
     return "\n".join(lines) + "\n"
 
 
+def vocabulary_arrays(seed, k=10, L=6, stop_frac=0.02):
+    """The same kind of tree as vocabulary_text() as arrays, vectorised so that the ORB-SLAM shape (k = 10, L = 6:
+    1,111,111 nodes, 1,000,000 words -- what ORBvoc.txt holds, TemplatedVocabulary.h:1338-1424; the file itself is a
+    missing blob) is generated in seconds.  Breadth-first creation order: the k children of a node are consecutive.
+    Returns parent [n] i32, is_leaf [n] u8, desc [n, 32] u8, weight [n] f64 for nodes 1..n (node 0 = root is implicit)."""
+    rng = np.random.default_rng(seed)
+    parents, leaves, descs, weights = [], [], [], []
+    level_ids = np.zeros(1, np.int64)
+    level_desc = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    next_id = 1
+    for lev in range(1, L + 1):
+        flips = max(8, 96 >> (lev - 1))
+        m = len(level_ids) * k
+        bits = np.unpackbits(np.repeat(level_desc, k, axis=0), axis=1, bitorder="little")       # [m, 256]
+        # `flips` random positions per child (a repeated position flips once: a child differs in <= flips bits)
+        pos = rng.integers(0, 256, (m, flips))
+        np.put_along_axis(bits, pos, 1 - np.take_along_axis(bits, pos, axis=1), axis=1)
+        d = np.packbits(bits, axis=1, bitorder="little")
+        leaf = lev == L
+        w = np.zeros(m)
+        if leaf:
+            w = np.where(rng.random(m) < stop_frac, 0.0, rng.uniform(0.5, 9.0, m))
+            w = np.round(w, 6)    # what the text format's %.6f keeps
+        parents.append(np.repeat(level_ids, k).astype(np.int32))
+        leaves.append(np.full(m, 1 if leaf else 0, np.uint8))
+        descs.append(d)
+        weights.append(w)
+        level_ids = np.arange(next_id, next_id + m, dtype=np.int64)
+        level_desc = d
+        next_id += m
+    return (np.concatenate(parents), np.concatenate(leaves), np.concatenate(descs, axis=0), np.concatenate(weights))
+
+
+def write_vocabulary_text(path, k, L, parent, is_leaf, desc, weight, chunk=65536):
+    """ORBvoc.txt layout (`k L 0 0`, then `parent is_leaf d0 .. d31 weight` per node), written in chunks."""
+    byte_txt = np.array([str(i) for i in range(256)])
+    with open(path, "w") as f:
+        f.write("%d %d 0 0\n" % (k, L))
+        for a in range(0, len(parent), chunk):
+            b = min(a + chunk, len(parent))
+            dtxt = byte_txt[desc[a:b]]
+            rows = [" ".join((str(p), str(lf), " ".join(dr), "%.6f" % w))
+                    for p, lf, dr, w in zip(parent[a:b].tolist(), is_leaf[a:b].tolist(), dtxt.tolist(), weight[a:b].tolist())]
+            f.write("\n".join(rows))
+            f.write("\n")
+
+
 def pose_graph(seed, n_nodes=60, n_loop_edges=25, meas_noise=0.0, drift=0.02, outlier_edges=0):
     """Keyframe poses on a noisy loop + relative-pose edges (loop_closure_utils.h:446-587: spanning-tree edges
     between consecutive keyframes, covisibility edges, one loop constraint).  Returns a dict with
