@@ -527,7 +527,10 @@ class Odometry {
       {
         std::unique_lock<std::mutex> lk(job_mutex);
         job_cv.wait(lk, [this] { return job_pending || worker_exit; });
-        if (worker_exit && !job_pending) return;
+        if (worker_exit && !job_pending) {
+          amd::release_thread_ctx();  // this thread's context goes now, not in a thread-local destructor
+          return;
+        }
         f = job;
         job_pending = false;
       }
@@ -729,7 +732,10 @@ class Odometry {
     std::vector<int32_t> pairs(2 * (size_t)opt.num_features_per_image);
     int n = 0, n_proj = 0;
     const auto& cam = calib_cam.intrinsics[0];
-    amd::check(vsl_map_track(dev_map, dev_frames, cur_base, current_pose.data(), amd::camera_model_id(cam->name()), cam->data(),
+    // the same pose the operator path projects with (src/slam.cpp:1099-1114: the constant-motion prediction while
+    // relocalisation is enabled and tracking is healthy)
+    const Sophus::SE3d T_proj = projection_pose();
+    amd::check(vsl_map_track(dev_map, dev_frames, cur_base, T_proj.data(), amd::camera_model_id(cam->name()), cam->data(),
                              cam->width(), cam->height(), opt.cam_z_threshold, opt.match_max_dist_2d, opt.feature_match_max_dist,
                              opt.feature_match_test_next_best, pairs.data(), &n, &n_proj),
                "vsl_map_track");

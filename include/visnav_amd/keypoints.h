@@ -30,20 +30,36 @@ static_assert(sizeof(std::bitset<256>) == 32, "std::bitset<256> must be four 64-
 namespace amd {
 // One context per host thread: the reference calls this path from up to three threads
 // (main, opt_thread, global_ba_thread -- src/slam.cpp:1557, :1780).
+struct CtxHolder {
+  vsl_ctx* c = nullptr;
+  ~CtxHolder() {
+    if (c) vsl_ctx_destroy(c);
+  }
+};
+inline CtxHolder& ctx_holder() {
+  static thread_local CtxHolder h;
+  return h;
+}
 inline vsl_ctx* ctx() {
-  struct Holder {
-    vsl_ctx* c = nullptr;
-    Holder() {
-      // the same device rule as the RCCL communicator (device_select.h): VISNAV_AMD_DEVICE, LOCAL_RANK, RANK
-      if (vsl_ctx_create(device_index_for(vsl_device_count()), &c) != VSL_OK) {
-        std::fprintf(stderr, "visnav_amd: %s\n", vsl_last_error(nullptr));
-        std::abort();
-      }
+  CtxHolder& h = ctx_holder();
+  if (!h.c) {
+    // the same device rule as the RCCL communicator (device_select.h): VISNAV_AMD_DEVICE, LOCAL_RANK, RANK
+    if (vsl_ctx_create(device_index_for(vsl_device_count()), &h.c) != VSL_OK) {
+      std::fprintf(stderr, "visnav_amd: %s\n", vsl_last_error(nullptr));
+      std::abort();
     }
-    ~Holder() { vsl_ctx_destroy(c); }
-  };
-  static thread_local Holder h;
+  }
   return h.c;
+}
+// Destroys the calling thread's context NOW instead of in the thread-local destructor (a thread that is about to exit
+// calls this when tools that hook the HIP runtime -- rocprofv3 -- are already tearing their own thread state down by
+// the time thread-local destructors run).  A later ctx() on the same thread creates a fresh one.
+inline void release_thread_ctx() {
+  CtxHolder& h = ctx_holder();
+  if (h.c) {
+    vsl_ctx_destroy(h.c);
+    h.c = nullptr;
+  }
 }
 inline void check(int rc, const char* what) {
   if (rc != VSL_OK) {

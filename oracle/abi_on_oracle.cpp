@@ -32,6 +32,7 @@ static int fail(vsl_ctx* c, int code, const char* msg) {
 extern "C" {
 const char* vsl_version(void) { return "vslam ABI on the CPU oracle (baseline only)"; }
 const char* vsl_last_error(const vsl_ctx* c) { return c ? c->err : g_err; }
+int vsl_device_count(void) { return 1; }  // one "device": the host
 int vsl_ctx_create(int, vsl_ctx** out) {
   *out = new vsl_ctx();
   (*out)->err[0] = 0;

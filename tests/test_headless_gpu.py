@@ -107,6 +107,13 @@ def test_relocalization_branch(loop_sequence):
     assert out["ate_rmse_m"] < 0.015, out
     assert out["reloc_check_ok"] == 1 and out["reloc_check_err_m"] < 0.03, out
     assert out["bow_vectors"] == out["keyframes"]
+    # with relocalisation on, the guided search projects with the constant-motion prediction (src/slam.cpp:1099-1114); the
+    # device-resident path must use the same pose (it used current_pose until round 3): byte-identical trajectories
+    ta, tb = d / "reloc_ops.csv", d / "reloc_fused.csv"
+    common = ["--frames", "120", "--kf-min-inliers", "400", "--voc-path", str(d / "voc.txt"), "--relocalization"]
+    _run(d, *common, "--traj", str(ta))
+    _run(d, *common, "--traj", str(tb), "--fused")
+    assert ta.read_bytes() == tb.read_bytes()
 
 
 def test_loop_closing_stages_and_global_ba(loop_sequence):

@@ -1,0 +1,63 @@
+#!/bin/bash
+# Single-stream device accounting: rocprofv3 --kernel-trace --stats (+ memory-copy trace) of
+# `slam_headless --fused` with the reference's default-on branches on the benchmark's rendered lap.  On the GPU box:
+#   bash tools/e2e_profile.sh <round tag, e.g. r03> [n_frames step radius]
+# writes gpurun_out/<tag>_e2e_kernel_stats.{csv,json}; copy them to profiles/ (tools/install_profiles.sh).
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; N=${2:-640}; STEP=${3:-0.03}; RAD=${4:-2.674}
+D=/tmp/vsl_lap_${N}_${STEP}_${RAD}
+V=/tmp/vsl_voc_k10L6_s7.txt
+if [ ! -f $D/calib.json ] || [ ! -f $V ]; then
+python3 - <<PY
+import sys, importlib, os; sys.path.insert(0, "$R"); import __graft_entry__ as e; e.load_package()
+sq = importlib.import_module('visual_slam_amd.synth_sequence'); s = importlib.import_module('visual_slam_amd.synth')
+if not os.path.exists("$D/calib.json"):
+    sq.render_sequence("$D", n_frames=$N, seed=1, step_m=$STEP, radius=$RAD, workers=min(16, os.cpu_count()))
+if not os.path.exists("$V"):
+    s.write_vocabulary_text("$V", 10, 6, *s.vocabulary_arrays(7, 10, 6))
+PY
+fi
+LAP=$(python3 -c "import math; print(max(int(round(2*math.pi*$RAD/$STEP))-20,1))")
+FLAGS="--dataset-path $D --cam-calib $D/calib.json --voc-path $V --relocalization --loop-closure --force-loop $LAP:0 --fused"
+OUT=$R/gpurun_out/${TAG}_e2e_kt
+rm -rf $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT -- $R/visual-slam_amd/slam_headless $FLAGS > $R/gpurun_out/${TAG}_e2e_kt.log 2>&1
+tail -1 $R/gpurun_out/${TAG}_e2e_kt.log | cut -c1-400
+python3 - $OUT $R/gpurun_out/${TAG}_e2e_kernel_stats $N "$FLAGS" $R/gpurun_out/${TAG}_e2e_kt.log <<'PY'
+import csv, glob, json, os, sys
+out_dir, dst, n, flags, log = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+ks = max(glob.glob(out_dir + '/*/*kernel_stats.csv'), key=os.path.getmtime)
+rows = list(csv.DictReader(open(ks)))
+line = [l for l in open(log) if l.startswith('{"frames"')][-1]
+app = json.loads(line)
+warm = min(n, 60)                      # the application's untimed warm-up object runs the first 60 frames as well
+frames = n + warm
+launches = sum(int(r['Calls']) for r in rows)
+total_ns = sum(float(r['TotalDurationNs']) for r in rows)
+copies = 0
+for f in glob.glob(out_dir + '/*/*memory_copy_stats.csv'):
+    copies = sum(int(r['Calls']) for r in csv.DictReader(open(f)))
+with open(dst + '.csv', 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['kernel', 'calls', 'calls_per_frame', 'avg_us', 'total_ms', 'percent'])
+    for r in rows:
+        name = r['Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
+        w.writerow([name, r['Calls'], '%.3f' % (int(r['Calls']) / frames), '%.2f' % (float(r['AverageNs']) / 1e3),
+                    '%.3f' % (float(r['TotalDurationNs']) / 1e6), r['Percentage']])
+doc = {"command": "rocprofv3 --kernel-trace --memory-copy-trace --stats -- slam_headless " + flags.replace(os.environ.get('GRAFT_REPO_ROOT', ''), '.'),
+       "frames": frames, "frames_note": "%d timed + %d of the untimed warm-up object" % (n, warm),
+       "keyframes": app["keyframes"], "loops_closed": app["loops_closed"], "global_ba_runs": app["global_ba_runs"],
+       "kernel_launches": launches, "kernel_launches_per_frame": round(launches / frames, 2),
+       "memcpy_calls_per_frame": round(copies / frames, 2) if copies else None,
+       "sum_kernel_us_per_frame": round(total_ns / 1e3 / frames, 2),
+       "launch_floor_us_per_frame": round(4.0 * launches / frames, 1),
+       "wall_ms_per_frame_under_profiler": app["ms_per_frame"],
+       "note": "launch floor = launches x ~4 us of host cost per launch on this stack (DESIGN 5); kernel sums include the "
+               "keyframes' local BA, the ORB front end, pose graph and global BA amortised over all frames",
+       "top_kernels": [{"kernel": r['Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0],
+                        "calls_per_frame": round(int(r['Calls']) / frames, 3), "avg_us": round(float(r['AverageNs']) / 1e3, 2),
+                        "us_per_frame": round(float(r['TotalDurationNs']) / 1e3 / frames, 2)} for r in rows[:14]]}
+json.dump(doc, open(dst + '.json', 'w'), indent=1)
+print(json.dumps({k: doc[k] for k in ("frames", "kernel_launches_per_frame", "memcpy_calls_per_frame", "sum_kernel_us_per_frame", "wall_ms_per_frame_under_profiler")}))
+for k in doc["top_kernels"]: print(k)
+PY

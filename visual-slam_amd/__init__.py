@@ -393,6 +393,35 @@ class Context:
         return scores[:m].copy()
 
 
+class BaArrays:
+    """Owns the contiguous numpy arrays of a flattened bundle-adjustment problem (the layout of vsl_ba_problem,
+    include/vslam_hip.h): what Context.bundle_adjust / ba_linearize / BaSession take."""
+
+    def __init__(self, poses, cam_fixed, cam_intr, intr, points, obs_cam, obs_lm, obs_uv, cam_model=(0, 0)):
+        self.poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7).copy()
+        self.cam_fixed = np.ascontiguousarray(cam_fixed, np.uint8).copy()
+        self.cam_intr = np.ascontiguousarray(cam_intr, np.int32).copy()
+        self.intr = np.ascontiguousarray(intr, np.float64).reshape(2, 8).copy()
+        self.points = np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy()
+        self.obs_cam = np.ascontiguousarray(obs_cam, np.int32).copy()
+        self.obs_lm = np.ascontiguousarray(obs_lm, np.int32).copy()
+        self.obs_uv = np.ascontiguousarray(obs_uv, np.float64).reshape(-1, 2).copy()
+        self.cam_model = tuple(int(m) for m in cam_model)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(d["poses"], d["cam_fixed"], d["cam_intr"], d["intr"], d["points"], d["obs_cam"], d["obs_lm"], d["obs_uv"],
+                   d.get("cam_model", (0, 0)))
+
+    def copy(self):
+        return BaArrays(self.poses, self.cam_fixed, self.cam_intr, self.intr, self.points, self.obs_cam, self.obs_lm,
+                        self.obs_uv, self.cam_model)
+
+    @property
+    def n_free(self):
+        return int((self.cam_fixed == 0).sum())
+
+
 class BaSession:
     """vsl_ba_session: the step-wise (multi-GPU) bundle-adjustment API; see ba_dist.py for the loop."""
 

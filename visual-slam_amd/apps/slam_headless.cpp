@@ -174,7 +174,8 @@ int main(int argc, char** argv) {
                      o.current_pose.data()[4], o.current_pose.data()[5], o.current_pose.data()[6]);
     }
     o.finish();
-    o.release_device();  // the thread-local context dies with this thread
+    o.release_device();
+    amd::release_thread_ctx();  // explicitly, not in the thread-local destructor (rocprofv3 is torn down by then)
   };
   int n_kf = 0;
   std::vector<std::thread> threads;
@@ -217,6 +218,7 @@ int main(int argc, char** argv) {
         }
         reloc_err_m = std::sqrt(e);
       }
+      amd::release_thread_ctx();
     });
     t.join();
   }

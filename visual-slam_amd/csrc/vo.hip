@@ -125,6 +125,69 @@ __global__ __launch_bounds__(1024) void compact_projection_kernel(const double* 
   if (threadIdx.x == 0) *n_out = base_s;
 }
 
+// project_landmarks + the order-preserving compaction in ONE launch (vsl_map_track): a workgroup projects 1024 landmarks,
+// compacts them in landmark order, and takes its base offset from the chain of its predecessors' totals ("stream
+// scan": block b waits for block b - 1's running total, published as one 64-bit word (epoch << 32 | total) with
+// release / acquire at device scope -- no flags to reset between calls, the epoch changes).  Workgroups are dispatched
+// in index order and a map of 100 k landmarks is 100 workgroups on 256 compute units: a predecessor is always resident.
+struct PoseIntr {
+  double v[16];  // pose (qx qy qz qw tx ty tz, pad) | intrinsics (8)
+};
+__global__ __launch_bounds__(1024) void project_compact_kernel(PoseIntr pi, int model, int width, int height,
+                                                               const double* __restrict__ points, int n, double z_thr,
+                                                               double* __restrict__ out_uv, int32_t* __restrict__ out_idx,
+                                                               int32_t* __restrict__ n_out, unsigned long long* __restrict__ chain,
+                                                               unsigned int epoch) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool ok = false;
+  double u = 0, v = 0;
+  if (i < n) {
+    const double* pose = pi.v;
+    const double qi[4] = {-pose[0], -pose[1], -pose[2], pose[3]};
+    const double nt[3] = {pose[4] * -1.0, pose[5] * -1.0, pose[6] * -1.0};
+    double ti[3], rp[3];
+    quat_rotate_d(qi, nt, ti);
+    const double p[3] = {points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]};
+    quat_rotate_d(qi, p, rp);
+    const double pc[3] = {rp[0] + ti[0], rp[1] + ti[1], rp[2] + ti[2]};
+    ok = !(pc[2] < z_thr);
+    if (ok) {
+      project_exact(model, pi.v + 8, pc[0], pc[1], pc[2], u, v);
+      ok = !(u > (double)width || v > (double)height || u < 0 || v < 0);
+    }
+  }
+  const unsigned long long m = __ballot(ok);
+  if (lane == 0) wave_tot[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < 16; w++) total += wave_tot[w];
+    unsigned long long prev = 0;
+    if (blockIdx.x > 0) {
+      do {
+        prev = __hip_atomic_load(&chain[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((unsigned int)(prev >> 32) != epoch);
+    }
+    const int base = (int)(unsigned int)prev;
+    __hip_atomic_store(&chain[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned int)(base + total), __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    base_s = base;
+    if (blockIdx.x == gridDim.x - 1) *n_out = base + total;
+  }
+  __syncthreads();
+  if (ok) {
+    int off = base_s;
+    for (int w = 0; w < wave; w++) off += wave_tot[w];
+    const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+    out_uv[2 * (size_t)p] = u;
+    out_uv[2 * (size_t)p + 1] = v;
+    out_idx[p] = i;
+  }
+}
+
 // one wavefront per keypoint; result[k] = matched landmark index or -1
 __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restrict__ kp_xy, const uint64_t* __restrict__ kp_desc,
                                                            int n_kp, const double* __restrict__ proj_uv,
@@ -134,16 +197,26 @@ __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restr
                                                            int threshold, double dist_2_best, int32_t* __restrict__ result,
                                                            const int32_t* __restrict__ kp_xy_i32,
                                                            const int32_t* __restrict__ obs_index,
-                                                           const int32_t* __restrict__ n_kp_dev,
-                                                           const int32_t* __restrict__ n_proj_dev) {
+                                                           const int32_t* __restrict__ n_kp_dev, int result_cap,
+                                                           const int32_t* __restrict__ n_proj_dev,
+                                                           int32_t* __restrict__ mail_hdr,
+                                                           const int32_t* __restrict__ tie_count_dev) {
   // Device-resident callers (vsl_map_track) pass the keypoints of a frame store slot (int32 positions,
   // count on the device), the number of projected landmarks on the device, and observation descriptors
   // through an index into the map's descriptor pool; the host-buffer entry point passes none of them.
   if (n_kp_dev) n_kp = *n_kp_dev;
   if (n_proj_dev) n_proj = *n_proj_dev;
+  if (mail_hdr && blockIdx.x == 0 && threadIdx.x == 0) {  // the header of the caller's mailbox (vsl_map_track)
+    mail_hdr[0] = n_proj;
+    mail_hdr[1] = tie_count_dev ? *tie_count_dev : 0;
+    mail_hdr[2] = n_kp;
+  }
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (k >= n_kp) return;  // wave-uniform
+  if (k >= n_kp) {  // wave-uniform; the slot still gets its "no match" (the callers no longer memset the array)
+    if (lane == 0 && k < result_cap) result[k] = -1;
+    return;
+  }
   const double kx = kp_xy_i32 ? (double)kp_xy_i32[2 * (size_t)k] : kp_xy[2 * (size_t)k];
   const double ky = kp_xy_i32 ? (double)kp_xy_i32[2 * (size_t)k + 1] : kp_xy[2 * (size_t)k + 1];
   uint32_t d[8];
@@ -330,7 +403,8 @@ extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, con
   VSL_HIP(ctx, hipMemcpyAsync(dstart, lm_obs_start, 4 * (L + 1), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(find_matches_kernel, dim3((n_kp + 3) / 4), dim3(256), 0, ctx->stream, dkxy, dkd, n_kp, dpuv, dplm, n_proj,
                      dstart, dod, match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, dres,
-                     (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                     (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, n_kp, (const int32_t*)nullptr,
+                     (int32_t*)nullptr, (const int32_t*)nullptr);
   hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, dres, n_kp, dpairs, dn);
   VSL_CHECK_LAUNCH(ctx);
   void* hp = nullptr;
@@ -371,6 +445,11 @@ struct vsl_map {
   int32_t* result = nullptr;    // [cap_kp]
   int32_t* pairs = nullptr;     // [cap_kp][2]
   int32_t* gather_ids = nullptr;  // [cap_kp]
+  unsigned long long* chain = nullptr;  // [cap_lms / 1024 + 1] running totals of project_compact_kernel
+  int chain_cap = 0;
+  unsigned int epoch = 0;
+  int32_t* mailbox = nullptr;  // pinned host memory the matching kernel writes: [n_proj, tie_count, n_kp, pad | result[cap_kp]]
+  int mailbox_cap = 0;
 };
 
 namespace {
@@ -458,9 +537,10 @@ extern "C" void vsl_map_destroy(vsl_map* m) {
   if (!m) return;
   (void)hipSetDevice(m->ctx->device);
   void* ptrs[] = {m->points, m->obs_start, m->obs_index, m->pool, m->uv, m->out_uv, m->out_idx, m->keep,
-                  m->pose_intr, m->counters, m->result, m->pairs, m->gather_ids};
+                  m->pose_intr, m->counters, m->result, m->pairs, m->gather_ids, m->chain};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (m->mailbox) (void)hipHostFree(m->mailbox);
   delete m;
 }
 
@@ -548,38 +628,71 @@ extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* 
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   int rc = map_reserve_kp(m, f->F);
   if (rc) return rc;
-  if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;  // descriptors of the slot must be final
   const int n = m->n_lms;
-  if (n == 0) return VSL_OK;
-  double hp[16];
-  for (int i = 0; i < 7; i++) hp[i] = pose7[i];
-  hp[7] = 0;
-  for (int i = 0; i < 8; i++) hp[8 + i] = intr8[i];
-  VSL_HIP(ctx, hipMemcpyAsync(m->pose_intr, hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(project_landmarks_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->pose_intr, cam_model,
-                     m->pose_intr + 8, width, height, m->points, n, cam_z_threshold, m->uv, m->keep);
-  hipLaunchKernelGGL(compact_projection_kernel, dim3(1), dim3(1024), 0, ctx->stream, m->uv, m->keep, n, m->out_uv, m->out_idx,
-                     m->counters);
-  VSL_HIP(ctx, hipMemsetAsync(m->result, 0xFF, 4 * (size_t)f->F, ctx->stream));
-  hipLaunchKernelGGL(find_matches_kernel, dim3((f->F + 3) / 4), dim3(256), 0, ctx->stream, (const double*)nullptr,
-                     f->kp_desc + 4 * (size_t)slot * f->F, f->F, m->out_uv, m->out_idx, n, m->obs_start, m->pool,
-                     match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, m->result,
-                     f->kp_xy + 2 * (size_t)slot * f->F, m->obs_index, f->kp_count + slot, m->counters);
-  hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, m->result, f->F, m->pairs, m->counters + 1);
-  VSL_CHECK_LAUNCH(ctx);
-  void* hpin = nullptr;
-  rc = vsl_ctx_hpinned(ctx, 64 + 8 * (size_t)f->F, &hpin);
-  if (rc) return rc;
-  int32_t* cnt = (int32_t*)hpin;
-  int32_t* hpairs = (int32_t*)((char*)hpin + 64);
-  VSL_HIP(ctx, hipMemcpyAsync(cnt, m->counters, 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (pairs) VSL_HIP(ctx, hipMemcpyAsync(hpairs, m->pairs, 8 * (size_t)f->F, hipMemcpyDeviceToHost, ctx->stream));
-  VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (n_projected) *n_projected = cnt[0];
-  *n_pairs = cnt[1];
-  if (cnt[1] > 0) {
-    if (!pairs) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_track: pairs is null");
-    std::memcpy(pairs, hpairs, 8 * (size_t)cnt[1]);
+  if (n == 0) return vsl_resolve_ties(ctx, f, nullptr);
+  // Two launches and one synchronisation per call (round 3; it was a tie-guard round trip, a pose upload, four kernels,
+  // a memset and two copies): the pose travels as a kernel argument, projection + ordered compaction are one kernel,
+  // the matching kernel writes its per-keypoint results, the projected count and the frame store's near-tie count
+  // straight into pinned host memory, and the match list is compacted on the host (<= F entries).
+  const int n_blocks = (n + 1023) / 1024;
+  if (n_blocks + 1 > m->chain_cap) {
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->chain) (void)hipFree(m->chain);
+    m->chain = nullptr;
+    m->chain_cap = 0;
+    const int cap = 2 * n_blocks + 64;
+    VSL_HIP(ctx, hipMalloc((void**)&m->chain, 8 * (size_t)cap));
+    VSL_HIP(ctx, hipMemsetAsync(m->chain, 0, 8 * (size_t)cap, ctx->stream));
+    m->chain_cap = cap;
+    m->epoch = 0;
   }
+  if (f->F + 4 > m->mailbox_cap) {
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->mailbox) (void)hipHostFree(m->mailbox);
+    m->mailbox = nullptr;
+    m->mailbox_cap = 0;
+    VSL_HIP(ctx, hipHostMalloc((void**)&m->mailbox, 4 * ((size_t)f->F + 4), hipHostMallocMapped | hipHostMallocCoherent));
+    m->mailbox_cap = f->F + 4;
+  }
+  PoseIntr pi;
+  for (int i = 0; i < 7; i++) pi.v[i] = pose7[i];
+  pi.v[7] = 0;
+  for (int i = 0; i < 8; i++) pi.v[8 + i] = intr8[i];
+  if (++m->epoch == 0) {  // 2^32 calls later: the chain words of epoch 0 are the freshly cleared ones
+    VSL_HIP(ctx, hipMemsetAsync(m->chain, 0, 8 * (size_t)m->chain_cap, ctx->stream));
+    m->epoch = 1;
+  }
+  hipLaunchKernelGGL(project_compact_kernel, dim3(n_blocks), dim3(1024), 0, ctx->stream, pi, cam_model, width, height, m->points, n,
+                     cam_z_threshold, m->out_uv, m->out_idx, m->counters, m->chain, m->epoch);
+  int32_t* mail = m->mailbox;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    hipLaunchKernelGGL(find_matches_kernel, dim3((f->F + 3) / 4), dim3(256), 0, ctx->stream, (const double*)nullptr,
+                       f->kp_desc + 4 * (size_t)slot * f->F, f->F, m->out_uv, m->out_idx, n, m->obs_start, m->pool,
+                       match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, mail + 4,
+                       f->kp_xy + 2 * (size_t)slot * f->F, m->obs_index, f->kp_count + slot, f->F, m->counters, mail,
+                       f->ties_pending ? f->tie_count : (const int32_t*)nullptr);
+    VSL_CHECK_LAUNCH(ctx);
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // The descriptors of the slot must be final (rBRIEF near-tie guard, describe.hip).  The guard's count came along
+    // with the results: zero (all but ~3 in a million frames) -> done, no second round trip; otherwise resolve the
+    // ties the usual way and match once more.
+    if (!f->ties_pending) break;
+    if (mail[1] == 0) {
+      f->ties_pending = false;
+      break;
+    }
+    if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;
+  }
+  if (n_projected) *n_projected = mail[0];
+  int np = 0;
+  const int32_t* res = mail + 4;
+  for (int k = 0; k < f->F; k++)
+    if (res[k] >= 0) {
+      if (!pairs) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_map_track: pairs is null");
+      pairs[2 * np] = k;
+      pairs[2 * np + 1] = res[k];
+      np++;
+    }
+  *n_pairs = np;
   return VSL_OK;
 }
