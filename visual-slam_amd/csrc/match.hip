@@ -305,24 +305,83 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 #define MX_KEY_SCALE 2048.0f
 #define MX_PAD_KEY_F 4.0e6f  // rows past the end of the database: above every real key (max real key < 2^21)
 
+//
+// Round 3: the distance matrix is no longer computed twice.  The reference scans forward once and checks the reverse
+// direction only for rows that pass threshold + ratio (keypoints.h:355-362, :282-312), so
+//   launch 1 (REVERSE = false): queries = set a, database = set b -> best / second per row i          (n_a x n_b distances)
+//   launch 2 (REVERSE = true):  every workgroup first lists, in LDS, the columns j = best(i) of the rows that passed
+//                               (ascending j, <= n_b of them; ~a third of the set on the benchmark frames), then the SAME
+//                               tile loop runs with those columns as queries against set a       (~0.35 n_a x n_b distances)
+// Columns nobody points at keep KEY_INIT-free garbage from an earlier launch -- match_finalize only reads bk1[best(i)] of
+// passing rows, exactly the entries launch 2 wrote.  Both grids are 1-D and XCD-aware: the hardware deals workgroups
+// round-robin to the 8 XCDs, so block id b serves pair 8 (b / 8 / blocks_per_pair) + b % 8 -- all workgroups of a pair
+// share one XCD's L2 and the pair's descriptors are fetched from HBM once instead of once per XCD.
+template <bool REVERSE>
 __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mx_kernel(const uint64_t* __restrict__ desc,
                                                                    const int32_t* __restrict__ kp_count,
                                                                    const int32_t* __restrict__ pair_slots,
                                                                    uint32_t* __restrict__ best_key,
-                                                                   uint32_t* __restrict__ second_key, int F) {
+                                                                   uint32_t* __restrict__ second_key, int F, int n_pairs,
+                                                                   int blocks_per_pair, int threshold, double dist_2_best) {
   __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
   __shared__ __align__(16) float rowkey[2][64];  // 256 * 2048 + m, or MX_PAD_KEY_F past the end
   __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
-  const int pair = blockIdx.z, dir = blockIdx.y;
+  const int xj = (int)(blockIdx.x >> 3);
+  const int pair = (xj / blocks_per_pair) * 8 + (int)(blockIdx.x & 7u);
+  if (pair >= n_pairs) return;  // the pair count is padded to a multiple of 8
+  const int blk = xj % blocks_per_pair;
+  constexpr int dir = REVERSE ? 1 : 0;
   const int slot_q = pair_slots[2 * pair + dir];
   const int slot_d = pair_slots[2 * pair + 1 - dir];
-  const int n_q = kp_count[slot_q], n_d = kp_count[slot_d];
-  const int q0 = blockIdx.x * (32 * MM_WAVES);
-  if (q0 >= n_q) return;  // workgroup-uniform
+  int n_q = kp_count[slot_q];
+  const int n_d = kp_count[slot_d];
+  const int q0 = blk * (32 * MM_WAVES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
+  // REVERSE: the queries are the columns some passing row points at, listed in ascending order
+  __shared__ uint16_t sel[REVERSE ? 2048 : 2];
+  __shared__ unsigned char flag[REVERSE ? 2048 : 2];
+  __shared__ int sel_wave[MM_WAVES];
+  if (REVERSE) {
+    const uint32_t* bk0 = best_key + ((size_t)pair * 2) * F;
+    const uint32_t* sk0 = second_key + ((size_t)pair * 2) * F;
+    for (int j = tid; j < 2048; j += 64 * MM_WAVES) flag[j] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_d; i += 64 * MM_WAVES) {  // n_d = size of set a here: its rows are the forward pass's
+      const uint32_t bk = bk0[i];
+      const int d1 = (int)(bk >> KEY_SHIFT), d2 = (int)(sk0[i] >> KEY_SHIFT);
+      if (n_q > 0 && d1 < threshold && !((double)d2 < (double)d1 * dist_2_best)) flag[bk & ((1u << KEY_SHIFT) - 1)] = 1;
+    }
+    __syncthreads();
+    constexpr int PER = 2048 / (64 * MM_WAVES);  // contiguous flags per thread
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < PER; u++) cnt += flag[tid * PER + u];
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) sel_wave[wave] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < MM_WAVES; w++) {
+      if (w < wave) base += sel_wave[w];
+      total += sel_wave[w];
+    }
+    int pos = base + incl - cnt;
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+      if (flag[tid * PER + u]) sel[pos++] = (uint16_t)(tid * PER + u);
+    n_q = total;
+    __syncthreads();
+  }
+  if (q0 >= n_q) return;  // workgroup-uniform
   const int qc = q0 + wave * 32 + c;
-  const uint32_t* __restrict__ qd = (const uint32_t*)(desc + ((size_t)slot_q * F + (qc < n_q ? qc : 0)) * 4);
+  const int qrow = REVERSE ? (int)sel[qc < n_q ? qc : 0] : (qc < n_q ? qc : 0);
+  const uint32_t* __restrict__ qd = (const uint32_t*)(desc + ((size_t)slot_q * F + qrow) * 4);
   const uint32_t* __restrict__ dbase = (const uint32_t*)(desc + (size_t)slot_d * F * 4);
   if (tid < 256) {
     uint32_t x = (uint32_t)tid;
@@ -418,7 +477,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mx_kernel(const uint64_
       const int ki = (int)__uint_as_float(kb);                   // (acc + 256) * 2048 + m, exact
       return ((uint32_t)((ki >> 11) + pq - 256) << KEY_SHIFT) | (uint32_t)(ki & 2047);
     };
-    const size_t o = ((size_t)pair * 2 + dir) * F + qc;
+    const size_t o = ((size_t)pair * 2 + dir) * F + qrow;
     best_key[o] = unpack(b);
     second_key[o] = unpack(sk);
   }
@@ -494,10 +553,14 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
                          f->kp_count, f->pair_slots, f->best_key, f->second_key, f->F);
     } else {
       dim3 grid((f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES), 2, n_pairs);
-      if (db_bound <= 2048 && !ctx->match_use_i8)
-        hipLaunchKernelGGL(hamming_mx_kernel, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count, f->pair_slots,
-                           f->best_key, f->second_key, f->F);
-      else if (ctx->match_no_stagger)
+      if (db_bound <= 2048 && !ctx->match_use_i8) {
+        const int bpp = (f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES);
+        const dim3 grid1((unsigned)(((n_pairs + 7) / 8) * 8 * bpp));
+        hipLaunchKernelGGL(hamming_mx_kernel<false>, grid1, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
+                           f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, threshold, dist_2_best);
+        hipLaunchKernelGGL(hamming_mx_kernel<true>, grid1, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
+                           f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, threshold, dist_2_best);
+      } else if (ctx->match_no_stagger)
         hipLaunchKernelGGL(hamming_mfma_kernel<false>, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
                            f->pair_slots, f->best_key, f->second_key, f->F);
       else
