@@ -41,8 +41,9 @@ def test_session_world1_matches_single_call_and_oracle(vsl, orc, synth):
     assert s.initial_cost == pytest.approx(s1.initial_cost, rel=1e-12)
     assert s.final_cost == pytest.approx(s1.final_cost, rel=1e-9)
     assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-7)
-    # 58 free cameras -> the large-system Schur path (fp64 atomics: summation order varies run to run),
-    # so ill-conditioned depths may move by more than the well-conditioned bulk
+    # 58 free cameras -> the large-system Schur path.  Its sums are fixed-order gathers (bit-reproducible since the
+    # round-2 rewrite), but the session path reduces per landmark RANGE and adds the partial systems, i.e. in another
+    # order than the single call: ill-conditioned depths may move by more than the well-conditioned bulk
     assert np.allclose(a_sess.poses, a_one.poses, rtol=0, atol=1e-7)
     dp = np.abs(a_sess.points - a_one.points).max(1)
     assert (dp < 1e-6).mean() > 0.97 and dp.max() < 0.05
@@ -106,7 +107,7 @@ def test_rccl_backend_collectives_at_world_size_one():
     import sys
     from conftest import ROOT
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "rccl_smoke.py")], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "rccl smoke ok" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "rccl smoke ok" in r.stdout and "rccl session ok" in r.stdout, r.stdout + r.stderr
 
 
 def _write_problem(path, d):
@@ -143,6 +144,39 @@ def test_cpp_global_bundle_adjustment_through_rccl(tmp_path, orc, synth, ctx):
     assert np.allclose(poses, one.poses, rtol=0, atol=1e-7)
     dp = np.abs(points - one.points).max(1)
     assert (dp < 1e-6).mean() > 0.97 and dp.max() < 0.05
+
+
+def test_linearize_at_baseline_config_4_matches_oracle(vsl, orc, synth):
+    # BASELINE.json configs[4] at FULL size, against the ORACLE: 500 keyframes = 1000 cameras,
+    # ~97 k landmarks, ~880 k observations; one ba_linearize -- the reduced camera system S (5988 x 5988), the gradient g
+    # and the robustified cost -- GPU (the large-system gather path) vs orc.ba_linearize (map_utils.h / loop_closure_utils.h
+    # functor + the restated Schur elimination), 1e-9 relative to the largest entry; and through two landmark ranges
+    # (the multi-GPU partition): the partial systems add up to the same S.
+    d = synth.ba_problem(5, n_kf=500, n_lms=100000, loop_radius=200.0, max_range=15.0)
+    arr = _arr(orc, d)
+    c = vsl.Context(0)
+    S, g, cost = c.ba_linearize(arr)
+    eS, eg, ecost = orc.ba_linearize(arr)
+    n = 6 * int((d["cam_fixed"] == 0).sum())
+    assert S.shape == eS.shape == (n, n) and n == 5988
+    assert cost == pytest.approx(ecost, rel=1e-12)
+    scale = np.abs(eS).max()
+    assert np.abs(S - eS).max() <= 1e-9 * scale
+    assert np.abs(g - eg).max() <= 1e-9 * np.abs(eg).max()
+    assert np.abs(S - S.T).max() <= 1e-9 * scale
+    L = len(arr.points)
+    obs_per_lm = np.bincount(arr.obs_lm, minlength=L)
+    ranges = vsl_dist(vsl).landmark_ranges(obs_per_lm, 2)
+    Ss, gs, cs = 0, 0, 0
+    for first, count in ranges:
+        S1, g1, c1 = c.ba_linearize(arr, lm_first=first, lm_count=count)
+        Ss, gs, cs = Ss + S1, gs + g1, cs + c1
+    assert np.abs(Ss - eS).max() <= 1e-9 * scale and cs == pytest.approx(ecost, rel=1e-12)
+    c.close()
+
+
+def vsl_dist(vsl):
+    return importlib.import_module("visual_slam_amd.dist")
 
 
 def test_global_ba_full_size_properties(vsl, orc, synth):

@@ -23,6 +23,14 @@ import numpy as np
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 
+class _DeviceDoubles:
+    """`count` float64 values at device address `ptr`, exposed through __cuda_array_interface__ so that
+    torch.as_tensor() wraps the memory without copying it."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3, "strides": None}
+
+
 def _make_allreduce(pkg, ctx, group):
     """The callback the C++ loop uses for its collectives (device pointer, count of doubles, op, stream)."""
     import torch
@@ -41,13 +49,13 @@ def _make_allreduce(pkg, ctx, group):
                 dist.all_reduce(t, op=rop, group=group)
                 ctx._ck(ctx.L.vsl_ctx_memcpy(ctx.h, C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), 0))
             else:
-                # RCCL: a device tensor on torch's current stream (= the context's stream, see below); the two copies
-                # are device-to-device on that stream, the collective is ordered against it by torch
-                t = torch.empty(int(count), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
-                ctx._ck(ctx.L.vsl_ctx_memcpy(ctx.h, C.c_void_p(t.data_ptr()), C.c_void_p(buf), C.c_size_t(nbytes), 2))
+                # RCCL: IN PLACE on the library's own device buffer -- a tensor that aliases it (no allocation, no copies)
+                # -- ordered by torch against its current stream, which is the context's stream (see below): the
+                # collective waits for the kernels that produced the buffer and the solver's next kernel waits for the
+                # collective through stream events; the host never synchronises (round 2 allocated a tensor, copied
+                # device-to-device twice and called current_stream().synchronize() per collective)
+                t = torch.as_tensor(_DeviceDoubles(int(buf), int(count)), device=torch.device("cuda", torch.cuda.current_device()))
                 dist.all_reduce(t, op=rop, group=group)
-                torch.cuda.current_stream().synchronize()
-                ctx._ck(ctx.L.vsl_ctx_memcpy(ctx.h, C.c_void_p(buf), C.c_void_p(t.data_ptr()), C.c_size_t(nbytes), 2))
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             state["error"] = e
@@ -56,7 +64,8 @@ def _make_allreduce(pkg, ctx, group):
     return ALLREDUCE_FN(fn), state
 
 
-def bundle_adjust_distributed(pkg, ctx, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0, group=None):
+def bundle_adjust_distributed(pkg, ctx, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0, group=None,
+                              collectives_at_world_one=False):
     """arr: flattened problem (same object as Context.bundle_adjust takes), identical on every rank.
     Optimises arr.poses / arr.points in place on every rank; returns a summary namespace.
 
@@ -73,7 +82,10 @@ def bundle_adjust_distributed(pkg, ctx, arr, use_huber=True, huber=1.0, max_iter
     with torch.cuda.stream(stream):
         st = ctx._ba_struct(arr)
         o = ctx._ba_opts(use_huber, huber, max_iters, verbosity)
-        cb, state = (_make_allreduce(pkg, ctx, group) if world > 1 else (C.cast(None, ALLREDUCE_FN), {"error": None}))
+        # (collectives_at_world_one: a one-rank process group still goes through every collective -- how a one-GPU box
+        # exercises the RCCL path end to end)
+        use_cb = world > 1 or (collectives_at_world_one and distributed)
+        cb, state = (_make_allreduce(pkg, ctx, group) if use_cb else (C.cast(None, ALLREDUCE_FN), {"error": None}))
         out = pkg.BaSummary()
         rc = ctx.L.vsl_global_bundle_adjust(ctx.h, C.byref(st), C.byref(o), cb, None, int(rank), int(world), C.byref(out))
         if state["error"] is not None:

@@ -144,7 +144,12 @@ struct vsl_frames {
   bool ties_pending = false, ties_from_angles = false;
   bool detect_meta_dirty = true;    // MAX / NCAND not in their reset state (first use, or a failed launch)
   bool describe_meta_dirty = true;  // same for NEXACT
-  int last_desc_first = 0, last_desc_n = 0, last_desc_rotate = 1;  // range of the last describe launch (overflow fallback)
+  // slot ranges described by the fast kernels since the last vsl_resolve_ties, in launch order: an exact-list overflow
+  // in ANY of them is redone by the generic f64 kernel there (several asynchronous launches may precede one resolve)
+  struct DescRange {
+    int first, n, rotate;
+  };
+  std::vector<DescRange> pending_desc;
   int exact_fallbacks = 0;            // how often that fallback ran (diagnostic)
   bool store_response = false;  // K1 writes the fp32 response image only for the parity hook
   std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
