@@ -452,8 +452,11 @@ class Odometry {
       }
       auto t2 = Clk::now();
       if (opt.fused_tracking) {
-        fused_track(md);
-        fused_download_corners(cur_base, kdl);
+        // relocalisation / loop closure match keyframe descriptors on the host on demand: then the descriptors are
+        // downloaded too; otherwise the positions ride along with the matches (one round trip per tracked frame)
+        const bool with_desc = opt.enable_relocalization || opt.enable_loop_closure;
+        fused_track(md, with_desc ? nullptr : &kdl);
+        if (with_desc) fused_download_corners(cur_base, kdl);
         fused_prefetch(next_left);
         feature_corners[fcidl] = kdl;
       } else {
@@ -713,7 +716,9 @@ class Odometry {
   }
 
   // project_landmarks + find_matches_landmarks of the reference against the device-resident table
-  void fused_track(LandmarkMatchData& md) {
+  // `kd_out` (frames that are not keyframes, descriptors not needed on the host): the keypoint positions come back in
+  // the same round trip as the matches
+  void fused_track(LandmarkMatchData& md, KeypointsData* kd_out = nullptr) {
     md.matches.clear();
     if (map_dirty) {
       std::vector<double> pts;
@@ -735,11 +740,19 @@ class Odometry {
     // the same pose the operator path projects with (src/slam.cpp:1099-1114: the constant-motion prediction while
     // relocalisation is enabled and tracking is healthy)
     const Sophus::SE3d T_proj = projection_pose();
-    amd::check(vsl_map_track(dev_map, dev_frames, cur_base, T_proj.data(), amd::camera_model_id(cam->name()), cam->data(),
-                             cam->width(), cam->height(), opt.cam_z_threshold, opt.match_max_dist_2d, opt.feature_match_max_dist,
-                             opt.feature_match_test_next_best, pairs.data(), &n, &n_proj),
+    std::vector<double> xy;
+    int n_xy = 0;
+    if (kd_out) xy.resize(2 * (size_t)opt.num_features_per_image);
+    amd::check(vsl_map_track_corners(dev_map, dev_frames, cur_base, T_proj.data(), amd::camera_model_id(cam->name()), cam->data(),
+                                     cam->width(), cam->height(), opt.cam_z_threshold, opt.match_max_dist_2d,
+                                     opt.feature_match_max_dist, opt.feature_match_test_next_best, pairs.data(), &n, &n_proj,
+                                     kd_out ? xy.data() : nullptr, kd_out ? &n_xy : nullptr),
                "vsl_map_track");
     for (int i = 0; i < n; i++) md.matches.emplace_back(pairs[2 * i], table_ids[(size_t)pairs[2 * i + 1]]);
+    if (kd_out) {
+      kd_out->corners.clear();
+      for (int i = 0; i < n_xy; i++) kd_out->corners.emplace_back(xy[2 * i], xy[2 * i + 1]);
+    }
   }
 
   void fused_download_corners(int slot, KeypointsData& kd) {

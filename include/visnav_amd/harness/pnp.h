@@ -262,37 +262,59 @@ inline RansacResult ransac_p3p(const std::vector<Vec3>& f, const std::vector<Vec
 }
 
 // optimize_nonlinear: Gauss-Newton over T <- T * exp(delta) on r_i = normalize(R^T (P_i - t)) - f_i.
+// With q = R^T (P - t), u = q / |q|:  du/dq = (I - u u^T) / |q|,  dq/d(upsilon) = -I,  dq/d(omega) = [q]x, and because
+// u^T [q]x = 0 the rotation block of the Jacobian is simply [u]x.  The normal equations then need only 21 sums per point
+// instead of a dense 3 x 6 Jacobian product (the refinement was 2/3 of the host time of a tracked frame):
+//   H_uu = sum (I - u u^T) / |q|^2,  H_ww = sum (I - u u^T),  H_uw = -[sum u / |q|]x,
+//   g_u = -sum (r - u (u . r)) / |q|,  g_w = sum r x u.
 inline Pose refine_pose(const Pose& T0, const std::vector<Vec3>& f, const std::vector<Vec3>& P, const std::vector<int>& idx,
                         int iterations = 10) {
   Pose T = T0;
   for (int it = 0; it < iterations; it++) {
-    double H[6][6] = {{0}}, g[6] = {0};
+    double huu[6] = {0}, hww[6] = {0}, w[3] = {0}, gu[3] = {0}, gw[3] = {0};  // symmetric 3 x 3 as xx xy xz yy yz zz
+    const Mat3 Rt = transpose(T.R);
     for (int i : idx) {
-      const Vec3 q = transpose(T.R) * (P[i] - T.t);
-      const double nq = norm(q);
-      if (nq < 1e-12) continue;
-      const Vec3 u = (1.0 / nq) * q;
+      const Vec3 q = Rt * (P[i] - T.t);
+      const double n2 = dot(q, q);
+      if (n2 < 1e-24) continue;
+      const double inv = 1.0 / std::sqrt(n2);
+      const Vec3 u = inv * q;
       const Vec3 r = u - f[i];
-      // du/dq = (I - u u^T) / |q|;  dq/d(upsilon) = -I,  dq/d(omega) = [q]x
-      double D[3][3];
-      const double uu[3] = {u.x, u.y, u.z};
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) D[a][b] = ((a == b ? 1.0 : 0.0) - uu[a] * uu[b]) / nq;
-      const Mat3 Q = skew(q);
-      double J[3][6];
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++) {
-          J[a][b] = -D[a][b];
-          J[a][3 + b] = D[a][0] * Q.m[0][b] + D[a][1] * Q.m[1][b] + D[a][2] * Q.m[2][b];
-        }
-      const double rr[3] = {r.x, r.y, r.z};
-      for (int a = 0; a < 6; a++) {
-        for (int b = a; b < 6; b++) H[a][b] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];  // upper triangle
-        g[a] += J[0][a] * rr[0] + J[1][a] * rr[1] + J[2][a] * rr[2];
+      const double a[6] = {1.0 - u.x * u.x, -u.x * u.y, -u.x * u.z, 1.0 - u.y * u.y, -u.y * u.z, 1.0 - u.z * u.z};
+      const double inv2 = inv * inv;
+      for (int k = 0; k < 6; k++) {
+        hww[k] += a[k];
+        huu[k] += a[k] * inv2;
       }
+      w[0] += u.x * inv;
+      w[1] += u.y * inv;
+      w[2] += u.z * inv;
+      const double ur = dot(u, r);
+      gu[0] -= (r.x - u.x * ur) * inv;
+      gu[1] -= (r.y - u.y * ur) * inv;
+      gu[2] -= (r.z - u.z * ur) * inv;
+      gw[0] += r.y * u.z - r.z * u.y;
+      gw[1] += r.z * u.x - r.x * u.z;
+      gw[2] += r.x * u.y - r.y * u.x;
     }
-    for (int a = 0; a < 6; a++)
-      for (int b = 0; b < a; b++) H[a][b] = H[b][a];
+    double H[6][6], g[6];
+    const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        H[a][b] = huu[sym[a][b]];
+        H[3 + a][3 + b] = hww[sym[a][b]];
+      }
+    // H_uw = -[w]x, H_wu = its transpose = [w]x
+    const double wx[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        H[a][3 + b] = -wx[a][b];
+        H[3 + a][b] = wx[a][b];
+      }
+    for (int a = 0; a < 3; a++) {
+      g[a] = gu[a];
+      g[3 + a] = gw[a];
+    }
     // solve H d = -g (Gaussian elimination with partial pivoting; tiny damping for rank safety)
     double M[6][7];
     for (int a = 0; a < 6; a++) {

@@ -273,6 +273,12 @@ int vsl_map_info(const vsl_map* map, int* n_landmarks, int* n_observation_refs, 
 int vsl_map_track(vsl_map* map, vsl_frames* f, int slot, const double* pose7, int cam_model, const double* intr8, int width,
                   int height, double cam_z_threshold, double match_max_dist_2d, int feature_match_threshold,
                   double feature_match_dist_2_best, int32_t* pairs, int* n_pairs, int* n_projected);
+/* The same call, which also hands back the slot's keypoint positions (corners_xy: 2 * max_features doubles, *n_corners)
+ * in the same round trip -- the positions the caller's PnP needs, without a second download. */
+int vsl_map_track_corners(vsl_map* map, vsl_frames* f, int slot, const double* pose7, int cam_model, const double* intr8,
+                          int width, int height, double cam_z_threshold, double match_max_dist_2d, int feature_match_threshold,
+                          double feature_match_dist_2_best, int32_t* pairs, int* n_pairs, int* n_projected, double* corners_xy,
+                          int* n_corners);
 
 /* -------------------------------------------------------- bundle adjustment */
 /*

@@ -228,4 +228,8 @@ int vsl_map_set_landmarks(vsl_map*, int, const double*, const int32_t*, const in
 int vsl_map_track(vsl_map*, vsl_frames*, int, const double*, int, const double*, int, int, double, double, int, double, int32_t*, int*, int*) {
   return VSL_ERR_NO_DEVICE;
 }
+int vsl_map_track_corners(vsl_map*, vsl_frames*, int, const double*, int, const double*, int, int, double, double, int, double, int32_t*,
+                          int*, int*, double*, int*) {
+  return VSL_ERR_NO_DEVICE;
+}
 }  // extern "C"

@@ -1,15 +1,17 @@
 #!/bin/bash
 # Copies the outputs of tools/refresh_profiles.sh (merged back under gpurun_out/refresh/) into profiles/<round>_*.
-#   bash tools/install_profiles.sh r02
+#   bash tools/install_profiles.sh r03
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/refresh
 cp $O/bench_line.json profiles/${R}_bench_line.json
 cp $(ls $O/kt1/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_1stream.csv
 cp $(ls $O/kt2/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_2streams.csv
 cp $(ls $O/lba/*/*_kernel_stats.csv | head -1) profiles/${R}_local_ba_kernel_stats.csv
 cp $(ls $O/gba/*/*_kernel_stats.csv | head -1) profiles/${R}_global_ba_kernel_stats.csv
+cp $(ls $O/bow/*/*_kernel_stats.csv | head -1) profiles/${R}_bow_orb_kernel_stats.csv
+cp $O/${R}_e2e_kernel_stats.json $O/${R}_e2e_kernel_stats.csv profiles/
 python tools/pmc_summary.py $O profiles/${R}_pmc_traffic.json 512
 python tools/sq_summary.py $O profiles/${R}_matcher_sq_counters.json
 python tools/frame_sq_summary.py $O profiles/${R}_frame_sq_counters.json
@@ -17,7 +19,7 @@ python - $R <<'PY'
 import csv, glob, statistics, re, sys
 R = sys.argv[1]
 f = glob.glob('gpurun_out/refresh/kt1/*/*_kernel_trace.csv')[0]
-lines = ["rocprofv3 --kernel-trace of `python3 bench.py --streams 1 --batch 512 --passes 18 --steps 20 --warmup 5 --cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0` (tools/refresh_profiles.sh):",
+lines = ["rocprofv3 --kernel-trace of `python3 bench.py --streams 1 --batch 512 --passes 18 --steps 20 --warmup 5 --cpu-frames 0 --no-ba --no-gba --no-e2e --no-bow --stream-seconds 0` (tools/refresh_profiles.sh):",
          "per-launch kernel durations in microseconds, 512 stereo frames = 1024 images per launch; the HIP events of bench.py cover the LAST 5 passes."]
 d = {}
 for r in csv.DictReader(open(f)):

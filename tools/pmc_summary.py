@@ -21,7 +21,7 @@ STAGES = {  # stage -> (kernel, read width calibration, write width calibration)
     "describe": ("describe_tile_kernel", "calib_read_b32", "calib_write_b64"),  # launches of >= 96 images (describe_fast_kernel below that)
     "describe_bin": ("describe_bin_kernel", "calib_read_b32", "calib_write_b64"),
     "describe_exact": ("exact_bits_kernel", "calib_read_b32", "calib_write_b64"),
-    "match": ("hamming_mx_kernel", "calib_read_b32", "calib_write_b64"),
+    "match": ("hamming_mx_kernel", "calib_read_b32", "calib_write_b64", 2),  # forward + reverse pass = one match launch (round 3)
     "match_finalize": ("match_finalize_kernel", "calib_read_b32", "calib_write_b64"),
 }
 CALIB_BYTES = 1 << 30
@@ -50,14 +50,18 @@ def main():
         factors["calib_write_b64"] = CALIB_BYTES / (sum(d.values()) / len(d) * 1024)
     acc = collect(root / "pmc")
     kernels = {}
-    for stage, (kern, rcal, wcal) in STAGES.items():
+    for stage, spec in STAGES.items():
+        kern, rcal, wcal = spec[:3]
+        per_launch = spec[3] if len(spec) > 3 else 1   # dispatches of this kernel that make up one launch of the stage
         ent = {"kernel": kern}
+        if per_launch > 1:
+            ent["dispatches_per_launch"] = per_launch
         tot = corrected = 0.0
         for ctr, calname in (("FETCH_SIZE", rcal), ("WRITE_SIZE", wcal)):
             d = acc.get((kern, ctr))
             if not d:
                 continue
-            mean = sum(d.values()) / len(d)
+            mean = per_launch * sum(d.values()) / len(d)
             ent[f"{ctr}_KiB"] = round(mean, 1)
             ent[f"{ctr}_dispatches"] = len(d)
             ent[f"{ctr}_factor"] = round(factors.get(calname, 1.0), 4)

@@ -1,19 +1,19 @@
 #!/bin/bash
 # Regenerates the measurements behind profiles/<round>_*: run ON the GPU box from the repo root
-#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh r02'
-# then `bash tools/install_profiles.sh r02` here (tools/README.md).  Counters are collected in their own passes,
+#   gpurun --timeout 1190 -- 'bash tools/refresh_profiles.sh r03'
+# then `bash tools/install_profiles.sh r03` here (tools/README.md).  Counters are collected in their own passes,
 # never together with tracing (MI355X_MICROARCH.md, rocprofv3 PMC slots).  The HBM-traffic passes come first and their
 # summary is written into the box's profiles/ before the plain bench run, so the committed bench line carries the
 # roofline.traffic of the SAME build.
 set -e
 R=$PWD
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 O=$R/gpurun_out/refresh
 rm -rf $O && mkdir -p $O  # (clear the LOCAL gpurun_out/refresh too before a new run: gpurun merges, it does not delete)
 cd /tmp && export TMPDIR=/tmp
-LITE="--cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0 --gen-workers 1"
+LITE="--cpu-frames 0 --no-ba --no-gba --no-e2e --no-bow --stream-seconds 0 --gen-workers 1"
 # (no forked generator workers under the profiler: the frames are generated once here and cached under /tmp)
-python3 $R/bench.py --streams 1 --batch 512 --passes 1 --steps 1 --warmup 0 --cpu-frames 0 --no-ba --no-gba --no-e2e --stream-seconds 0 > /dev/null 2>&1
+python3 $R/bench.py --streams 1 --batch 512 --passes 1 --steps 1 --warmup 0 --cpu-frames 0 --no-ba --no-gba --no-e2e --no-bow --stream-seconds 0 > /dev/null 2>&1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, plus the calibration of both counters on known byte counts
 PMCARGS="--streams 1 --batch 512 --passes 1 --steps 3 --warmup 1 --profile-steps 1 $LITE"
 echo "bench.py $PMCARGS" > $O/pmc_command.txt
@@ -22,7 +22,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc/write -- python3 $R/ben
 echo calib; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib/fetch -- $R/tools/probes/pmc_calib > $O/calib_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/calib/write -- $R/tools/probes/pmc_calib > $O/calib_w.log 2>&1
 python3 $R/tools/pmc_summary.py $O $R/profiles/${ROUND}_pmc_traffic.json 512 > $O/pmc_summary.log 2>&1
+# single-stream device accounting of the end-to-end leg (kernel launches and kernel time per frame); its summary goes
+# into the box's profiles/ as well, so that the bench line's device_accounting block is this build's
+echo e2e; (cd $R && bash tools/e2e_profile.sh $ROUND > $O/e2e_profile.log 2>&1; cp gpurun_out/${ROUND}_e2e_kernel_stats.json gpurun_out/${ROUND}_e2e_kernel_stats.csv profiles/ 2>/dev/null; cp gpurun_out/${ROUND}_e2e_kernel_stats.json gpurun_out/${ROUND}_e2e_kernel_stats.csv $O/)
+cd /tmp
 echo bench; (cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench.err)
+# BoW (K8 / K9) and the ORB front end: kernel durations on the k = 10 / L = 6 vocabulary
+echo bow; rocprofv3 --kernel-trace --stats --output-format csv -d $O/bow -- python3 $R/tools/bow_probe.py --no-oracle > $O/bow.log 2>&1
 # kernel durations: one stream (the isolated durations the roofline uses) and the default two-stream run
 # (as long as the default run -- 18 passes x 20 steps after 5 warm-up steps -- so that the trace sees the sustained clocks the bench line's stage times see)
 echo kt1; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --streams 1 --batch 512 --passes 18 --steps 20 --warmup 5 $LITE > $O/kt1.log 2>&1

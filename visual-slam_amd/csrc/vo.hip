@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restr
                                                            const int32_t* __restrict__ n_kp_dev, int result_cap,
                                                            const int32_t* __restrict__ n_proj_dev,
                                                            int32_t* __restrict__ mail_hdr,
-                                                           const int32_t* __restrict__ tie_count_dev) {
+                                                           const int32_t* __restrict__ tie_count_dev,
+                                                           int32_t* __restrict__ mail_xy) {
   // Device-resident callers (vsl_map_track) pass the keypoints of a frame store slot (int32 positions,
   // count on the device), the number of projected landmarks on the device, and observation descriptors
   // through an index into the map's descriptor pool; the host-buffer entry point passes none of them.
@@ -219,6 +220,10 @@ __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restr
   }
   const double kx = kp_xy_i32 ? (double)kp_xy_i32[2 * (size_t)k] : kp_xy[2 * (size_t)k];
   const double ky = kp_xy_i32 ? (double)kp_xy_i32[2 * (size_t)k + 1] : kp_xy[2 * (size_t)k + 1];
+  if (mail_xy && lane == 0 && kp_xy_i32) {  // the keypoint's position rides along (the host needs it for PnP)
+    mail_xy[2 * (size_t)k] = kp_xy_i32[2 * (size_t)k];
+    mail_xy[2 * (size_t)k + 1] = kp_xy_i32[2 * (size_t)k + 1];
+  }
   uint32_t d[8];
   {
     const uint32_t* p = (const uint32_t*)(kp_desc + 4 * (size_t)k);
@@ -404,7 +409,7 @@ extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, con
   hipLaunchKernelGGL(find_matches_kernel, dim3((n_kp + 3) / 4), dim3(256), 0, ctx->stream, dkxy, dkd, n_kp, dpuv, dplm, n_proj,
                      dstart, dod, match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, dres,
                      (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, n_kp, (const int32_t*)nullptr,
-                     (int32_t*)nullptr, (const int32_t*)nullptr);
+                     (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr);
   hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, dres, n_kp, dpairs, dn);
   VSL_CHECK_LAUNCH(ctx);
   void* hp = nullptr;
@@ -620,16 +625,32 @@ extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* 
                              int width, int height, double cam_z_threshold, double match_max_dist_2d,
                              int feature_match_threshold, double feature_match_dist_2_best, int32_t* pairs, int* n_pairs,
                              int* n_projected) {
+  return vsl_map_track_corners(m, f, slot, pose7, cam_model, intr8, width, height, cam_z_threshold, match_max_dist_2d,
+                               feature_match_threshold, feature_match_dist_2_best, pairs, n_pairs, n_projected, nullptr, nullptr);
+}
+
+// vsl_map_track + the slot's keypoint positions (corners_xy[2 * max_features], *n_corners) in the same round trip:
+// what the host needs for PnP without a second download.
+extern "C" int vsl_map_track_corners(vsl_map* m, vsl_frames* f, int slot, const double* pose7, int cam_model, const double* intr8,
+                                     int width, int height, double cam_z_threshold, double match_max_dist_2d,
+                                     int feature_match_threshold, double feature_match_dist_2_best, int32_t* pairs,
+                                     int* n_pairs, int* n_projected, double* corners_xy, int* n_corners) {
   if (!m || !f || !pose7 || !intr8 || !n_pairs || slot < 0 || slot >= f->max_images || cam_model < 0 || cam_model > 3)
     return VSL_ERR_INVALID;
   vsl_ctx* ctx = m->ctx;
   *n_pairs = 0;
   if (n_projected) *n_projected = 0;
+  if (n_corners) *n_corners = 0;
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   int rc = map_reserve_kp(m, f->F);
   if (rc) return rc;
   const int n = m->n_lms;
-  if (n == 0) return vsl_resolve_ties(ctx, f, nullptr);
+  if (n == 0) {
+    if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;
+    if (corners_xy && n_corners)
+      return vsl_frames_download_keypoints(ctx, f, slot, f->F, corners_xy, nullptr, nullptr, n_corners);
+    return VSL_OK;
+  }
   // Two launches and one synchronisation per call (round 3; it was a tie-guard round trip, a pose upload, four kernels,
   // a memset and two copies): the pose travels as a kernel argument, projection + ordered compaction are one kernel,
   // the matching kernel writes its per-keypoint results, the projected count and the frame store's near-tie count
@@ -646,13 +667,13 @@ extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* 
     m->chain_cap = cap;
     m->epoch = 0;
   }
-  if (f->F + 4 > m->mailbox_cap) {
+  if (3 * f->F + 4 > m->mailbox_cap) {
     VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (m->mailbox) (void)hipHostFree(m->mailbox);
     m->mailbox = nullptr;
     m->mailbox_cap = 0;
-    VSL_HIP(ctx, hipHostMalloc((void**)&m->mailbox, 4 * ((size_t)f->F + 4), hipHostMallocMapped | hipHostMallocCoherent));
-    m->mailbox_cap = f->F + 4;
+    VSL_HIP(ctx, hipHostMalloc((void**)&m->mailbox, 4 * (3 * (size_t)f->F + 4), hipHostMallocMapped | hipHostMallocCoherent));
+    m->mailbox_cap = 3 * f->F + 4;
   }
   PoseIntr pi;
   for (int i = 0; i < 7; i++) pi.v[i] = pose7[i];
@@ -670,7 +691,7 @@ extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* 
                        f->kp_desc + 4 * (size_t)slot * f->F, f->F, m->out_uv, m->out_idx, n, m->obs_start, m->pool,
                        match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, mail + 4,
                        f->kp_xy + 2 * (size_t)slot * f->F, m->obs_index, f->kp_count + slot, f->F, m->counters, mail,
-                       f->ties_pending ? f->tie_count : (const int32_t*)nullptr);
+                       f->ties_pending ? f->tie_count : (const int32_t*)nullptr, corners_xy ? mail + 4 + f->F : (int32_t*)nullptr);
     VSL_CHECK_LAUNCH(ctx);
     VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // The descriptors of the slot must be final (rBRIEF near-tie guard, describe.hip).  The guard's count came along
@@ -694,5 +715,11 @@ extern "C" int vsl_map_track(vsl_map* m, vsl_frames* f, int slot, const double* 
       np++;
     }
   *n_pairs = np;
+  if (corners_xy && n_corners) {
+    const int nk = mail[2] < f->F ? mail[2] : f->F;
+    const int32_t* xy = mail + 4 + f->F;
+    for (int k = 0; k < 2 * nk; k++) corners_xy[k] = (double)xy[k];
+    *n_corners = nk;
+  }
   return VSL_OK;
 }
