@@ -192,11 +192,18 @@ inline double bearing_score(const Pose& T_w_c, const Vec3& f, const Vec3& P) {
   return 1.0 - dot(f, normalized(q));
 }
 
+// 1 - f . q / |q| < threshold  <=>  f . q > (1 - threshold) |q|: compared in squared form (no square root or division
+// per point; RANSAC calls this for every correspondence on every iteration).  threshold < 1 (a few pixels).
 inline void select_within(const Pose& T, const std::vector<Vec3>& f, const std::vector<Vec3>& P, double threshold,
                           std::vector<int>& inliers) {
   inliers.clear();
-  for (size_t i = 0; i < f.size(); i++)
-    if (bearing_score(T, f[i], P[i]) < threshold) inliers.push_back((int)i);
+  const Mat3 Rt = transpose(T.R);
+  const double c = 1.0 - threshold, c2 = c * c;
+  for (size_t i = 0; i < f.size(); i++) {
+    const Vec3 q = Rt * (P[i] - T.t);
+    const double d = dot(f[i], q);
+    if (d > 0.0 && d * d > c2 * dot(q, q)) inliers.push_back((int)i);
+  }
 }
 
 struct RansacResult {

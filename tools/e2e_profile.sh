@@ -4,20 +4,20 @@
 #   bash tools/e2e_profile.sh <round tag, e.g. r03> [n_frames step radius]
 # writes gpurun_out/<tag>_e2e_kernel_stats.{csv,json}; copy them to profiles/ (tools/install_profiles.sh).
 R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; N=${2:-640}; STEP=${3:-0.03}; RAD=${4:-2.674}
-D=/tmp/vsl_lap_${N}_${STEP}_${RAD}
+LOOK=${LOOK:-90}
+D=/tmp/vsl_lap_${N}_${STEP}_${RAD}_${LOOK}
 V=/tmp/vsl_voc_k10L6_s7.txt
 if [ ! -f $D/calib.json ] || [ ! -f $V ]; then
 python3 - <<PY
 import sys, importlib, os; sys.path.insert(0, "$R"); import __graft_entry__ as e; e.load_package()
 sq = importlib.import_module('visual_slam_amd.synth_sequence'); s = importlib.import_module('visual_slam_amd.synth')
 if not os.path.exists("$D/calib.json"):
-    sq.render_sequence("$D", n_frames=$N, seed=1, step_m=$STEP, radius=$RAD, workers=min(16, os.cpu_count()))
+    sq.render_sequence("$D", n_frames=$N, seed=1, step_m=$STEP, radius=$RAD, workers=min(16, os.cpu_count()), look_deg=$LOOK)
 if not os.path.exists("$V"):
     s.write_vocabulary_text("$V", 10, 6, *s.vocabulary_arrays(7, 10, 6))
 PY
 fi
-LAP=$(python3 -c "import math; print(max(int(round(2*math.pi*$RAD/$STEP))-20,1))")
-FLAGS="--dataset-path $D --cam-calib $D/calib.json --voc-path $V --relocalization --loop-closure --force-loop $LAP:0 --fused"
+FLAGS="--dataset-path $D --cam-calib $D/calib.json --voc-path $V --relocalization --loop-closure --fused"
 OUT=$R/gpurun_out/${TAG}_e2e_kt
 rm -rf $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -195,15 +195,17 @@ class BoxRoom:
         return np.clip(np.rint(out), 0, 255).astype(np.uint8).reshape(bearings.shape[:2])
 
 
-def trajectory(n_frames, step_m=0.03, radius=1.2):
+def trajectory(n_frames, step_m=0.03, radius=1.2, look_deg=0.0):
     """Body (= cam0) poses T_w_i: a circle in the x-z plane (y is down), looking along the tangent with a
-    slow pitch oscillation; ~3 cm and ~1.4 degrees per frame."""
+    slow pitch oscillation; ~3 cm and ~1.4 degrees per frame.  look_deg turns the viewing direction about the
+    vertical axis relative to the tangent (+90: radially outwards, towards the nearest wall -- close,
+    well-conditioned structure for an 11 cm stereo baseline; 0: along the path, structure 4-7 m away)."""
     poses = []
     for k in range(n_frames):
         th = k * step_m / radius
         c = np.array([radius * np.cos(th), 0.15 * np.sin(2.3 * th), radius * np.sin(th)])
         # forward = tangent direction (-sin, 0, cos): yaw such that z_cam maps to it
-        yaw = np.arctan2(-np.sin(th), np.cos(th))
+        yaw = np.arctan2(-np.sin(th), np.cos(th)) + np.deg2rad(look_deg)
         R = rot_y(yaw) @ rot_x(0.06 * np.sin(1.7 * th))
         poses.append((R, c))
     return poses
@@ -224,13 +226,13 @@ def _render_frame(k):
 
 
 def render_sequence(out_dir, n_frames=60, seed=1, t0_ns=1403715273262142976, dt_ns=50_000_000, png_level=1,
-                    step_m=0.03, radius=1.2, workers=1):
+                    step_m=0.03, radius=1.2, workers=1, look_deg=0.0):
     """Writes <out_dir>/{cam0,cam1}/data.csv + data/*.png, state_groundtruth_estimate0/data.csv and
     <out_dir>/calib.json.  Returns the list of body poses (R_wi, t_wi).  The path is a circle: more than
     2 pi radius / step_m frames revisit the start (loop closure).  workers > 1 renders frames in forked
     processes (call before anything touches the GPU)."""
     room = BoxRoom(seed)
-    poses = trajectory(n_frames, step_m=step_m, radius=radius)
+    poses = trajectory(n_frames, step_m=step_m, radius=radius, look_deg=look_deg)
     bear = [ds_unproject_grid(CALIB["intrinsics"][c]) for c in range(2)]
     T_i_c = []
     for c in range(2):
@@ -254,7 +256,7 @@ def render_sequence(out_dir, n_frames=60, seed=1, t0_ns=1403715273262142976, dt_
         for k in range(n_frames):
             _render_frame(k)
     # ground truth at 4x the frame rate (positions interpolated on the same parametrisation), EuRoC columns
-    fine = trajectory(4 * (n_frames - 1) + 1, step_m=step_m / 4, radius=radius)
+    fine = trajectory(4 * (n_frames - 1) + 1, step_m=step_m / 4, radius=radius, look_deg=look_deg)
     with open(os.path.join(out_dir, "state_groundtruth_estimate0", "data.csv"), "w", newline="") as f:
         f.write("#timestamp, p_RS_R_x [m], p_RS_R_y [m], p_RS_R_z [m], q_RS_w [], q_RS_x [], q_RS_y [], q_RS_z [], "
                 "v_RS_R_x, v_RS_R_y, v_RS_R_z, b_w_x, b_w_y, b_w_z, b_a_x, b_a_y, b_a_z\r\n")
