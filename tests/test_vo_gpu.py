@@ -161,6 +161,38 @@ def test_map_track_equals_host_buffer_path(vsl, ctx, synth, seed, n_lms):
     # tracking twice gives the same answer (scratch state is per call)
     got2, _ = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
     assert np.array_equal(got2, exp)
+    # ... and the keypoint positions can ride along in the same round trip (vsl_map_track_corners)
+    got3, n_proj3, xy3 = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2, with_corners=True)
+    assert np.array_equal(got3, exp) and n_proj3 == n_proj and np.array_equal(xy3, fr.keypoints(0)[0])
+    m.close()
+    fr.close()
+
+
+def test_map_track_resolves_pending_ties_and_large_maps(vsl, ctx, orc, synth):
+    # (1) the rBRIEF near-tie guard rides along with the track results: with the guard band widened so that ties ARE
+    # pending, the call must patch the descriptors (host libm) and match once more -- same matches as with the ties
+    # resolved up front; (2) a map of > 1024 landmarks spans several workgroups of the projection kernel: the stream-scan
+    # compaction must keep the landmark order (40,000 landmarks = 40 chained workgroups), call after call (the chain
+    # words are epoch-tagged, never reset)
+    fr, kp_xy, kp_desc, pose, points, start, pool = _frame_and_map_inputs(vsl, ctx, synth, 6, 40000)
+    model, intr = 1, INTR[1]
+    m = vsl.Map(ctx)
+    m.append_descriptors(pool)
+    m.set_landmarks(points, start, np.arange(len(pool), dtype=np.int32))
+    uv, idx = ctx.project_landmarks(pose, model, intr, 752, 480, points, 0.1)
+    exp = ctx.find_matches_landmarks(kp_xy, kp_desc, uv, idx, start, pool, 20.0, 70, 1.2)
+    for _ in range(3):
+        got, n_proj = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
+        assert n_proj == len(uv) and np.array_equal(got, exp)
+    left = synth.stereo_pair(6)[0]
+    ctx.set_tie_eps(1e-3)   # ~1e-3 of the samples become "near ties": pending when track is called
+    try:
+        fr.detect_describe(0, 1, 1500, True)
+        got, _ = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
+    finally:
+        ctx.set_tie_eps(1e-12)
+    assert np.array_equal(fr.keypoints(0)[2], orc.detect_describe(left, 1500, True)[2])   # the ties were resolved
+    assert np.array_equal(got, exp)
     m.close()
     fr.close()
 

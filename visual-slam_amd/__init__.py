@@ -747,13 +747,24 @@ class Map:
         return a.value, b.value, c.value
 
     def track(self, frames, slot, pose7, model, intr8, width, height, cam_z_threshold=0.1, max_dist_2d=20.0, threshold=70,
-              dist_2_best=1.2):
+              dist_2_best=1.2, with_corners=False):
+        """project_landmarks + find_matches_landmarks against the frame store slot: (pairs, n_projected); with_corners:
+        also the slot's keypoint positions from the same round trip (vsl_map_track_corners)."""
         pose7 = np.ascontiguousarray(pose7, np.float64)
         intr8 = np.ascontiguousarray(intr8, np.float64)
         pairs = np.zeros((frames.F, 2), np.int32)
         n, npj = C.c_int32(), C.c_int32()
-        self.ctx._ck(self.ctx.L.vsl_map_track(self.h, frames.h, int(slot), pose7.ctypes.data_as(f64p), int(model),
-                                              intr8.ctypes.data_as(f64p), int(width), int(height), C.c_double(cam_z_threshold),
-                                              C.c_double(max_dist_2d), int(threshold), C.c_double(dist_2_best),
-                                              pairs.ctypes.data_as(i32p), C.byref(n), C.byref(npj)))
-        return pairs[:n.value].copy(), npj.value
+        if not with_corners:
+            self.ctx._ck(self.ctx.L.vsl_map_track(self.h, frames.h, int(slot), pose7.ctypes.data_as(f64p), int(model),
+                                                  intr8.ctypes.data_as(f64p), int(width), int(height), C.c_double(cam_z_threshold),
+                                                  C.c_double(max_dist_2d), int(threshold), C.c_double(dist_2_best),
+                                                  pairs.ctypes.data_as(i32p), C.byref(n), C.byref(npj)))
+            return pairs[:n.value].copy(), npj.value
+        xy = np.zeros((frames.F, 2), np.float64)
+        nk = C.c_int32()
+        self.ctx._ck(self.ctx.L.vsl_map_track_corners(self.h, frames.h, int(slot), pose7.ctypes.data_as(f64p), int(model),
+                                                      intr8.ctypes.data_as(f64p), int(width), int(height),
+                                                      C.c_double(cam_z_threshold), C.c_double(max_dist_2d), int(threshold),
+                                                      C.c_double(dist_2_best), pairs.ctypes.data_as(i32p), C.byref(n),
+                                                      C.byref(npj), xy.ctypes.data_as(f64p), C.byref(nk)))
+        return pairs[:n.value].copy(), npj.value, xy[:nk.value].copy()
