@@ -300,6 +300,10 @@ class Odometry {
     }
     n_tracking_lost++;
     const Sophus::SE3d tracking_result = md.T_w_c;
+    if (opt.fused_tracking && orb_voc) {  // lazily: this frame's descriptors for relocalize_camera's matching
+      KeypointsData& kd = feature_corners[fcidl];
+      if (kd.corner_descriptors.size() != kd.corners.size()) fused_download_corners(cur_base, kd);
+    }
     ImageRef l(img_left);
     if (orb_voc && relocalize_camera(fcidl, l.img, calib_cam, graph, orb_voc, orb_db, cameras, vel, current_pose, feature_corners,
                                      landmarks, opt.motion_threshold, opt.reprojection_error_pnp_inlier_threshold_pixel, md, rng)) {
@@ -452,11 +456,10 @@ class Odometry {
       }
       auto t2 = Clk::now();
       if (opt.fused_tracking) {
-        // relocalisation / loop closure match keyframe descriptors on the host on demand: then the descriptors are
-        // downloaded too; otherwise the positions ride along with the matches (one round trip per tracked frame)
-        const bool with_desc = opt.enable_relocalization || opt.enable_loop_closure;
-        fused_track(md, with_desc ? nullptr : &kdl);
-        if (with_desc) fused_download_corners(cur_base, kdl);
+        // the positions ride along with the matches (one round trip per tracked frame).  The DESCRIPTORS of a frame that
+        // is not a keyframe are needed on the host only when tracking is lost and relocalize_camera matches them against
+        // keyframes (tracking.h:283): they are fetched then (localize()), not on every frame
+        fused_track(md, &kdl);
         fused_prefetch(next_left);
         feature_corners[fcidl] = kdl;
       } else {
