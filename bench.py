@@ -771,6 +771,7 @@ def main():
                     "operator_sequence": run(exe, default_flags + ["--traj", d + "/gpu_ops.csv"], 1),
                     "device_resident": run(exe, default_flags + ["--fused", "--traj", d + "/gpu.csv"], 2),
                     "device_resident_4_streams": run(exe, default_flags + ["--fused", "--replicas", "4"], 1),
+                    "device_resident_16_streams": run(exe, default_flags + ["--fused", "--replicas", "16"], 1),
                     "cpu_oracle": run(cpu_exe, default_flags + ["--traj", d + "/cpu.csv"], 1),
                     "stages_open_loop": run(exe, ["--voc-path", voc_path, "--inject-drift", "300:0.5,0,0.3", "--fused"], 1),  # loop closure off
                     "stages_device_resident": run(exe, stage_flags + ["--fused"], 1),
@@ -806,6 +807,11 @@ def main():
                     "stage_ms_total": e["stage_ms_total"],
                     "frames_per_s_operator_by_operator": runs["operator_sequence"].get("frames_per_s"),
                     "frames_per_s_4_independent_streams_one_gpu": runs["device_resident_4_streams"].get("frames_per_s"),
+                    # BASELINE configs[3] in miniature: independent streams (one host thread, context, frame store and map
+                    # each) sharing ONE GPU; every stream reproduces the same trajectory bit for bit (streams_agree)
+                    "frames_per_s_16_independent_streams_one_gpu": runs["device_resident_16_streams"].get("frames_per_s"),
+                    "independent_streams_agree": bool(runs["device_resident_4_streams"].get("streams_agree")) and
+                                                 bool(runs["device_resident_16_streams"].get("streams_agree")),
                     "operator_path_and_device_resident_path_same_trajectory_file": same_traj,
                     "sequence_render_s": round(t_render, 1)}
                 out["end_to_end_single_stream"]["device_accounting"] = device_accounting(e)
