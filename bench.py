@@ -180,7 +180,9 @@ def write_orb_shaped_vocabulary(synth, path):
     """k = 10, L = 6 (1,111,111 nodes, 1,000,000 words): the SHAPE of ORBvoc.txt, which the reference loads
     (TemplatedVocabulary.h:1338-1424) and which is a missing blob in its tree; the tree itself is synthetic."""
     if not os.path.exists(path):
-        synth.write_vocabulary_text(path, 10, 6, *synth.vocabulary_arrays(7, 10, 6))
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        synth.write_vocabulary_text(tmp, 10, 6, *synth.vocabulary_arrays(7, 10, 6))
+        os.replace(tmp, path)   # atomically: a half-written file is never picked up by a later run
     return path
 
 
@@ -715,7 +717,10 @@ def main():
         # ---- BoW (K8 / K9) at the reference's vocabulary shape; the vocabulary file also serves the end-to-end legs
         voc_path = None
         if (args.bow or args.e2e) and world == 1:
-            voc_path = write_orb_shaped_vocabulary(synth, "/tmp/vsl_voc_k10L6_s7.txt")
+            import hashlib
+            # (the name carries a hash of the generator's source: a file written by an older synth.py is not reused)
+            voc_path = write_orb_shaped_vocabulary(synth, "/tmp/vsl_voc_k10L6_s7_%s.txt" % hashlib.sha256(
+                (ROOT / "visual-slam_amd" / "synth.py").read_bytes()).hexdigest()[:12])
         if args.bow and world == 1:
             out["bow"] = bow_measurement(vsl, ctx, synth, ring, voc_path, entry.load_oracle() if args.cpu_frames > 0 else None)
 
