@@ -57,6 +57,12 @@ struct OdometryOptions {  // defaults = the pangolin::Var defaults of src/slam.c
   int ba_max_iterations = 20;
   int ba_verbose = 0;
   bool async_ba = false;  // true: optimize() runs in its own thread like the reference (result depends on timing)
+  // async_ba with a DETERMINISTIC hand-over: the optimised window is merged back exactly this many frames after the
+  // keyframe that started it (the main thread waits there if the worker is not done), and no keyframe is taken while a
+  // result is outstanding -- the reference's rule (!opt_running && !opt_finished, src/slam.cpp:1374-1377) with the
+  // timing taken out.  1 = the hand-over of the synchronous mode (merge at the end of the next frame: identical
+  // trajectories); larger values hide the optimisation under the tracking of the following frames.  0 = off.
+  int ba_merge_after = 0;
   // true: the per-frame device work goes through the device-resident frame store + map (include/vslam_hip.h
   // "device-resident map"): the image is uploaded once, keypoints and descriptors stay in HBM, landmark
   // projection + guided matching is ONE call, stereo matching runs slot against slot, and keyframe
@@ -470,8 +476,14 @@ class Odometry {
       auto t3 = Clk::now();
       localize(fcidl, img_left, kdl, md);
       auto t4 = Clk::now();
-      if ((int)md.inliers.size() < opt.new_kf_min_inliers && !opt_running && !opt_finished) take_keyframe = true;
-      if (!opt_running && opt_finished) merge_optimized();
+      if (opt.async_ba && opt.ba_merge_after > 0) {  // deterministic hand-over
+        if (ba_pending) ba_age++;
+        if ((int)md.inliers.size() < opt.new_kf_min_inliers && !ba_pending) take_keyframe = true;
+        if (ba_pending && ba_age >= opt.ba_merge_after) merge_optimized();  // waits for the worker
+      } else {
+        if ((int)md.inliers.size() < opt.new_kf_min_inliers && !opt_running && !opt_finished) take_keyframe = true;
+        if (!opt_running && opt_finished) merge_optimized();
+      }
       auto t5 = Clk::now();
       clock.project_match_ms += ms(t0, t1) + ms(t2, t3);
       clock.detect_ms += ms(t1, t2);
@@ -494,7 +506,7 @@ class Odometry {
   // Wait for a running optimisation and merge it (end of sequence).
   void finish() {
     wait_worker();
-    if (opt_finished) merge_optimized();
+    if (opt_finished || ba_pending) merge_optimized();
   }
 
   // src/slam.cpp:1712-1722: keyframe positions of the left camera in the body frame vs ground truth
@@ -519,6 +531,8 @@ class Odometry {
   Corners corners_opt;  // keypoint positions of the active cameras, private to the optimisation thread
   Calibration calib_cam_opt;
   std::atomic<bool> opt_running{false}, opt_finished{false};
+  bool ba_pending = false;  // main thread only: an optimisation was started and its result is not merged yet
+  int ba_age = 0;           // frames since it was started
   // the reference starts a new std::thread per optimisation (src/slam.cpp:1557); here ONE worker thread lives as
   // long as the object, so its thread-local vsl_ctx (stream, scratch, code objects) is created once
   std::unique_ptr<std::thread> opt_thread;
@@ -572,14 +586,29 @@ class Odometry {
 
   // src/slam.cpp:1510-1571
   void optimize() {
+    if (opt.async_ba) {  // a forced keyframe (tracking lost, a test hook) may arrive while a result is outstanding:
+      wait_worker();     // the worker owns cameras_opt / landmarks_opt until it is done
+      if (opt_finished || ba_pending) merge_optimized();
+    }
     cameras_opt.clear();
     landmarks_opt.clear();
     corners_opt.clear();
+    // The snapshot the optimisation works on (src/slam.cpp:1511-1553 copies whole Camera / Landmark objects).  Only
+    // what bundle_adjustment reads and merge_optimized writes back is copied here -- the pose, the position, the
+    // window's observations: a Landmark's all_obs map and a Camera's map_points / BoW / covisibility members cost a
+    // millisecond of node allocations per keyframe and are never touched by the optimisation.
     for (const auto& kv : landmarks)
-      if (kv.second.active) landmarks_opt.emplace(kv.first, kv.second);
+      if (kv.second.active) {
+        Landmark& l = landmarks_opt[kv.first];
+        l.p = kv.second.p;
+        l.obs = kv.second.obs;
+        l.active = true;
+      }
     for (const auto& kv : cameras)
       if (kv.second.active) {
-        cameras_opt.emplace(kv.first, kv.second);
+        Camera& c = cameras_opt[kv.first];
+        c.T_w_c = kv.second.T_w_c;
+        c.active = true;
         KeypointsData kd;
         kd.corners = feature_corners.at(kv.first).corners;
         corners_opt[kv.first] = kd;
@@ -593,6 +622,8 @@ class Odometry {
     ba_options.verbosity_level = opt.ba_verbose;
     calib_cam_opt = calib_cam;
     opt_running = true;
+    ba_pending = true;
+    ba_age = 0;
     clock.ba_runs++;
     auto work = [this, fid, ba_options] {
       const std::set<FrameCamId> fixed_cameras = {FrameCamId(fid, 0), FrameCamId(fid, 1)};
@@ -617,17 +648,18 @@ class Odometry {
     wait_worker();
     for (const auto& kv : landmarks_opt) {
       Landmark& lm = landmarks.at(kv.first);
-      lm = kv.second;
+      lm.p = kv.second.p;  // the one member the optimisation changes (the reference assigns the whole copy back)
       lm.modified = true;
       const Camera& from = cameras_opt.count(lm.from_fcid) ? cameras_opt.at(lm.from_fcid) : cameras.at(lm.from_fcid);
       lm.p_c = to_eigen(inverse(to_pose(from.T_w_c)) * to_vec3(lm.p));
     }
     for (const auto& kv : cameras_opt) {
-      cameras.at(kv.first) = kv.second;
+      cameras.at(kv.first).T_w_c = kv.second.T_w_c;
       cameras.at(kv.first).modified = true;
     }
     calib_cam = calib_cam_opt;
     opt_finished = false;
+    ba_pending = false;
     map_dirty = true;  // landmark positions moved
   }
 

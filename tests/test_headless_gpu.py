@@ -73,6 +73,23 @@ def test_headless_pipeline_reference_defaults_and_asynchronous_ba(sequence):
     assert out["ate_rmse_m"] < 0.02, out
 
 
+def test_bundle_adjustment_in_its_own_thread_with_a_deterministic_hand_over(sequence, tmp_path):
+    # --async-ba --ba-merge-after N: optimize() runs in the worker thread (the reference's opt_thread, src/slam.cpp:1557)
+    # and its result is merged exactly N frames after the keyframe.  N = 1 is the hand-over of the synchronous mode:
+    # byte-identical trajectories.  N = 8 hides the optimisation under the tracking of the next frames: deterministic
+    # (two runs agree byte for byte, operator path == device-resident path) and as accurate.
+    seq_dir, _ = sequence
+    t_sync, t_a1, t_a8, t_a8b, t_a8f = (tmp_path / n for n in ("sync.csv", "a1.csv", "a8.csv", "a8b.csv", "a8f.csv"))
+    s = _run(seq_dir, "--kf-min-inliers", "500", "--traj", str(t_sync))
+    a1 = _run(seq_dir, "--kf-min-inliers", "500", "--async-ba", "--ba-merge-after", "1", "--traj", str(t_a1))
+    assert a1["async_ba"] is True and t_a1.read_bytes() == t_sync.read_bytes()
+    a8 = _run(seq_dir, "--kf-min-inliers", "500", "--async-ba", "--ba-merge-after", "8", "--traj", str(t_a8))
+    _run(seq_dir, "--kf-min-inliers", "500", "--async-ba", "--ba-merge-after", "8", "--traj", str(t_a8b))
+    _run(seq_dir, "--kf-min-inliers", "500", "--async-ba", "--ba-merge-after", "8", "--fused", "--traj", str(t_a8f))
+    assert t_a8.read_bytes() == t_a8b.read_bytes() == t_a8f.read_bytes()
+    assert a8["keyframes"] >= 2 and a8["ate_rmse_m"] < 0.02 and abs(a8["ate_rmse_m"] - s["ate_rmse_m"]) < 0.01
+
+
 def test_headless_pipeline_computes_bow_vectors_per_keyframe(sequence, tmp_path, synth):
     # --voc-path like the reference binary: every keyframe goes through compute_bow_vector (ORB front end +
     # vocabulary transform, keypoints.h:243-254 / src/slam.cpp:1206-1208); the odometry itself is unaffected

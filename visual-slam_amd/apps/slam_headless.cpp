@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     else if (a == "--traj") traj_path = need("--traj");
     else if (a == "--voc-path") voc_path = need("--voc-path");
     else if (a == "--async-ba") opt.async_ba = true;
+    else if (a == "--ba-merge-after") opt.ba_merge_after = std::atoi(need("--ba-merge-after").c_str());  // with --async-ba: deterministic hand-over
     else if (a == "--fused") opt.fused_tracking = true;
     else if (a == "--no-lookahead") lookahead = false;
     else if (a == "--replicas") replicas = std::atoi(need("--replicas").c_str());
