@@ -185,6 +185,10 @@ void* vsl_frames_images_dev(vsl_frames* f);
  * has passed the copy. */
 int vsl_frames_upload(vsl_ctx* ctx, vsl_frames* f, int first, int n, const uint8_t* imgs,
                       size_t pitch, size_t img_stride);
+/* Page-locks / releases a caller-owned host buffer (hipHostRegister): uploads from it are asynchronous DMA transfers
+ * instead of staged copies.  Optional; the buffer must stay valid until it is unregistered. */
+int vsl_host_register(vsl_ctx* ctx, void* ptr, size_t bytes);
+int vsl_host_unregister(vsl_ctx* ctx, void* ptr);
 /* detectKeypointsAndDescriptors over slots [first, first+n) (asynchronous). */
 int vsl_frames_detect_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, int num_features,
                                int rotate_features);

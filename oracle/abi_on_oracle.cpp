@@ -33,6 +33,8 @@ extern "C" {
 const char* vsl_version(void) { return "vslam ABI on the CPU oracle (baseline only)"; }
 const char* vsl_last_error(const vsl_ctx* c) { return c ? c->err : g_err; }
 int vsl_device_count(void) { return 1; }  // one "device": the host
+int vsl_host_register(vsl_ctx*, void*, size_t) { return VSL_OK; }  // nothing to pin on the CPU path
+int vsl_host_unregister(vsl_ctx*, void*) { return VSL_OK; }
 int vsl_ctx_create(int, vsl_ctx** out) {
   *out = new vsl_ctx();
   (*out)->err[0] = 0;

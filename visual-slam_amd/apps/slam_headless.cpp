@@ -106,6 +106,13 @@ int main(int argc, char** argv) {
     }
   }
   const double decode_s = std::chrono::duration<double>(Clk::now() - d0).count();
+  // page-lock the decoded images: the per-frame upload is then an asynchronous DMA transfer (the look-ahead of the
+  // device-resident path enqueues it under the host work of the previous frame); failures are not fatal
+  int n_pinned = 0;
+  for (int i = 0; i < n_frames; i++) {
+    n_pinned += vsl_host_register(amd::ctx(), left[i].px.data(), left[i].px.size()) == VSL_OK;
+    n_pinned += vsl_host_register(amd::ctx(), right[i].px.data(), right[i].px.size()) == VSL_OK;
+  }
   if (!drop_spec.empty()) {
     int a = 0, b = -1;
     if (std::sscanf(drop_spec.c_str(), "%d-%d", &a, &b) == 2)
@@ -238,6 +245,11 @@ int main(int argc, char** argv) {
       std::fclose(f);
     }
   }
+  if (n_pinned == 2 * n_frames)
+    for (int i = 0; i < n_frames; i++) {
+      vsl_host_unregister(amd::ctx(), left[i].px.data());
+      vsl_host_unregister(amd::ctx(), right[i].px.data());
+    }
   size_t n_active = 0;
   for (const auto& kv : odo.landmarks) n_active += kv.second.active ? 1 : 0;
   const StageClock& c = odo.clock;
@@ -250,5 +262,6 @@ int main(int argc, char** argv) {
       n_frames, n_kf, replicas, replicas_agree ? "true" : "false", replicas * n_frames / run_s, 1e3 * run_s / n_frames, decode_s, ate, n_assoc, odo.landmarks.size(), n_active,
       opt.async_ba ? "true" : "false", opt.fused_tracking ? "true" : "false", c.detect_ms, c.stereo_match_ms, c.project_match_ms, c.localize_ms, c.map_ms, c.ba_ms, c.bow_ms, odo.loop_ms, odo.gba_ms, c.ba_runs, odo.bow_vectors.size(),
       odo.n_tracking_lost, odo.n_relocalized, odo.n_loops_closed, odo.n_global_ba, reloc_ok, reloc_err_m);
+  amd::release_thread_ctx();  // the main thread's context (image registration), before static / thread-local teardown
   return 0;
 }

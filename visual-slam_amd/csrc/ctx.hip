@@ -286,6 +286,21 @@ extern "C" int vsl_frames_upload(vsl_ctx* ctx, vsl_frames* f, int first, int n, 
   return VSL_OK;
 }
 
+// Page-lock a caller-owned host buffer (a decoded image, a ring of frames) so that vsl_frames_upload from it is a real
+// asynchronous DMA instead of a staged copy through the runtime's own pinned buffer.
+extern "C" int vsl_host_register(vsl_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx || !ptr || bytes == 0) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_host_register: bad arguments");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  VSL_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return VSL_OK;
+}
+extern "C" int vsl_host_unregister(vsl_ctx* ctx, void* ptr) {
+  if (!ctx || !ptr) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_host_unregister: bad arguments");
+  VSL_HIP(ctx, hipSetDevice(ctx->device));
+  VSL_HIP(ctx, hipHostUnregister(ptr));
+  return VSL_OK;
+}
+
 // Cross-stream ordering without a host round trip (an upload context feeding a compute context, the compute context
 // handing the buffer back: bench.py's streaming mode; the reference's order is load -> detect, src/slam.cpp:1122-1128).
 struct vsl_event {
