@@ -5,6 +5,7 @@
 // arrays of vsl_ba_problem, call the MI355X solver, and write poses / landmark positions back in
 // place -- the contract of the Ceres version (parameter blocks are the containers' own storage).
 #pragma once
+#include <stdexcept>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -54,9 +55,14 @@ inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_
   std::vector<int32_t> cam_intr, obs_cam, obs_lm;
   std::vector<Camera*> cam_ptr;
   std::vector<Landmark*> lm_ptr;
-  std::map<FrameCamId, int> cam_index;
+  // cameras in std::map order; an observation list (std::map<FrameCamId, FeatureId>) is walked against it with two
+  // cursors instead of two tree lookups per observation (20 k observations per local window)
+  std::vector<FrameCamId> cam_id;
+  std::vector<const KeypointsData*> cam_kd;
   for (auto& kv : cameras) {  // std::map order == the order Ceres receives the blocks (map_utils.h:359)
-    cam_index[kv.first] = (int)cam_ptr.size();
+    cam_id.push_back(kv.first);
+    const auto kd = feature_corners.find(kv.first);
+    cam_kd.push_back(kd == feature_corners.end() ? nullptr : &kd->second);
     cam_ptr.push_back(&kv.second);
     const double* d = kv.second.T_w_c.data();
     poses.insert(poses.end(), d, d + 7);
@@ -69,9 +75,13 @@ inline void run_ba(const Corners& feature_corners, bool use_huber, double huber_
     const int li = (int)lm_ptr.size();
     lm_ptr.push_back(&lm);
     points.insert(points.end(), lm.p.data(), lm.p.data() + 3);
+    size_t ci = 0;
     for (const auto& ob : track) {
-      const auto& p_2d = feature_corners.at(ob.first).corners[ob.second];  // .at(): std::out_of_range like the reference
-      obs_cam.push_back(cam_index.at(ob.first));
+      while (ci < cam_id.size() && cam_id[ci] < ob.first) ci++;
+      if (ci == cam_id.size() || ob.first < cam_id[ci] || !cam_kd[ci])  // .at(): std::out_of_range like the reference
+        throw std::out_of_range("bundle_adjustment: an observation refers to a camera / keypoint set that is not there");
+      const auto& p_2d = cam_kd[ci]->corners[ob.second];
+      obs_cam.push_back((int32_t)ci);
       obs_lm.push_back(li);
       uv.push_back(p_2d[0]);
       uv.push_back(p_2d[1]);
