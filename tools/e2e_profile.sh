@@ -17,7 +17,15 @@ if not os.path.exists("$V"):
     s.write_vocabulary_text("$V", 10, 6, *s.vocabulary_arrays(7, 10, 6))
 PY
 fi
-FLAGS="--dataset-path $D --cam-calib $D/calib.json --voc-path $V --relocalization --loop-closure --fused"
+# LEG=stages: the loop-closing-stages leg of bench.py (injected drift + forced candidate: compute_sim3, pose graph, global
+# BA kernels appear in the statistics); default: the reference-defaults leg
+if [ "${LEG:-main}" = "stages" ]; then
+  LAP=$(python3 -c "import math; print(max(int(round(2*math.pi*$RAD/$STEP))-20,1))")
+  FLAGS="--dataset-path $D --cam-calib $D/calib.json --voc-path $V --loop-closure --inject-drift 300:0.5,0,0.3 --force-loop $LAP:0 --fused"
+  TAG=${TAG}_stages
+else
+  FLAGS="--dataset-path $D --cam-calib $D/calib.json --voc-path $V --relocalization --loop-closure --fused"
+fi
 OUT=$R/gpurun_out/${TAG}_e2e_kt
 rm -rf $OUT
 cd /tmp && export TMPDIR=/tmp

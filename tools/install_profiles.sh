@@ -12,6 +12,8 @@ cp $(ls $O/lba/*/*_kernel_stats.csv | head -1) profiles/${R}_local_ba_kernel_sta
 cp $(ls $O/gba/*/*_kernel_stats.csv | head -1) profiles/${R}_global_ba_kernel_stats.csv
 cp $(ls $O/bow/*/*_kernel_stats.csv | head -1) profiles/${R}_bow_orb_kernel_stats.csv
 cp $O/${R}_e2e_kernel_stats.json $O/${R}_e2e_kernel_stats.csv profiles/
+cp $O/${R}_stages_e2e_kernel_stats.json profiles/${R}_e2e_loop_closing_stages_kernel_stats.json
+cp $O/${R}_stages_e2e_kernel_stats.csv profiles/${R}_e2e_loop_closing_stages_kernel_stats.csv
 python tools/pmc_summary.py $O profiles/${R}_pmc_traffic.json 512
 python tools/sq_summary.py $O profiles/${R}_matcher_sq_counters.json
 python tools/frame_sq_summary.py $O profiles/${R}_frame_sq_counters.json

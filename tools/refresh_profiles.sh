@@ -25,6 +25,7 @@ python3 $R/tools/pmc_summary.py $O $R/profiles/${ROUND}_pmc_traffic.json 512 > $
 # single-stream device accounting of the end-to-end leg (kernel launches and kernel time per frame); its summary goes
 # into the box's profiles/ as well, so that the bench line's device_accounting block is this build's
 echo e2e; (cd $R && LOOK=90 bash tools/e2e_profile.sh $ROUND > $O/e2e_profile.log 2>&1; cp gpurun_out/${ROUND}_e2e_kernel_stats.json gpurun_out/${ROUND}_e2e_kernel_stats.csv profiles/ 2>/dev/null; cp gpurun_out/${ROUND}_e2e_kernel_stats.json gpurun_out/${ROUND}_e2e_kernel_stats.csv $O/)
+(cd $R && LOOK=90 LEG=stages bash tools/e2e_profile.sh $ROUND > $O/e2e_stages_profile.log 2>&1; cp gpurun_out/${ROUND}_stages_e2e_kernel_stats.json gpurun_out/${ROUND}_stages_e2e_kernel_stats.csv $O/ 2>/dev/null)
 cd /tmp
 echo bench; (cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench.err)
 # BoW (K8 / K9) and the ORB front end: kernel durations on the k = 10 / L = 6 vocabulary
