@@ -252,6 +252,14 @@ def bow_measurement(vsl, ctx, synth, ring, voc_path, orc=None):
             row["scores_equal_oracle"] = bool(np.array_equal(np.asarray(exp), sc[:n_cpu]))
         out["score_batch"].append(row)
     ctx.set_profiling(False)
+    # HBM traffic of these kernels from the newest committed PMC passes (tools/bow_pmc.sh: FETCH_SIZE x 2 + WRITE_SIZE,
+    # the calibration of profiles/rNN_pmc_traffic.json), taken on the same vocabulary and descriptor counts
+    try:
+        pm = json.loads(sorted((ROOT / "profiles").glob("r*_bow_pmc_traffic.json"))[-1].read_text())["kernels"]
+        out["transform"]["traffic"] = pm["bow_descend_kernel"]["bytes_largest_dispatch"] + pm["bow_assemble_kernel"]["bytes_largest_dispatch"]
+        out["score_batch"][-1]["traffic"] = pm["bow_score_lds_kernel"]["bytes_largest_dispatch"]
+    except Exception:
+        pass
     if orc is not None:
         t0 = time.perf_counter()
         ov = orc.Vocabulary(voc_path)
