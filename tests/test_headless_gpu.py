@@ -223,3 +223,45 @@ def test_gpu_pipeline_and_cpu_oracle_pipeline_agree(sequence, tmp_path):
     c = cpu("--frames", "60", "--kf-min-inliers", "500")
     assert abs(c["keyframes"] - g["keyframes"]) <= 2
     assert g["ate_rmse_m"] < 0.015 and c["ate_rmse_m"] < 0.015, (g["ate_rmse_m"], c["ate_rmse_m"])
+
+
+@pytest.fixture(scope="module")
+def benchmark_lap(tmp_path_factory, vsl, synth):
+    """bench.py's end-to-end input: 640 frames on a circle of 560, cameras looking at the nearest wall, and a vocabulary
+    of the ORBvoc.txt shape (k = 10, L = 6).  Rendered in a fresh process (forked workers, no GPU state)."""
+    import os
+    import sys
+    d = tmp_path_factory.mktemp("benchlap")
+    code = ("import sys, importlib; sys.path.insert(0, %r); import __graft_entry__ as e; e.load_package(); "
+            "sq = importlib.import_module('visual_slam_amd.synth_sequence'); "
+            "sq.render_sequence(%r, n_frames=640, seed=1, step_m=0.03, radius=2.674, workers=%d, look_deg=90.0)"
+            % (str(ROOT), str(d), max(1, min(16, os.cpu_count() or 1))))
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=900)
+    synth.write_vocabulary_text(d / "voc.txt", 10, 6, *synth.vocabulary_arrays(7, 10, 6))
+    return d
+
+
+def test_benchmark_lap_with_the_reference_default_branches(benchmark_lap, tmp_path):
+    # The end-to-end legs of bench.py, asserted (the bench only reports them):
+    #  * reference defaults (relocalisation + loop closure + per-keyframe BoW on the 1.1 M-node tree), no hook: the lap
+    #    is tracked to a few centimetres, every keyframe has its BoW vector, loop DETECTION ran on every keyframe and
+    #    nothing closed; operator path and device-resident path write the same trajectory file;
+    #  * the loop-closing stages (injected drift + forced candidate, relocalisation off): one loop closes, one global BA
+    #    runs and the trajectory error drops well below the open-loop one.
+    d = benchmark_lap
+    voc = str(d / "voc.txt")
+    ta, tb = tmp_path / "ops.csv", tmp_path / "fused.csv"
+    dflt = ["--relocalization", "--loop-closure", "--voc-path", voc]
+    a = _run(d, *dflt, "--traj", str(ta))
+    b = _run(d, *dflt, "--fused", "--traj", str(tb))
+    assert ta.read_bytes() == tb.read_bytes()
+    assert b["frames"] == 640 and b["keyframes"] >= 15 and b["bow_vectors"] == b["keyframes"]
+    assert b["ate_rmse_m"] < 0.03 and b["tracking_lost"] <= 2, b
+    assert b["loops_closed"] == 0 and b["stage_ms_total"]["loop"] > 0 and b["stage_ms_total"]["bow"] > 0
+    assert a["ate_rmse_m"] == b["ate_rmse_m"]
+    drift = ["--voc-path", voc, "--inject-drift", "300:0.5,0,0.3", "--fused"]
+    open_loop = _run(d, *drift)
+    closed = _run(d, *drift, "--loop-closure", "--force-loop", "540:0")
+    assert open_loop["loops_closed"] == 0 and open_loop["ate_rmse_m"] > 1.0
+    assert closed["loops_closed"] >= 1 and closed["global_ba_runs"] >= 1 and closed["stage_ms_total"]["global_ba"] > 0
+    assert closed["ate_rmse_m"] < 0.6 * open_loop["ate_rmse_m"], (closed["ate_rmse_m"], open_loop["ate_rmse_m"])

@@ -10,6 +10,9 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as entry  # noqa: E402
 
 vsl = entry.load_package()
+import os  # noqa: E402
+if os.environ.get("VSL_SO"):  # a second build of the library (experimental kernel) for same-box comparisons
+    vsl._SO = Path(os.environ["VSL_SO"]).resolve()
 orc = entry.load_oracle()
 synth = importlib.import_module("visual_slam_amd.synth")
 ctx = vsl.Context(0)

@@ -414,7 +414,12 @@ inline __device__ bool inv3(const double* P, double* Pi) {
 
 // K7, small systems.  See the file header.  LB landmarks are staged per barrier pair.
 #define SCH_THREADS 1024
+#ifndef SCH_LB
 #define SCH_LB 16
+#endif
+#ifndef SCH_GMAX
+#define SCH_GMAX 256
+#endif
 #define SCH_KMAX 24   // observations of one landmark that hit FREE cameras (<= free cameras <= 21)
 #define SCH_EPT 16    // owned entries per thread: n <= 128
 #define SCH_CMAX 22   // free cameras
@@ -1738,7 +1743,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   st.small = D.n <= 128 && D.nfree <= SCH_CMAX && kmax_free <= SCH_KMAX;
   st.nb_obs = (D.O + 255) / 256;
   st.nb_upd = (std::max(D.C, D.L) + 255) / 256;
-  st.G = std::min(256, (D.L + SCH_LB - 1) / SCH_LB);
+  st.G = std::min(SCH_GMAX, (D.L + SCH_LB - 1) / SCH_LB);
   st.lm_per_wg = ((D.L + st.G - 1) / st.G + SCH_LB - 1) / SCH_LB * SCH_LB;
   st.G = (D.L + st.lm_per_wg - 1) / st.lm_per_wg;
 
