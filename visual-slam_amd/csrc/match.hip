@@ -309,20 +309,69 @@ typedef float v16f_t __attribute__((ext_vector_type(16)));
 // Round 3: the distance matrix is no longer computed twice.  The reference scans forward once and checks the reverse
 // direction only for rows that pass threshold + ratio (keypoints.h:355-362, :282-312), so
 //   launch 1 (REVERSE = false): queries = set a, database = set b -> best / second per row i          (n_a x n_b distances)
-//   launch 2 (REVERSE = true):  every workgroup first lists, in LDS, the columns j = best(i) of the rows that passed
-//                               (ascending j, <= n_b of them; ~a third of the set on the benchmark frames), then the SAME
-//                               tile loop runs with those columns as queries against set a       (~0.35 n_a x n_b distances)
+//   match_select_kernel:        one workgroup per pair lists the columns j = best(i) of the rows that passed (ascending j,
+//                               <= n_b of them; ~a third of the set on the benchmark frames)
+//   launch 2 (REVERSE = true):  the SAME tile loop with those columns as queries against set a    (~0.35 n_a x n_b distances)
 // Columns nobody points at keep KEY_INIT-free garbage from an earlier launch -- match_finalize only reads bk1[best(i)] of
 // passing rows, exactly the entries launch 2 wrote.  Both grids are 1-D and XCD-aware: the hardware deals workgroups
 // round-robin to the 8 XCDs, so block id b serves pair 8 (b / 8 / blocks_per_pair) + b % 8 -- all workgroups of a pair
 // share one XCD's L2 and the pair's descriptors are fetched from HBM once instead of once per XCD.
+// Between the two passes: one workgroup per pair lists the columns j = best(i) of the rows that pass threshold + ratio,
+// ascending and without repeats, into the (not yet written) match buffer of the pair; the count goes to match_count.
+// (First version: every workgroup of the reverse launch rebuilt this list in LDS -- six times per pair, four of them
+// only to find out that they have nothing to do.)
+__global__ __launch_bounds__(512) void match_select_kernel(const int32_t* __restrict__ kp_count, const int32_t* __restrict__ pair_slots,
+                                                           const uint32_t* __restrict__ best_key,
+                                                           const uint32_t* __restrict__ second_key, int F, int threshold,
+                                                           double dist_2_best, int32_t* __restrict__ sel_list,
+                                                           int32_t* __restrict__ sel_count) {
+  __shared__ unsigned char flag[2048];
+  __shared__ int sel_wave[8];
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_a = kp_count[pair_slots[2 * pair]], n_b = kp_count[pair_slots[2 * pair + 1]];
+  const uint32_t* bk0 = best_key + ((size_t)pair * 2) * F;
+  const uint32_t* sk0 = second_key + ((size_t)pair * 2) * F;
+  for (int j = tid; j < 2048; j += 512) flag[j] = 0;
+  __syncthreads();
+  for (int i = tid; i < n_a; i += 512) {
+    const uint32_t bk = bk0[i];
+    const int d1 = (int)(bk >> KEY_SHIFT), d2 = (int)(sk0[i] >> KEY_SHIFT);
+    if (n_b > 0 && d1 < threshold && !((double)d2 < (double)d1 * dist_2_best)) flag[bk & ((1u << KEY_SHIFT) - 1)] = 1;
+  }
+  __syncthreads();
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) cnt += flag[tid * 4 + u];
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) sel_wave[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    if (w < wave) base += sel_wave[w];
+    total += sel_wave[w];
+  }
+  int pos = base + incl - cnt;
+  int32_t* out = sel_list + (size_t)pair * 2 * F;
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (flag[tid * 4 + u]) out[pos++] = tid * 4 + u;
+  if (tid == 0) sel_count[pair] = total;
+}
+
 template <bool REVERSE>
 __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mx_kernel(const uint64_t* __restrict__ desc,
                                                                    const int32_t* __restrict__ kp_count,
                                                                    const int32_t* __restrict__ pair_slots,
                                                                    uint32_t* __restrict__ best_key,
                                                                    uint32_t* __restrict__ second_key, int F, int n_pairs,
-                                                                   int blocks_per_pair, int threshold, double dist_2_best) {
+                                                                   int blocks_per_pair, const int32_t* __restrict__ sel_list,
+                                                                   const int32_t* __restrict__ sel_count) {
   __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
   __shared__ __align__(16) float rowkey[2][64];  // 256 * 2048 + m, or MX_PAD_KEY_F past the end
   __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
@@ -338,49 +387,12 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mx_kernel(const uint64_
   const int q0 = blk * (32 * MM_WAVES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  // REVERSE: the queries are the columns some passing row points at, listed in ascending order
-  __shared__ uint16_t sel[REVERSE ? 2048 : 2];
-  __shared__ unsigned char flag[REVERSE ? 2048 : 2];
-  __shared__ int sel_wave[MM_WAVES];
-  if (REVERSE) {
-    const uint32_t* bk0 = best_key + ((size_t)pair * 2) * F;
-    const uint32_t* sk0 = second_key + ((size_t)pair * 2) * F;
-    for (int j = tid; j < 2048; j += 64 * MM_WAVES) flag[j] = 0;
-    __syncthreads();
-    for (int i = tid; i < n_d; i += 64 * MM_WAVES) {  // n_d = size of set a here: its rows are the forward pass's
-      const uint32_t bk = bk0[i];
-      const int d1 = (int)(bk >> KEY_SHIFT), d2 = (int)(sk0[i] >> KEY_SHIFT);
-      if (n_q > 0 && d1 < threshold && !((double)d2 < (double)d1 * dist_2_best)) flag[bk & ((1u << KEY_SHIFT) - 1)] = 1;
-    }
-    __syncthreads();
-    constexpr int PER = 2048 / (64 * MM_WAVES);  // contiguous flags per thread
-    int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < PER; u++) cnt += flag[tid * PER + u];
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) sel_wave[wave] = incl;
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < MM_WAVES; w++) {
-      if (w < wave) base += sel_wave[w];
-      total += sel_wave[w];
-    }
-    int pos = base + incl - cnt;
-#pragma unroll
-    for (int u = 0; u < PER; u++)
-      if (flag[tid * PER + u]) sel[pos++] = (uint16_t)(tid * PER + u);
-    n_q = total;
-    __syncthreads();
-  }
+  // REVERSE: the queries are the columns some passing row points at, listed in ascending order by match_select_kernel
+  const int32_t* __restrict__ sel = sel_list + (size_t)pair * 2 * F;
+  if (REVERSE) n_q = sel_count[pair];
   if (q0 >= n_q) return;  // workgroup-uniform
   const int qc = q0 + wave * 32 + c;
-  const int qrow = REVERSE ? (int)sel[qc < n_q ? qc : 0] : (qc < n_q ? qc : 0);
+  const int qrow = REVERSE ? sel[qc < n_q ? qc : 0] : (qc < n_q ? qc : 0);
   const uint32_t* __restrict__ qd = (const uint32_t*)(desc + ((size_t)slot_q * F + qrow) * 4);
   const uint32_t* __restrict__ dbase = (const uint32_t*)(desc + (size_t)slot_d * F * 4);
   if (tid < 256) {
@@ -557,9 +569,13 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
         const int bpp = (f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES);
         const dim3 grid1((unsigned)(((n_pairs + 7) / 8) * 8 * bpp));
         hipLaunchKernelGGL(hamming_mx_kernel<false>, grid1, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
-                           f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, threshold, dist_2_best);
+                           f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, (const int32_t*)f->matches,
+                           (const int32_t*)f->match_count);
+        hipLaunchKernelGGL(match_select_kernel, dim3(n_pairs), dim3(512), 0, ctx->stream, f->kp_count, f->pair_slots, f->best_key,
+                           f->second_key, f->F, threshold, dist_2_best, f->matches, f->match_count);
         hipLaunchKernelGGL(hamming_mx_kernel<true>, grid1, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
-                           f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, threshold, dist_2_best);
+                           f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, (const int32_t*)f->matches,
+                           (const int32_t*)f->match_count);
       } else if (ctx->match_no_stagger)
         hipLaunchKernelGGL(hamming_mfma_kernel<false>, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
                            f->pair_slots, f->best_key, f->second_key, f->F);
