@@ -364,8 +364,16 @@ __global__ __launch_bounds__(512) void match_select_kernel(const int32_t* __rest
   if (tid == 0) sel_count[pair] = total;
 }
 
+// Occupancy target: THREE workgroups per compute unit (6 waves per SIMD: 78 VGPRs, 4 of them spilled) instead of the
+// two the compiler's own choice (107 VGPRs) allows.  A workgroup's time is set by its barrier-separated tile steps, a
+// third resident workgroup fills the gaps: 0.267 -> 0.256 ms per 512 pairs.  Measured around it: 5 waves per SIMD (84
+// VGPRs, still two workgroups) 0.278, 7 (72 VGPRs, 7 spills) 0.262-0.271, 8 (64 VGPRs, 16 spills) 0.278-0.282.
+#ifndef MX_WAVES_PER_EU
+#define MX_WAVES_PER_EU 6
+#endif
+#define MX_OCC __attribute__((amdgpu_waves_per_eu(MX_WAVES_PER_EU, MX_WAVES_PER_EU)))
 template <bool REVERSE>
-__global__ __launch_bounds__(64 * MM_WAVES) void hamming_mx_kernel(const uint64_t* __restrict__ desc,
+__global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const uint64_t* __restrict__ desc,
                                                                    const int32_t* __restrict__ kp_count,
                                                                    const int32_t* __restrict__ pair_slots,
                                                                    uint32_t* __restrict__ best_key,
