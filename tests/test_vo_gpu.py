@@ -91,6 +91,38 @@ def test_find_matches_tie_semantics(ctx, orc):
         assert np.array_equal(ctx.find_matches_landmarks(*args), orc.find_matches_landmarks(*args)), dists
 
 
+def test_find_matches_radius_boundary(ctx, orc):
+    # the kernel tests dx^2 + dy^2 < T with the host-computed T that makes it the same decision as the reference's
+    # (p_2d - kp).norm() < match_max_dist_2d (vo_utils.h:108) for EVERY double: projected points exactly on the circle
+    # (3-4-5 triangles: norm == radius, not a hit), one ulp inside / outside it, squared sums within an ulp of radius^2
+    # (where sqrt rounds to the radius itself), radii that are not representable squares
+    z = np.zeros(4, np.uint64)
+    for radius in (20.0, 5.0, 0.1, 19.999999999999996, 7.3, 1e-3, 123.456):
+        pts = []
+        for ang in np.linspace(0.0, 2 * np.pi, 97):
+            for scale in (1.0, np.nextafter(1.0, 0), np.nextafter(1.0, 2), 1 - 1e-15, 1 + 1e-15, 1 - 3e-16, 1 + 3e-16):
+                pts.append([300.0 + radius * scale * np.cos(ang), 200.0 + radius * scale * np.sin(ang)])
+        if radius == 20.0:
+            pts += [[312.0, 216.0], [288.0, 184.0], [312.0, np.nextafter(216.0, 0)], [312.0, np.nextafter(216.0, 1e9)]]
+        n = len(pts)
+        start = np.arange(n + 1, dtype=np.int32)
+        obs = np.zeros((n, 4), np.uint64)
+        # every landmark alone against the keypoint: n single-landmark calls would be slow -- instead give landmark i the
+        # descriptor distance i % 60 and compare the whole result with the oracle for several thresholds
+        for i in range(n):
+            for b in range(i % 60):
+                obs[i, b // 64] |= np.uint64(1) << np.uint64(b % 64)
+        for sub in (slice(0, n), slice(n // 3, n), slice(0, n, 7), slice(5, n, 11)):
+            idx = np.arange(n, dtype=np.int32)[sub]
+            args = ([[300.0, 200.0]], [z], np.asarray(pts)[sub], np.arange(len(idx), dtype=np.int32),
+                    np.arange(len(idx) + 1, dtype=np.int32), obs[sub], radius, 70, 1.0)
+            assert np.array_equal(ctx.find_matches_landmarks(*args), orc.find_matches_landmarks(*args)), (radius, sub)
+        # and landmark by landmark on the circle itself (the first 97 * 7 points): hit / no hit must agree one by one
+        for i in list(range(0, 97 * 7, 13)) + list(range(97 * 7, n)):
+            args = ([[300.0, 200.0]], [z], [pts[i]], np.zeros(1, np.int32), np.array([0, 1], np.int32), obs[:1], radius, 70, 1.0)
+            assert np.array_equal(ctx.find_matches_landmarks(*args), orc.find_matches_landmarks(*args)), (radius, i)
+
+
 def test_find_matches_empty(ctx):
     z = np.zeros((0, 4), np.uint64)
     assert len(ctx.find_matches_landmarks(np.zeros((0, 2)), z, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros(1, np.int32), z)) == 0

@@ -188,12 +188,34 @@ __global__ __launch_bounds__(1024) void project_compact_kernel(PoseIntr pi, int 
   }
 }
 
+// The smallest double T with !(sqrt(T) < m): for x >= 0, sqrt(x) < m <=> x < T, because the correctly rounded square
+// root is monotone (host libm and the device's fp64 sqrt are both correctly rounded).  Bisection over the bit patterns
+// of the non-negative doubles (they order like the values).
+static double sqrt_less_threshold(double m) {
+  if (!(m > 0.0)) return 0.0;  // sqrt(x) < m never holds for x >= 0
+  if (std::isinf(m)) return m;
+  uint64_t lo = 0, hi;          // invariant: sqrt(value(lo)) < m, !(sqrt(value(hi)) < m)
+  {
+    const double inf = INFINITY;
+    memcpy(&hi, &inf, 8);
+  }
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    double v;
+    memcpy(&v, &mid, 8);
+    if (std::sqrt(v) < m) lo = mid; else hi = mid;
+  }
+  double T;
+  memcpy(&T, &hi, 8);
+  return T;
+}
+
 // one wavefront per keypoint; result[k] = matched landmark index or -1
 __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restrict__ kp_xy, const uint64_t* __restrict__ kp_desc,
                                                            int n_kp, const double* __restrict__ proj_uv,
                                                            const int32_t* __restrict__ proj_lm, int n_proj,
                                                            const int32_t* __restrict__ lm_obs_start,
-                                                           const uint64_t* __restrict__ obs_desc, double max_dist_2d,
+                                                           const uint64_t* __restrict__ obs_desc, double max_dist_sq,
                                                            int threshold, double dist_2_best, int32_t* __restrict__ result,
                                                            const int32_t* __restrict__ kp_xy_i32,
                                                            const int32_t* __restrict__ obs_index,
@@ -236,7 +258,10 @@ __global__ __launch_bounds__(256) void find_matches_kernel(const double* __restr
     bool hit = false;
     if (j < n_proj) {
       const double dx = kx - proj_uv[2 * (size_t)j], dy = ky - proj_uv[2 * (size_t)j + 1];
-      hit = sqrt(dx * dx + dy * dy) < max_dist_2d;
+      // the reference tests (p_2d - kp).norm() < match_max_dist_2d (vo_utils.h:108); max_dist_sq is the host-computed
+      // double T with sqrt(x) < match_max_dist_2d <=> x < T for every x >= 0 (sqrt_less_threshold below): the same
+      // decisions bit for bit without ~40 instructions of fp64 square root per lane and chunk
+      hit = dx * dx + dy * dy < max_dist_sq;
     }
     unsigned long long mask = __ballot(hit);
     while (mask) {
@@ -407,7 +432,7 @@ extern "C" int vsl_find_matches_landmarks(vsl_ctx* ctx, const double* kp_xy, con
   VSL_HIP(ctx, hipMemcpyAsync(dplm, proj_lm, 4 * P, hipMemcpyHostToDevice, ctx->stream));
   VSL_HIP(ctx, hipMemcpyAsync(dstart, lm_obs_start, 4 * (L + 1), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(find_matches_kernel, dim3((n_kp + 3) / 4), dim3(256), 0, ctx->stream, dkxy, dkd, n_kp, dpuv, dplm, n_proj,
-                     dstart, dod, match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, dres,
+                     dstart, dod, sqrt_less_threshold(match_max_dist_2d), feature_match_threshold, feature_match_dist_2_best, dres,
                      (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, n_kp, (const int32_t*)nullptr,
                      (int32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr);
   hipLaunchKernelGGL(compact_matches_kernel, dim3(1), dim3(1024), 0, ctx->stream, dres, n_kp, dpairs, dn);
@@ -686,10 +711,11 @@ extern "C" int vsl_map_track_corners(vsl_map* m, vsl_frames* f, int slot, const 
   hipLaunchKernelGGL(project_compact_kernel, dim3(n_blocks), dim3(1024), 0, ctx->stream, pi, cam_model, width, height, m->points, n,
                      cam_z_threshold, m->out_uv, m->out_idx, m->counters, m->chain, m->epoch);
   int32_t* mail = m->mailbox;
+  const double max_dist_sq = sqrt_less_threshold(match_max_dist_2d);
   for (int attempt = 0; attempt < 2; attempt++) {
     hipLaunchKernelGGL(find_matches_kernel, dim3((f->F + 3) / 4), dim3(256), 0, ctx->stream, (const double*)nullptr,
                        f->kp_desc + 4 * (size_t)slot * f->F, f->F, m->out_uv, m->out_idx, n, m->obs_start, m->pool,
-                       match_max_dist_2d, feature_match_threshold, feature_match_dist_2_best, mail + 4,
+                       max_dist_sq, feature_match_threshold, feature_match_dist_2_best, mail + 4,
                        f->kp_xy + 2 * (size_t)slot * f->F, m->obs_index, f->kp_count + slot, f->F, m->counters, mail,
                        f->ties_pending ? f->tie_count : (const int32_t*)nullptr, corners_xy ? mail + 4 + f->F : (int32_t*)nullptr);
     VSL_CHECK_LAUNCH(ctx);
