@@ -3,12 +3,14 @@
 #   bash tools/e2e_probe.sh <n_frames> <step_m> <radius> [extra slam_headless flags]
 R=$GRAFT_REPO_ROOT; N=${1:-640}; STEP=${2:-0.03}; RAD=${3:-2.674}; shift 3
 LOOK=${LOOK:-0}
-D=/tmp/vsl_lap_${N}_${STEP}_${RAD}_${LOOK}
+ROOM=${ROOM:-4.0,2.5,4.0}
+PPM=${PPM:-110.0}
+D=/tmp/vsl_lap_${N}_${STEP}_${RAD}_${LOOK}_${ROOM}_${PPM}
 if [ ! -f $D/calib.json ]; then
 python3 - <<PY
 import sys, importlib, os; sys.path.insert(0, "$R"); import __graft_entry__ as e; e.load_package()
 sq = importlib.import_module('visual_slam_amd.synth_sequence')
-sq.render_sequence("$D", n_frames=$N, seed=1, step_m=$STEP, radius=$RAD, workers=min(16, os.cpu_count()), look_deg=$LOOK)
+sq.render_sequence("$D", n_frames=$N, seed=1, step_m=$STEP, radius=$RAD, workers=min(16, os.cpu_count()), look_deg=$LOOK, room_half=($ROOM), px_per_m=$PPM)
 PY
 fi
 V=/tmp/vsl_voc_k10L6_s7.txt

@@ -226,12 +226,12 @@ def _render_frame(k):
 
 
 def render_sequence(out_dir, n_frames=60, seed=1, t0_ns=1403715273262142976, dt_ns=50_000_000, png_level=1,
-                    step_m=0.03, radius=1.2, workers=1, look_deg=0.0):
+                    step_m=0.03, radius=1.2, workers=1, look_deg=0.0, room_half=(4.0, 2.5, 4.0), px_per_m=110.0):
     """Writes <out_dir>/{cam0,cam1}/data.csv + data/*.png, state_groundtruth_estimate0/data.csv and
     <out_dir>/calib.json.  Returns the list of body poses (R_wi, t_wi).  The path is a circle: more than
     2 pi radius / step_m frames revisit the start (loop closure).  workers > 1 renders frames in forked
     processes (call before anything touches the GPU)."""
-    room = BoxRoom(seed)
+    room = BoxRoom(seed, half=room_half, px_per_m=px_per_m)
     poses = trajectory(n_frames, step_m=step_m, radius=radius, look_deg=look_deg)
     bear = [ds_unproject_grid(CALIB["intrinsics"][c]) for c in range(2)]
     T_i_c = []
