@@ -352,7 +352,10 @@ inline Pose refine_pose(const Pose& T0, const std::vector<Vec3>& f, const std::v
     // first-order translation (V(omega) ~ I for the small steps taken here)
     T.t = T.t + T.R * ups;
     T.R = T.R * exp_so3(om);
-    if (norm(ups) + norm(om) < 1e-8) break;  // 10 nm / 1e-8 rad: far below the measurement noise
+    // Gauss-Newton converges quadratically here: a step below 1e-5 (10 um / 1e-5 rad) leaves an error of the order of its
+    // square (measured on 600 correspondences: steps 1e-2, 7e-6, 4e-10) -- far below the measurement noise.  (The
+    // earlier 1e-8 bought a third pass over the inliers that moved the pose by 4e-10.)
+    if (norm(ups) + norm(om) < 1e-5) break;
   }
   return T;
 }
