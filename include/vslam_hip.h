@@ -204,6 +204,7 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
 /* Diagnostic knobs for the parity tests (results never change, only which kernel path produces them):
  *   "match_use_valu" (0/1)          popcount matcher instead of the matrix-core one
  *   "match_use_i8" (0/1)            int8 matrix-core matcher where the block-scaled FP4 one would run (<= 2048 features)
+ *   "match_two_pass" (0/1)          FP4 matcher as forward + reverse passes also for launches of fewer than 8 pairs
  *   "match_no_stagger" (0/1)        matrix-core matcher with every wave of a workgroup in the same phase order
  *   "force_generic_describe" (0/1)  f64 describe kernel for every call
  *   "describe_tile_min_images" (default 96) describe launches of at least this many images use the shared-tile

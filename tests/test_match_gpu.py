@@ -46,7 +46,9 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
     d2[9] = np.uint64(0xFFFFFFFFFFFFFFFF)
     exp = orc.match_descriptors(d1, d2, 70, 1.2)
     assert np.array_equal(ctx.match_descriptors(d1, d2, 70, 1.2), exp)
-    for knob in ("match_use_valu", "match_use_i8"):   # the popcount kernel; the int8 matrix-core kernel (default here: FP4)
+    # the popcount kernel; the int8 matrix-core kernel (default here: FP4); the FP4 kernel as forward + reverse passes
+    # (the default of launches of >= 8 pairs -- a single pair runs both full directions in one launch)
+    for knob in ("match_use_valu", "match_use_i8", "match_two_pass"):
         ctx.set_diagnostic(knob, 1)
         try:
             got = ctx.match_descriptors(d1, d2, 70, 1.2)
@@ -55,7 +57,13 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
         assert np.array_equal(got, exp), knob
     # thresholds / ratios that move the cutoff (including "everything passes" and ratio < 1)
     for thr, ratio in ((1, 1.2), (70, 1.0), (70, 0.5), (70, 3.0), (130, 1.2), (200, 1.5), (256, 1.2), (300, 2.0)):
-        assert np.array_equal(ctx.match_descriptors(d1, d2, thr, ratio), orc.match_descriptors(d1, d2, thr, ratio)), (thr, ratio)
+        exp_tr = orc.match_descriptors(d1, d2, thr, ratio)
+        assert np.array_equal(ctx.match_descriptors(d1, d2, thr, ratio), exp_tr), (thr, ratio)
+        ctx.set_diagnostic("match_two_pass", 1)
+        try:
+            assert np.array_equal(ctx.match_descriptors(d1, d2, thr, ratio), exp_tr), (thr, ratio, "two passes")
+        finally:
+            ctx.set_diagnostic("match_two_pass", 0)
 
 
 @pytest.mark.parametrize("n1,n2", [(2048, 2048), (2047, 2049), (2049, 100), (100, 2049)])

@@ -19,6 +19,7 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "force_generic_describe") ctx->force_generic_describe = value != 0;
   else if (k == "describe_tile_min_images") ctx->describe_tile_min_images = value;
   else if (k == "bow_keys64") ctx->bow_keys64 = value != 0;
+  else if (k == "match_two_pass") ctx->match_two_pass = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
   else if (k == "exact_list_cap") ctx->exact_list_cap = value;
   else if (k == "ba_schur_entries") ctx->ba_schur_entries = value != 0;

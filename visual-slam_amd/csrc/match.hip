@@ -379,15 +379,22 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
                                                                    uint32_t* __restrict__ best_key,
                                                                    uint32_t* __restrict__ second_key, int F, int n_pairs,
                                                                    int blocks_per_pair, const int32_t* __restrict__ sel_list,
-                                                                   const int32_t* __restrict__ sel_count) {
+                                                                   const int32_t* __restrict__ sel_count, int both_dirs) {
   __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
   __shared__ __align__(16) float rowkey[2][64];  // 256 * 2048 + m, or MX_PAD_KEY_F past the end
   __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
   const int xj = (int)(blockIdx.x >> 3);
   const int pair = (xj / blocks_per_pair) * 8 + (int)(blockIdx.x & 7u);
   if (pair >= n_pairs) return;  // the pair count is padded to a multiple of 8
-  const int blk = xj % blocks_per_pair;
-  constexpr int dir = REVERSE ? 1 : 0;
+  int blk = xj % blocks_per_pair;
+  // both_dirs (REVERSE = false only; launches of a few pairs, where three dependent launches cost more than the second
+  // full matrix): the second half of a pair's blocks runs the b -> a direction in the same launch, like rounds 1-2
+  int dir = REVERSE ? 1 : 0;
+  if (!REVERSE && both_dirs) {
+    const int half = blocks_per_pair >> 1;
+    dir = blk >= half ? 1 : 0;
+    blk -= dir * half;
+  }
   const int slot_q = pair_slots[2 * pair + dir];
   const int slot_d = pair_slots[2 * pair + 1 - dir];
   int n_q = kp_count[slot_q];
@@ -575,15 +582,25 @@ int vsl_launch_match(vsl_ctx* ctx, vsl_frames* f, int n_pairs, int threshold, do
       dim3 grid((f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES), 2, n_pairs);
       if (db_bound <= 2048 && !ctx->match_use_i8) {
         const int bpp = (f->F + 32 * MM_WAVES - 1) / (32 * MM_WAVES);
+        if (n_pairs < 8 && !ctx->match_two_pass) {
+          // a handful of pairs (the per-keyframe stereo match, sim3 / relocalisation calls): ONE launch with both full
+          // directions -- the launch is latency-bound (a pair is 12 workgroups on 256 compute units), two more dependent
+          // launches cost more than the redundant distances (28 vs 50 us of device time for one pair)
+          const dim3 grid2((unsigned)(((n_pairs + 7) / 8) * 8 * 2 * bpp));
+          hipLaunchKernelGGL(hamming_mx_kernel<false>, grid2, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
+                             f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, 2 * bpp, (const int32_t*)f->matches,
+                             (const int32_t*)f->match_count, 1);
+        } else {
         const dim3 grid1((unsigned)(((n_pairs + 7) / 8) * 8 * bpp));
         hipLaunchKernelGGL(hamming_mx_kernel<false>, grid1, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
                            f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, (const int32_t*)f->matches,
-                           (const int32_t*)f->match_count);
+                           (const int32_t*)f->match_count, 0);
         hipLaunchKernelGGL(match_select_kernel, dim3(n_pairs), dim3(512), 0, ctx->stream, f->kp_count, f->pair_slots, f->best_key,
                            f->second_key, f->F, threshold, dist_2_best, f->matches, f->match_count);
         hipLaunchKernelGGL(hamming_mx_kernel<true>, grid1, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
                            f->pair_slots, f->best_key, f->second_key, f->F, n_pairs, bpp, (const int32_t*)f->matches,
-                           (const int32_t*)f->match_count);
+                           (const int32_t*)f->match_count, 0);
+        }
       } else if (ctx->match_no_stagger)
         hipLaunchKernelGGL(hamming_mfma_kernel<false>, grid, dim3(64 * MM_WAVES), 0, ctx->stream, f->kp_desc, f->kp_count,
                            f->pair_slots, f->best_key, f->second_key, f->F);

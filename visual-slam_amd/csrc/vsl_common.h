@@ -65,6 +65,7 @@ struct vsl_ctx {
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
   bool match_use_i8 = false;            // diagnostic: int8 matrix-core matcher even where the FP4 one applies (<= 2048 features)
   bool match_no_stagger = false;        // diagnostic: all waves of a matcher workgroup in the same phase order (the pre-stagger kernel)
+  bool match_two_pass = false;          // diagnostic: forward + reverse passes of the FP4 matcher even for launches of fewer than 8 pairs (which default to one launch with both full directions)
   bool match_use_valu = false;          // diagnostic: VALU popcount matcher instead of the MFMA one
   bool force_generic_describe = false;  // diagnostic: use the f64 kernel for every describe call
   int select_bucket_cap = 128;          // diagnostic: fullest response bin the counting sort of the selection kernel accepts (0: always the bitonic network)
