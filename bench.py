@@ -24,7 +24,18 @@ and the per-pair match counts are read back per batch.  It reports the PCIe rate
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, timed with HIP events on the stream the
 kernels run on; `cpu_baseline` is the CPU oracle (a port of the reference's path, the reference itself cannot be
-built offline) timed on this box's host cores on a bounded sample of the same frames.
+built offline) timed on this box's host cores on a bounded sample of the same frames -- and the timed run's outputs
+for those frames are compared with the oracle's (`outputs_equal_oracle_sample`).
+
+At N = 1 the line also carries: `local_ba` / `global_ba` (ms per LM iteration, BASELINE configs[2] / [4]); `bow` (DBoW2
+transform and L1 score on a k = 10, L = 6 vocabulary, device time, bytes, oracle beside it); the end-to-end legs of the
+headless next_step pipeline on a rendered 640-frame lap -- `end_to_end_single_stream` with the reference's default-on
+branches (relocalisation, loop closure, per-keyframe BoW) next to `cpu_baseline_end_to_end` (the same application on
+the CPU oracle), `end_to_end_loop_closing_stages` (a labelled stage exerciser), `end_to_end_vo_subset` (round 2's
+configuration) -- and the single-stream device accounting from the committed rocprofv3 summary.
+
+`--gpus N` without a launcher starts the N ranks itself (torch.distributed.run as a child process); under a launcher
+WORLD_SIZE must equal N.
 """
 import argparse
 import importlib
