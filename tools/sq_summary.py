@@ -18,15 +18,16 @@ def main():
                     k = row["Kernel_Name"]
                     if "hamming_m" not in k:
                         continue
-                    if "hamming_mx" in k:
-                        name = "fp4_block_scaled"
+                    if "hamming_mx" in k:  # round 3: a match launch is a forward and a reverse dispatch of this kernel
+                        name = "fp4_block_scaled_reverse_pass" if ("<true>" in k or "ILb1" in k) else "fp4_block_scaled_forward_pass"
                     elif "true" in k or "Lb1" in k:
                         name = "int8_staggered"
                     else:
                         name = "int8_lockstep"
                     acc[name][row["Counter_Name"]][(str(f), row["Dispatch_Id"])] += float(row["Counter_Value"])
-    doc = {"note": "rocprofv3 --pmc (no tracing) of tools/match_probe.py: 512 stereo pairs of 1500 keypoints per launch, both "
-                   "directions; mean per dispatch in millions.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, "
+    doc = {"note": "rocprofv3 --pmc (no tracing) of tools/match_probe.py: 512 stereo pairs of 1500 keypoints per launch; mean per "
+                   "DISPATCH in millions (the FP4 matcher is a forward dispatch over all 1500 queries and a reverse dispatch "
+                   "over the ~300 listed columns per pair; the int8 variants run both full directions in one dispatch).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, "
                    "SQ_VALU_MFMA_BUSY_CYCLES and SQ_VALU_MFMA_COEXEC_CYCLES count cycles (MI355X_MICROARCH.md).",
            "kernels": {}}
     for name, ctrs in acc.items():
