@@ -296,14 +296,19 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
 //   the int8 form needs for K = 32 (tools/probes/fp4_mfma_probe.hip: exact on random data, 48 vs 52 ticks per
 //   dependent instruction), so the matrix-pipe time per tile halves, and so do the LDS bytes per expanded descriptor
 //   (128 B) and the registers of the query fragment.
-//   Keys stay lane-local: key = fma(acc, 2048, 256 * 2048 + m) is an exact non-negative f32 (< 2^21) whose bit pattern
-//   orders like the value, so best / second are v_min_u32 / v_med3_u32 on the bits; converted back to
+//   Keys stay lane-local and cost no instruction of their own: the accumulator of database row m STARTS at
+//   512 + m / 2048 (read from LDS straight into the accumulator registers), so after the four instructions of a tile it
+//   holds 512 + |d| - 2<q, d> + m / 2048 -- an exact positive f32 in [256, 769) with 11 fraction bits (21 significant
+//   bits), whose bit pattern orders like (distance, m).  best / second are v_min / v_med3 on the bits, three keys at a
+//   time (min3 + med3 give a triple's two smallest, one min + one med3 + one min fold them into the trackers: 5
+//   instructions per 3 keys where key-by-key tracking takes 6 and the separate fma a further 3); converted back to
 //   (distance << KEY_SHIFT) | m at the end.  m < 2048 is what limits this variant to 2048 database descriptors.
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 #define MX_ROW 144          // LDS bytes per expanded descriptor: 128 + 16 pad
 #define MX_KEY_SCALE 2048.0f
-#define MX_PAD_KEY_F 4.0e6f  // rows past the end of the database: above every real key (max real key < 2^21)
+#define MX_KEY_BIAS 512.0f   // keeps every accumulator in [256, 769): one sign, no zero, 2^-14 or finer spacing
+#define MX_PAD_KEY_F 4096.0f  // rows past the end of the database (all-zero rows: the accumulator stays here): above every real key
 
 //
 // Round 3: the distance matrix is no longer computed twice.  The reference scans forward once and checks the reverse
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
                                                                    int blocks_per_pair, const int32_t* __restrict__ sel_list,
                                                                    const int32_t* __restrict__ sel_count, int both_dirs) {
   __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
-  __shared__ __align__(16) float rowkey[2][64];  // 256 * 2048 + m, or MX_PAD_KEY_F past the end
+  __shared__ __align__(16) float rowkey[2][64];  // 512 + m / 2048, or MX_PAD_KEY_F past the end: where the accumulators start
   __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
   const int xj = (int)(blockIdx.x >> 3);
   const int pair = (xj / blocks_per_pair) * 8 + (int)(blockIdx.x & 7u);
@@ -448,18 +453,32 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     if (!filler) return;
     *(v4i_t*)&tile[buf][frow * MX_ROW + fword * 16] = spread(wd);
     const int m = st * 64 + frow;
-    if (fword == 0) rowkey[buf][frow] = m < n_d ? (256.0f * MX_KEY_SCALE + (float)m) : MX_PAD_KEY_F;
+    if (fword == 0) rowkey[buf][frow] = m < n_d ? (MX_KEY_BIAS + (float)m * (1.0f / MX_KEY_SCALE)) : MX_PAD_KEY_F;
   };
   const int n_st = (n_d + 63) / 64;
   uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu, bB = 0xFFFFFFFFu, skB = 0xFFFFFFFFu;
+  // (B <= S) <- the two smallest of {B, S, k1, k2, k3}: lo <= mid are the triple's two smallest; the smallest of all is
+  // min(B, lo), the runner-up min(max(B, lo), S, mid) = med3(B, lo, min(S, mid)) because min(S, mid) >= min(B, lo)
+  auto fold3 = [](uint32_t& B, uint32_t& S, uint32_t k1, uint32_t k2, uint32_t k3) {
+    const uint32_t lo = min(min(k1, k2), k3), mid = umed3(k1, k2, k3);
+    S = umed3(B, lo, min(S, mid));
+    B = min(B, lo);
+  };
   store_row(0, 0, load_word(0));
   __syncthreads();
   for (int st = 0; st < n_st; st++) {
     const int buf = st & 1;
     uint32_t nw = 0;
     if (st + 1 < n_st) nw = load_word(st + 1);
-    v16f_t acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    v16f_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // accumulator register 4 g + j of a 32 x 32 tile belongs to database row 8 g + 4 h + j of the tile
+    v16f_t acc0, acc1;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 r0 = *(const float4*)&rowkey[buf][8 * g + 4 * h];
+      const float4 r1 = *(const float4*)&rowkey[buf][32 + 8 * g + 4 * h];
+      acc0[4 * g] = r0.x, acc0[4 * g + 1] = r0.y, acc0[4 * g + 2] = r0.z, acc0[4 * g + 3] = r0.w;
+      acc1[4 * g] = r1.x, acc1[4 * g + 1] = r1.y, acc1[4 * g + 2] = r1.z, acc1[4 * g + 3] = r1.w;
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       const v4i_t t0 = *(const v4i_t*)&tile[buf][c * MX_ROW + s * 32 + h * 16];
@@ -469,26 +488,16 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
       acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bq[s], acc0, 4, 4, 0, 127, 0, 127);
       acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[s], acc1, 4, 4, 0, 127, 0, 127);
     }
+    // 32 keys (disjoint database rows) into two independent trackers: five triples and one single key each
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const float4 rk = *(const float4*)&rowkey[buf][32 * half + 8 * g + 4 * h];
-        const float rks[4] = {rk.x, rk.y, rk.z, rk.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float av = half ? acc1[4 * g + j] : acc0[4 * g + j];
-          const uint32_t key = __float_as_uint(__builtin_fmaf(av, MX_KEY_SCALE, rks[j]));
-          if (half) {
-            skB = umed3(bB, key, skB);
-            bB = min(bB, key);
-          } else {
-            sk = umed3(b, key, sk);
-            b = min(b, key);
-          }
-        }
-      }
+    for (int t = 0; t < 5; t++) {
+      fold3(b, sk, __float_as_uint(acc0[3 * t]), __float_as_uint(acc0[3 * t + 1]), __float_as_uint(acc0[3 * t + 2]));
+      fold3(bB, skB, __float_as_uint(acc1[3 * t]), __float_as_uint(acc1[3 * t + 1]), __float_as_uint(acc1[3 * t + 2]));
     }
+    sk = umed3(b, __float_as_uint(acc0[15]), sk);
+    b = min(b, __float_as_uint(acc0[15]));
+    skB = umed3(bB, __float_as_uint(acc1[15]), skB);
+    bB = min(bB, __float_as_uint(acc1[15]));
     if (st + 1 < n_st) store_row(buf ^ 1, st + 1, nw);
     __syncthreads();
   }
@@ -501,8 +510,8 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     // float key -> (distance << KEY_SHIFT) | m; anything that is not a real row becomes KEY_INIT
     auto unpack = [&](uint32_t kb) -> uint32_t {
       if (kb >= __float_as_uint(MX_PAD_KEY_F)) return KEY_INIT;  // padded row or untouched tracker
-      const int ki = (int)__uint_as_float(kb);                   // (acc + 256) * 2048 + m, exact
-      return ((uint32_t)((ki >> 11) + pq - 256) << KEY_SHIFT) | (uint32_t)(ki & 2047);
+      const int ki = (int)(__uint_as_float(kb) * MX_KEY_SCALE);  // (512 + |d| - 2<q, d>) * 2048 + m, exact
+      return ((uint32_t)((ki >> 11) + pq - (int)MX_KEY_BIAS) << KEY_SHIFT) | (uint32_t)(ki & 2047);
     };
     const size_t o = ((size_t)pair * 2 + dir) * F + qrow;
     best_key[o] = unpack(b);
