@@ -11,6 +11,9 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as entry  # noqa: E402
 
 vsl = entry.load_package()
+import os  # noqa: E402
+if os.environ.get("VSL_SO"):  # a second build of the library (experimental kernel) for same-box comparisons
+    vsl._SO = Path(os.environ["VSL_SO"]).resolve()
 synth = importlib.import_module("visual_slam_amd.synth")
 Bu = 512
 base = np.concatenate([synth.stereo_pair_variants(100 + s, 4, margin=24) for s in range(16)])  # 64 distinct pairs
