@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
                                                                    int blocks_per_pair, const int32_t* __restrict__ sel_list,
                                                                    const int32_t* __restrict__ sel_count, int both_dirs) {
   __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
-  __shared__ __align__(16) float rowkey[2][64];  // 512 + m / 2048, or MX_PAD_KEY_F past the end: where the accumulators start
+  __shared__ __align__(16) float rowkey[64];  // last super tile only: 512 + m / 2048, or MX_PAD_KEY_F past the end
   __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
   const int xj = (int)(blockIdx.x >> 3);
   const int pair = (xj / blocks_per_pair) * 8 + (int)(blockIdx.x & 7u);
@@ -431,7 +431,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     o.w = (int)lut[w >> 24];
     return o;
   };
-  // query fragment of MFMA s (bits 64 s .. 64 s + 63): lane half h holds word 2 s + h; nibble 0x2 | (bit << 3)
+  // query fragment of MFMA s (bits 64 s .. 64 s + 63): lane half h holds word 2 s + h; nibble 0x2 | (bit << 3).
+  // An FP4 operand is the first four registers of the instruction's eight-register tuple; the other four are never
+  // read, so they stay undefined and the allocator may put anything there (written-out zeros cost 16 registers).
+  auto fp4_operand = [](v4i_t t) -> v8i_t { return __builtin_shufflevector(t, t, 0, 1, 2, 3, -1, -1, -1, -1); };
   v8i_t bq[4];
   int pq = 0;
 #pragma unroll
@@ -439,12 +442,13 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     const uint32_t w0 = qd[2 * s], w1 = qd[2 * s + 1];
     pq += __builtin_popcount(w0) + __builtin_popcount(w1);
     const v4i_t e = spread(h ? w1 : w0);
-    bq[s] = (v8i_t){(int)(((uint32_t)e.x << 2) | 0x22222222u), (int)(((uint32_t)e.y << 2) | 0x22222222u),
-                    (int)(((uint32_t)e.z << 2) | 0x22222222u), (int)(((uint32_t)e.w << 2) | 0x22222222u), 0, 0, 0, 0};
+    bq[s] = fp4_operand((v4i_t){(int)(((uint32_t)e.x << 2) | 0x22222222u), (int)(((uint32_t)e.y << 2) | 0x22222222u),
+                                (int)(((uint32_t)e.z << 2) | 0x22222222u), (int)(((uint32_t)e.w << 2) | 0x22222222u)});
   }
   // tile fill: thread t expands word (t & 7) of database row (t >> 3) of the 64-row super tile
   const bool filler = tid < 512;
   const int frow = tid >> 3, fword = tid & 7;
+  const int n_st = (n_d + 63) / 64;
   auto load_word = [&](int st) -> uint32_t {
     const int r0 = st * 64 + frow;
     return (filler && r0 < n_d) ? dbase[(size_t)r0 * 8 + fword] : 0u;
@@ -452,11 +456,11 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
   auto store_row = [&](int buf, int st, uint32_t wd) {
     if (!filler) return;
     *(v4i_t*)&tile[buf][frow * MX_ROW + fword * 16] = spread(wd);
+    // only the last super tile can hold rows past the end of the database; its accumulators start from these keys
     const int m = st * 64 + frow;
-    if (fword == 0) rowkey[buf][frow] = m < n_d ? (MX_KEY_BIAS + (float)m * (1.0f / MX_KEY_SCALE)) : MX_PAD_KEY_F;
+    if (fword == 0 && st == n_st - 1) rowkey[frow] = m < n_d ? (MX_KEY_BIAS + (float)m * (1.0f / MX_KEY_SCALE)) : MX_PAD_KEY_F;
   };
-  const int n_st = (n_d + 63) / 64;
-  uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu, bB = 0xFFFFFFFFu, skB = 0xFFFFFFFFu;
+  uint32_t b = 0xFFFFFFFFu, sk = 0xFFFFFFFFu;
   // (B <= S) <- the two smallest of {B, S, k1, k2, k3}: lo <= mid are the triple's two smallest; the smallest of all is
   // min(B, lo), the runner-up min(max(B, lo), S, mid) = med3(B, lo, min(S, mid)) because min(S, mid) >= min(B, lo)
   auto fold3 = [](uint32_t& B, uint32_t& S, uint32_t k1, uint32_t k2, uint32_t k3) {
@@ -464,45 +468,66 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     S = umed3(B, lo, min(S, mid));
     B = min(B, lo);
   };
+  // the two smallest (L <= M) of the 16 keys of one accumulator tile: five triples and one single key
+  auto tile_best2 = [&](uint32_t& L, uint32_t& M, const v16f_t& a) {
+    L = min(min(__float_as_uint(a[0]), __float_as_uint(a[1])), __float_as_uint(a[2]));
+    M = umed3(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]));
+#pragma unroll
+    for (int t = 1; t < 5; t++) fold3(L, M, __float_as_uint(a[3 * t]), __float_as_uint(a[3 * t + 1]), __float_as_uint(a[3 * t + 2]));
+    M = umed3(L, __float_as_uint(a[15]), M);
+    L = min(L, __float_as_uint(a[15]));
+  };
+  // accumulator register 4 g + j of a 32 x 32 tile belongs to database row 8 g + 4 h + j of the tile.  Every tile but
+  // the last starts from the SAME sixteen registers, 512 + (8 g + 4 h + j) / 2048 -- the matrix instruction reads them
+  // as C and writes the accumulator elsewhere, so starting a tile costs nothing -- and the tile's first row
+  // (64 st + 32 half) / 2048 is added to the tile's two smallest keys only (exact: all of it fits 21 bits).
+  v16f_t start;
+#pragma unroll
+  for (int i = 0; i < 16; i++) start[i] = MX_KEY_BIAS + (float)(8 * (i >> 2) + 4 * h + (i & 3)) * (1.0f / MX_KEY_SCALE);
   store_row(0, 0, load_word(0));
   __syncthreads();
+  float tile_first = 0.0f;  // (64 st) / 2048
   for (int st = 0; st < n_st; st++) {
     const int buf = st & 1;
     uint32_t nw = 0;
     if (st + 1 < n_st) nw = load_word(st + 1);
-    // accumulator register 4 g + j of a 32 x 32 tile belongs to database row 8 g + 4 h + j of the tile
-    v16f_t acc0, acc1;
+    // the two 32-row tiles of the super tile one after the other through ONE set of accumulators (a dependent chain of
+    // these instructions issues as fast as two interleaved ones, tools/probes/mfma_valu_coissue.hip; the second set
+    // cost 16 registers): while this wave folds a tile, the matrix pipe serves the other waves of the SIMD
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const float4 r0 = *(const float4*)&rowkey[buf][8 * g + 4 * h];
-      const float4 r1 = *(const float4*)&rowkey[buf][32 + 8 * g + 4 * h];
-      acc0[4 * g] = r0.x, acc0[4 * g + 1] = r0.y, acc0[4 * g + 2] = r0.z, acc0[4 * g + 3] = r0.w;
-      acc1[4 * g] = r1.x, acc1[4 * g + 1] = r1.y, acc1[4 * g + 2] = r1.z, acc1[4 * g + 3] = r1.w;
-    }
+    for (int half = 0; half < 2; half++) {
+      auto tile_quad = [&](int s) -> v8i_t {
+        return fp4_operand(*(const v4i_t*)&tile[buf][(c + 32 * half) * MX_ROW + s * 32 + h * 16]);
+      };
+      v16f_t acc;
+      if (st + 1 < n_st) {
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tile_quad(0), bq[0], start, 4, 4, 0, 127, 0, 127);
+      } else {
+        // last super tile: start from the keys in LDS (full row index, or the pad key for rows past the end)
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const v4i_t t0 = *(const v4i_t*)&tile[buf][c * MX_ROW + s * 32 + h * 16];
-      const v4i_t t1 = *(const v4i_t*)&tile[buf][(c + 32) * MX_ROW + s * 32 + h * 16];
-      const v8i_t a0 = {t0.x, t0.y, t0.z, t0.w, 0, 0, 0, 0};
-      const v8i_t a1 = {t1.x, t1.y, t1.z, t1.w, 0, 0, 0, 0};
-      acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bq[s], acc0, 4, 4, 0, 127, 0, 127);
-      acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bq[s], acc1, 4, 4, 0, 127, 0, 127);
-    }
-    // 32 keys (disjoint database rows) into two independent trackers: five triples and one single key each
+        for (int g = 0; g < 4; g++) {
+          const float4 r = *(const float4*)&rowkey[32 * half + 8 * g + 4 * h];
+          acc[4 * g] = r.x, acc[4 * g + 1] = r.y, acc[4 * g + 2] = r.z, acc[4 * g + 3] = r.w;
+        }
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tile_quad(0), bq[0], acc, 4, 4, 0, 127, 0, 127);
+      }
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      fold3(b, sk, __float_as_uint(acc0[3 * t]), __float_as_uint(acc0[3 * t + 1]), __float_as_uint(acc0[3 * t + 2]));
-      fold3(bB, skB, __float_as_uint(acc1[3 * t]), __float_as_uint(acc1[3 * t + 1]), __float_as_uint(acc1[3 * t + 2]));
+      for (int s = 1; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tile_quad(s), bq[s], acc, 4, 4, 0, 127, 0, 127);
+      uint32_t l, m;
+      tile_best2(l, m, acc);
+      if (st + 1 < n_st) {
+        const float first = tile_first + (float)(32 * half) / MX_KEY_SCALE;
+        l = __float_as_uint(__uint_as_float(l) + first), m = __float_as_uint(__uint_as_float(m) + first);
+      }
+      // (l, m) and (b, sk) are sorted pairs over disjoint rows
+      sk = umed3(b, l, min(sk, m));
+      b = min(b, l);
     }
-    sk = umed3(b, __float_as_uint(acc0[15]), sk);
-    b = min(b, __float_as_uint(acc0[15]));
-    skB = umed3(bB, __float_as_uint(acc1[15]), skB);
-    bB = min(bB, __float_as_uint(acc1[15]));
+    tile_first += 64.0f / MX_KEY_SCALE;
     if (st + 1 < n_st) store_row(buf ^ 1, st + 1, nw);
     __syncthreads();
   }
-  sk = min(umed3(b, bB, sk), skB);
-  b = min(b, bB);
+  // merge the two lane halves of a query column (disjoint database rows)
   const uint32_t b2 = (uint32_t)__shfl_xor((int)b, 32), s2 = (uint32_t)__shfl_xor((int)sk, 32);
   sk = min(umed3(b, b2, sk), s2);
   b = min(b, b2);
