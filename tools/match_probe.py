@@ -49,3 +49,24 @@ for var in [()] + ([tuple(knobs)] if knobs else []) + [()]:
           % (var or "default", ms / n, 2 * macs / (ms / n * 1e-3) / 1e12, 2 * macs / (ms / n * 1e-3) / 1e12 / 5000, same, nk.mean()), flush=True)
     for kv in var:
         ctx.set_diagnostic(kv[0], 0)
+
+if os.environ.get("MX_TIMING"):
+    import ctypes
+    out = (ctypes.c_longlong * 64)()
+    vsl.load().vsl_mx_timing(out)
+    for w in range(12):
+        a, b_, c_, n = out[4 * w:4 * w + 4]
+        print("wave %2d: per step (24 steps)  compute %6.0f  fill %6.0f  barrier %6.0f ticks;  whole loop %d ticks = %d wall-clock ticks (100 MHz) -> %.2f GHz"
+              % (w, a / 24, b_ / 24, c_ / 24, a + b_ + c_, n, (a + b_ + c_) / max(n, 1) * 0.1))
+
+    tl = (ctypes.c_longlong * (4 * 3072))()
+    vsl.load().vsl_mx_timeline(tl)
+    tl = np.array(tl[:], np.int64).reshape(3072, 4)
+    t0 = tl[:, 0].min()
+    ent, ls, le = (tl[:, 0] - t0) / 100.0, (tl[:, 1] - t0) / 100.0, (tl[:, 2] - t0) / 100.0
+    print("forward launch timeline (us from the first entry): last exit %.1f" % le.max())
+    for q in (0, 767, 768, 1000, 1535, 1536, 2304, 3071):
+        print("  block %4d: entry %6.1f  loop %6.1f .. %6.1f   (prologue %.1f us, loop %.1f us)  hw_id %08x" % (q, ent[q], ls[q], le[q], ls[q] - ent[q], le[q] - ls[q], tl[q, 3]))
+    print("  prologue us: mean %.1f  p10 %.1f  p90 %.1f;  loop us: mean %.1f p10 %.1f p90 %.1f" % ((ls - ent).mean(), np.percentile(ls - ent, 10), np.percentile(ls - ent, 90), (le - ls).mean(), np.percentile(le - ls, 10), np.percentile(le - ls, 90)))
+    hist, _ = np.histogram(ent, bins=16, range=(0, le.max()))
+    print("  entries per %.1f us bin:" % (le.max() / 16), hist.tolist())

@@ -376,7 +376,16 @@ __global__ __launch_bounds__(512) void match_select_kernel(const int32_t* __rest
 #ifndef MX_WAVES_PER_EU
 #define MX_WAVES_PER_EU 6
 #endif
+#ifndef MX_TIMING
+#define MX_TIMING 0
+#endif
 #define MX_OCC __attribute__((amdgpu_waves_per_eu(MX_WAVES_PER_EU, MX_WAVES_PER_EU)))
+#if MX_TIMING
+__device__ long long mx_dbg[4 * 16];
+__device__ long long mx_tl[4 * 3072];
+extern "C" int vsl_mx_timing(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx_dbg), sizeof(mx_dbg)); }
+extern "C" int vsl_mx_timeline(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx_tl), sizeof(mx_tl)); }
+#endif
 template <bool REVERSE>
 __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const uint64_t* __restrict__ desc,
                                                                    const int32_t* __restrict__ kp_count,
@@ -388,6 +397,9 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
   __shared__ __align__(16) unsigned char tile[2][64 * MX_ROW];
   __shared__ __align__(16) float rowkey[64];  // last super tile only: 512 + m / 2048, or MX_PAD_KEY_F past the end
   __shared__ uint32_t lut[256];                  // byte -> eight FP4 nibbles (bit j -> nibble j: 0x0 / 0x2)
+#if MX_TIMING
+  const long long wEntry = wall_clock64();
+#endif
   const int xj = (int)(blockIdx.x >> 3);
   const int pair = (xj / blocks_per_pair) * 8 + (int)(blockIdx.x & 7u);
   if (pair >= n_pairs) return;  // the pair count is padded to a multiple of 8
@@ -468,14 +480,22 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     S = umed3(B, lo, min(S, mid));
     B = min(B, lo);
   };
-  // the two smallest (L <= M) of the 16 keys of one accumulator tile: five triples and one single key
+  // the two smallest (L <= M) of the 16 keys of one accumulator tile, in 20 instructions: the minimum and the median of
+  // five triples (10); the two smallest of the five minima and the 16th key (7); the runner-up of the tile is either the
+  // runner-up of those six or the median of the winner's triple -- and every other median is above its own minimum, so
+  // min(runner-up of the six, smallest median) is the same thing (2 + 1)
   auto tile_best2 = [&](uint32_t& L, uint32_t& M, const v16f_t& a) {
-    L = min(min(__float_as_uint(a[0]), __float_as_uint(a[1])), __float_as_uint(a[2]));
-    M = umed3(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]));
+    uint32_t lo[5], mid[5];
 #pragma unroll
-    for (int t = 1; t < 5; t++) fold3(L, M, __float_as_uint(a[3 * t]), __float_as_uint(a[3 * t + 1]), __float_as_uint(a[3 * t + 2]));
-    M = umed3(L, __float_as_uint(a[15]), M);
-    L = min(L, __float_as_uint(a[15]));
+    for (int t = 0; t < 5; t++) {
+      const uint32_t k1 = __float_as_uint(a[3 * t]), k2 = __float_as_uint(a[3 * t + 1]), k3 = __float_as_uint(a[3 * t + 2]);
+      lo[t] = min(min(k1, k2), k3);
+      mid[t] = umed3(k1, k2, k3);
+    }
+    L = min(min(lo[0], lo[1]), lo[2]);
+    M = umed3(lo[0], lo[1], lo[2]);
+    fold3(L, M, lo[3], lo[4], __float_as_uint(a[15]));
+    M = min(M, min(min(min(mid[0], mid[1]), mid[2]), min(mid[3], mid[4])));
   };
   // accumulator register 4 g + j of a 32 x 32 tile belongs to database row 8 g + 4 h + j of the tile.  Every tile but
   // the last starts from the SAME sixteen registers, 512 + (8 g + 4 h + j) / 2048 -- the matrix instruction reads them
@@ -487,21 +507,33 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
   store_row(0, 0, load_word(0));
   __syncthreads();
   float tile_first = 0.0f;  // (64 st) / 2048
+#if MX_TIMING
+  long long tA = 0, tB = 0, tC = 0;
+  const long long w0 = wall_clock64();
+#endif
   for (int st = 0; st < n_st; st++) {
+#if MX_TIMING
+    const long long s0 = __builtin_amdgcn_s_memtime();
+#endif
     const int buf = st & 1;
     uint32_t nw = 0;
     if (st + 1 < n_st) nw = load_word(st + 1);
     // the two 32-row tiles of the super tile one after the other through ONE set of accumulators (a dependent chain of
     // these instructions issues as fast as two interleaved ones, tools/probes/mfma_valu_coissue.hip; the second set
     // cost 16 registers): while this wave folds a tile, the matrix pipe serves the other waves of the SIMD
+    // all four operand quads of a tile are requested together (one LDS round trip per tile, not one per instruction),
+    // the second tile's as soon as the first tile's instructions are issued -- they land while the first tile is folded
+    v4i_t quad[4];
+    auto request_tile = [&](int half) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) quad[s] = *(const v4i_t*)&tile[buf][(c + 32 * half) * MX_ROW + s * 32 + h * 16];
+    };
+    request_tile(0);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      auto tile_quad = [&](int s) -> v8i_t {
-        return fp4_operand(*(const v4i_t*)&tile[buf][(c + 32 * half) * MX_ROW + s * 32 + h * 16]);
-      };
       v16f_t acc;
       if (st + 1 < n_st) {
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tile_quad(0), bq[0], start, 4, 4, 0, 127, 0, 127);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(quad[0]), bq[0], start, 4, 4, 0, 127, 0, 127);
       } else {
         // last super tile: start from the keys in LDS (full row index, or the pad key for rows past the end)
 #pragma unroll
@@ -509,10 +541,11 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
           const float4 r = *(const float4*)&rowkey[32 * half + 8 * g + 4 * h];
           acc[4 * g] = r.x, acc[4 * g + 1] = r.y, acc[4 * g + 2] = r.z, acc[4 * g + 3] = r.w;
         }
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tile_quad(0), bq[0], acc, 4, 4, 0, 127, 0, 127);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(quad[0]), bq[0], acc, 4, 4, 0, 127, 0, 127);
       }
 #pragma unroll
-      for (int s = 1; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(tile_quad(s), bq[s], acc, 4, 4, 0, 127, 0, 127);
+      for (int s = 1; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(quad[s]), bq[s], acc, 4, 4, 0, 127, 0, 127);
+      if (half == 0) request_tile(1);
       uint32_t l, m;
       tile_best2(l, m, acc);
       if (st + 1 < n_st) {
@@ -524,9 +557,32 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
       b = min(b, l);
     }
     tile_first += 64.0f / MX_KEY_SCALE;
+#if MX_TIMING
+    asm volatile("" ::"v"(b), "v"(sk));
+    const long long s1 = __builtin_amdgcn_s_memtime();
+#endif
     if (st + 1 < n_st) store_row(buf ^ 1, st + 1, nw);
+#if MX_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    const long long s2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#if MX_TIMING
+    const long long s3 = __builtin_amdgcn_s_memtime();
+    tA += s1 - s0, tB += s2 - s1, tC += s3 - s2;
+#endif
   }
+#if MX_TIMING
+  if (!REVERSE && tid == 0 && blockIdx.x < 3072) {
+    mx_tl[4 * blockIdx.x] = wEntry, mx_tl[4 * blockIdx.x + 1] = w0, mx_tl[4 * blockIdx.x + 2] = wall_clock64();
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    mx_tl[4 * blockIdx.x + 3] = hw;
+  }
+  if (!REVERSE && blockIdx.x == 1000 && lane == 0) {
+    mx_dbg[4 * wave] = tA, mx_dbg[4 * wave + 1] = tB, mx_dbg[4 * wave + 2] = tC, mx_dbg[4 * wave + 3] = wall_clock64() - w0;
+  }
+#endif
   // merge the two lane halves of a query column (disjoint database rows)
   const uint32_t b2 = (uint32_t)__shfl_xor((int)b, 32), s2 = (uint32_t)__shfl_xor((int)sk, 32);
   sk = min(umed3(b, b2, sk), s2);
