@@ -66,6 +66,40 @@ def test_valu_matcher_variant_agrees(ctx, orc, synth):
             ctx.set_diagnostic("match_two_pass", 0)
 
 
+@pytest.mark.parametrize("thr,ratio", [(70, 1.2), (71, 1.2), (51, 1.5), (40, 2.0), (70, 1.0), (90, 0.9)])
+def test_match_best_and_runner_up_around_threshold_and_ratio(ctx, orc, synth, thr, ratio):
+    # Every query gets a planted best at distance d1 and a planted runner-up at distance d2, with d1 around the threshold
+    # and d2 around d1 * ratio and around (thr - 1) * ratio (products that are whole numbers included: 70 * 1.2 = 84.0);
+    # all other rows are random (distance ~128).  Same matches as the oracle in both orders of the sets, as one launch
+    # with both directions and as forward + reverse passes.
+    rng = np.random.default_rng(1000 * thr + int(10 * ratio))
+    cutoff = int(np.ceil(max(thr, (thr - 1) * ratio))) + 1
+    cases = []
+    for d1 in sorted({0, 1, thr - 2, thr - 1, thr, thr + 1, cutoff - 1, cutoff}):
+        if d1 < 0:
+            continue
+        around = {int(np.floor(d1 * ratio)) + k for k in (-1, 0, 1, 2)} | {cutoff - 2, cutoff - 1, cutoff, cutoff + 1, d1, d1 + 1}
+        cases += [(d1, d2) for d2 in sorted(around) if d1 <= d2 <= 200]
+    n1 = len(cases)
+    n2 = 1500
+    d1s = synth.random_descriptors(rng, n1)
+    d2s = synth.random_descriptors(rng, n2)
+    cols = rng.choice(n2, 2 * n1, replace=False)
+    for i, (a, b) in enumerate(cases):
+        d2s[cols[2 * i]] = synth.flip_bits(rng, d1s[i:i + 1], a)[0]
+        d2s[cols[2 * i + 1]] = synth.flip_bits(rng, d1s[i:i + 1], b)[0]
+    for x, y in ((d1s, d2s), (d2s, d1s)):
+        exp = orc.match_descriptors(x, y, thr, ratio)
+        assert len(exp) > 0 or thr < 2
+        for two_pass in (0, 1):
+            ctx.set_diagnostic("match_two_pass", two_pass)
+            try:
+                got = ctx.match_descriptors(x, y, thr, ratio)
+            finally:
+                ctx.set_diagnostic("match_two_pass", 0)
+            assert np.array_equal(got, exp), two_pass
+
+
 @pytest.mark.parametrize("n1,n2", [(2048, 2048), (2047, 2049), (2049, 100), (100, 2049)])
 def test_match_fp4_int8_kernel_boundary(ctx, orc, synth, n1, n2):
     # <= 2048 descriptors per set: block-scaled FP4 kernel (11 index bits in its f32 keys); above: the int8 kernel
