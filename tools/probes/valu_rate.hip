@@ -29,6 +29,15 @@ __global__ __launch_bounds__(256) void k(float* out, uint64_t* clk) {
       if (OP == 10) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_ge_f32 vcc, %2, %3\n v_cndmask_b32 %2, %2, %3, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");
       if (OP == 11) asm volatile("v_add_u32 %0, %0, %0\n v_add_u32 %1, %1, %1\n v_add_u32 %2, %2, %2\n v_add_u32 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
       if (OP == 12) asm volatile("v_fma_f64 %0, %0, %0, %0\n v_fma_f64 %1, %1, %1, %1\n v_fma_f64 %2, %2, %2, %2\n v_fma_f64 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+      if (OP == 14) asm volatile("v_min_u32 %0, %0, %1\n v_min_u32 %1, %1, %2\n v_min_u32 %2, %2, %3\n v_min_u32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 15) asm volatile("v_med3_u32 %0, %0, %1, %2\n v_med3_u32 %1, %1, %2, %3\n v_med3_u32 %2, %2, %3, %0\n v_med3_u32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 16) asm volatile("v_min3_u32 %0, %0, %1, %2\n v_min3_u32 %1, %1, %2, %3\n v_min3_u32 %2, %2, %3, %0\n v_min3_u32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 17) asm volatile("v_med3_u32 %0, %0, %1, %2\n v_min_u32 %1, %1, %2\n v_med3_u32 %2, %2, %3, %0\n v_min_u32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 18) asm volatile("v_max_u32 %0, %0, %1\n v_min_u32 %1, %1, %2\n v_max_u32 %2, %2, %3\n v_min_u32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 19) asm volatile("v_min_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_max_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 20) asm volatile("v_med3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_med3_f32 %2, %2, %3, %0\n v_min3_f32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 22) asm volatile("v_max_i32 %0, %0, %1\n v_min_i32 %1, %1, %2\n v_max_i32 %2, %2, %3\n v_min_i32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 23) asm volatile("v_pk_min_u16 %0, %0, %1\n v_pk_max_u16 %1, %1, %2\n v_pk_min_u16 %2, %2, %3\n v_pk_max_u16 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
       if (OP == 13) asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
     }
   }
@@ -88,5 +97,14 @@ int main() {
   run<6>("v_sqrt_f32", out, clk, blocks);
   run<9>("v_max3_f32", out, clk, blocks);
   run<10>("v_cmp+v_cndmask", out, clk, blocks);
+  run<14>("v_min_u32", out, clk, blocks);
+  run<15>("v_med3_u32", out, clk, blocks);
+  run<16>("v_min3_u32", out, clk, blocks);
+  run<17>("v_med3+v_min_u32", out, clk, blocks);
+  run<18>("v_max+v_min_u32", out, clk, blocks);
+  run<22>("v_max+v_min_i32", out, clk, blocks);
+  run<19>("v_min+v_max_f32", out, clk, blocks);
+  run<20>("v_med3+v_min3_f32", out, clk, blocks);
+  run<23>("v_pk_min/max_u16", out, clk, blocks);
   return 0;
 }

@@ -521,19 +521,14 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     // the two 32-row tiles of the super tile one after the other through ONE set of accumulators (a dependent chain of
     // these instructions issues as fast as two interleaved ones, tools/probes/mfma_valu_coissue.hip; the second set
     // cost 16 registers): while this wave folds a tile, the matrix pipe serves the other waves of the SIMD
-    // all four operand quads of a tile are requested together (one LDS round trip per tile, not one per instruction),
-    // the second tile's as soon as the first tile's instructions are issued -- they land while the first tile is folded
-    v4i_t quad[4];
-    auto request_tile = [&](int half) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) quad[s] = *(const v4i_t*)&tile[buf][(c + 32 * half) * MX_ROW + s * 32 + h * 16];
-    };
-    request_tile(0);
+    // (requesting all four operand quads of a tile ahead of its instructions bought 1 % and cost 12 registers: ten
+    // spilled registers per lane, i.e. +100 MB of scratch traffic per launch -- the quads are read one instruction ahead)
+#define MX_QUAD(half, s) fp4_operand(*(const v4i_t*)&tile[buf][(c + 32 * (half)) * MX_ROW + (s) * 32 + h * 16])
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       v16f_t acc;
       if (st + 1 < n_st) {
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(quad[0]), bq[0], start, 4, 4, 0, 127, 0, 127);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(MX_QUAD(half, 0), bq[0], start, 4, 4, 0, 127, 0, 127);
       } else {
         // last super tile: start from the keys in LDS (full row index, or the pad key for rows past the end)
 #pragma unroll
@@ -541,11 +536,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
           const float4 r = *(const float4*)&rowkey[32 * half + 8 * g + 4 * h];
           acc[4 * g] = r.x, acc[4 * g + 1] = r.y, acc[4 * g + 2] = r.z, acc[4 * g + 3] = r.w;
         }
-        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(quad[0]), bq[0], acc, 4, 4, 0, 127, 0, 127);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(MX_QUAD(half, 0), bq[0], acc, 4, 4, 0, 127, 0, 127);
       }
 #pragma unroll
-      for (int s = 1; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp4_operand(quad[s]), bq[s], acc, 4, 4, 0, 127, 0, 127);
-      if (half == 0) request_tile(1);
+      for (int s = 1; s < 4; s++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(MX_QUAD(half, s), bq[s], acc, 4, 4, 0, 127, 0, 127);
       uint32_t l, m;
       tile_best2(l, m, acc);
       if (st + 1 < n_st) {
