@@ -296,13 +296,15 @@ __global__ __launch_bounds__(64 * MM_WAVES) void hamming_mfma_kernel(const uint6
 //   the int8 form needs for K = 32 (tools/probes/fp4_mfma_probe.hip: exact on random data, 48 vs 52 ticks per
 //   dependent instruction), so the matrix-pipe time per tile halves, and so do the LDS bytes per expanded descriptor
 //   (128 B) and the registers of the query fragment.
-//   Keys stay lane-local and cost no instruction of their own: the accumulator of database row m STARTS at
-//   512 + m / 2048 (read from LDS straight into the accumulator registers), so after the four instructions of a tile it
-//   holds 512 + |d| - 2<q, d> + m / 2048 -- an exact positive f32 in [256, 769) with 11 fraction bits (21 significant
-//   bits), whose bit pattern orders like (distance, m).  best / second are v_min / v_med3 on the bits, three keys at a
-//   time (min3 + med3 give a triple's two smallest, one min + one med3 + one min fold them into the trackers: 5
-//   instructions per 3 keys where key-by-key tracking takes 6 and the separate fma a further 3); converted back to
-//   (distance << KEY_SHIFT) | m at the end.  m < 2048 is what limits this variant to 2048 database descriptors.
+//   Keys stay lane-local and cost no instruction of their own: an accumulator STARTS at 512 + row / 2048 (the C operand
+//   of a tile's first instruction: sixteen resident registers holding the row inside the tile, or, in the last super
+//   tile, keys from LDS with the full row index and a pad value), so after the four instructions of a tile it holds
+//   512 + |d| - 2<q, d> + row / 2048 -- an exact positive f32 in [256, 769) with 11 fraction bits (21 significant bits),
+//   whose bit pattern orders like (distance, row).  The two smallest of a tile's 16 keys come out of a two-level tree of
+//   v_min3 / v_med3 on the bits (20 instructions), the tile's first row is added to those two, three more instructions
+//   fold them into the lane's (best, second): 1.75 instructions per distance (DESIGN.md 8.3.1 has the measurements that
+//   led here: the tile loop runs at the vector issue rate).  Converted back to (distance << KEY_SHIFT) | m at the end;
+//   m < 2048 is what limits this variant to 2048 database descriptors.
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 #define MX_ROW 144          // LDS bytes per expanded descriptor: 128 + 16 pad
@@ -369,10 +371,13 @@ __global__ __launch_bounds__(512) void match_select_kernel(const int32_t* __rest
   if (tid == 0) sel_count[pair] = total;
 }
 
-// Occupancy target: THREE workgroups per compute unit (6 waves per SIMD: 78 VGPRs, 4 of them spilled) instead of the
-// two the compiler's own choice (107 VGPRs) allows.  A workgroup's time is set by its barrier-separated tile steps, a
-// third resident workgroup fills the gaps: 0.267 -> 0.256 ms per 512 pairs.  Measured around it: 5 waves per SIMD (84
-// VGPRs, still two workgroups) 0.278, 7 (72 VGPRs, 7 spills) 0.262-0.271, 8 (64 VGPRs, 16 spills) 0.278-0.282.
+// Occupancy target: THREE workgroups per compute unit (6 waves per SIMD = 80 VGPRs, which the kernel fills without
+// spilling -- a spilled register per lane is 6 MB of scratch stores per forward launch, and they reach HBM) instead of the
+// two the compiler's own choice allows: the tile loop is vector-issue-bound and a third workgroup keeps the issue port
+// busy across the other two's barriers.  Measured around it: 5 waves per SIMD 0.278 ms against 0.256 (first pass of
+// round 3), 7 (72 VGPRs, 10 spills) 0.230-0.234 against 0.222-0.227, 8 (64 VGPRs, 16 spills) 0.278-0.282.
+// -DMX_TIMING=1 builds the in-kernel clocks read by `MX_TIMING=1 tools/match_probe.py` (phase times of a workgroup's
+// step, the clock the chip holds, the timeline of a forward launch's workgroups).
 #ifndef MX_WAVES_PER_EU
 #define MX_WAVES_PER_EU 6
 #endif
