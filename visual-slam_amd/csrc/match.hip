@@ -512,6 +512,9 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
   store_row(0, 0, load_word(0));
   __syncthreads();
   float tile_first = 0.0f;  // (64 st) / 2048
+  // a wave whose 32 query columns all lie past the end only helps to fill the tiles (the last workgroup of a reverse
+  // pass is mostly such waves: reverse launch 68 -> 65 us)
+  const bool idle = __builtin_amdgcn_readfirstlane(q0 + wave * 32) >= n_q;
 #if MX_TIMING
   long long tA = 0, tB = 0, tC = 0;
   const long long w0 = wall_clock64();
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     // (requesting all four operand quads of a tile ahead of its instructions bought 1 % and cost 12 registers: ten
     // spilled registers per lane, i.e. +100 MB of scratch traffic per launch -- the quads are read one instruction ahead)
 #define MX_QUAD(half, s) fp4_operand(*(const v4i_t*)&tile[buf][(c + 32 * (half)) * MX_ROW + (s) * 32 + h * 16])
+    if (!idle)
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       v16f_t acc;
