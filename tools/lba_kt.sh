@@ -1,4 +1,5 @@
 R=$GRAFT_REPO_ROOT
+# kernel-time table of the local-BA probe under rocprofv3 (run on the GPU box): bash tools/lba_kt.sh
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/lbakt -- python3 $R/tools/local_ba_probe.py 7 > $R/gpurun_out/lbakt.log 2>&1
 python3 - $R/gpurun_out/lbakt <<'PY'
