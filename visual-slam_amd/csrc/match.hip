@@ -495,7 +495,10 @@ __global__ __launch_bounds__(64 * MM_WAVES) MX_OCC void hamming_mx_kernel(const 
     for (int t = 0; t < 5; t++) {
       const uint32_t k1 = __float_as_uint(a[3 * t]), k2 = __float_as_uint(a[3 * t + 1]), k3 = __float_as_uint(a[3 * t + 2]);
       lo[t] = min(min(k1, k2), k3);
-      mid[t] = umed3(k1, k2, k3);
+      // the median through the float builtin, not the inline-assembly umed3: these operands are matrix-core results,
+      // and the wait states a vector read of them needs are inserted by the compiler's hazard recogniser, which does not
+      // look inside inline assembly (all keys here are ordinary positive floats: same order as their bit patterns)
+      mid[t] = __float_as_uint(__builtin_amdgcn_fmed3f(a[3 * t], a[3 * t + 1], a[3 * t + 2]));
     }
     L = min(min(lo[0], lo[1]), lo[2]);
     M = umed3(lo[0], lo[1], lo[2]);
