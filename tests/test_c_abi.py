@@ -132,3 +132,30 @@ def test_three_host_threads_inside_the_library_concurrently(vsl, orc, synth):
     assert np.array_equal(results["frame"][2], exp_frame[2])
     assert np.array_equal(results["local"][0], exp_local[0]) and results["local"][1] == exp_local[1]   # small-system path: bit-reproducible
     assert results["global"][0] == exp_global[0] and results["global"][1] == pytest.approx(exp_global[1], rel=1e-9)
+
+
+def test_matcher_tile_kernels_do_not_spill(tmp_path):
+    """A spilled register per lane of the FP4 matcher is 6 MB of scratch stores per forward launch, and they reach HBM
+    (a build with ten spilled registers moved 225 MB per launch instead of 121).  The code object
+    metadata of both instances must say zero."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not shutil.which(hipcc):
+        pytest.skip("hipcc not installed")
+    src = ROOT / "visual-slam_amd" / "csrc" / "match.hip"
+    out = tmp_path / "match.s"
+    # the flags of visual-slam_amd/csrc/Makefile for match.o
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                    "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-I", str(ROOT / "include"), "-S", "--cuda-device-only",
+                    "-o", str(out), str(src)], check=True, capture_output=True, timeout=600)
+    meta = out.read_text().split("amdhsa.kernels:")[1]
+    seen = 0
+    for block in meta.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        if "hamming_mx_kernel" in name:
+            seen += 1
+            assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
+            assert int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1)) <= 80, name  # three workgroups per compute unit
+    assert seen == 2
