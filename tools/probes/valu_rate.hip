@@ -38,6 +38,14 @@ __global__ __launch_bounds__(256) void k(float* out, uint64_t* clk) {
       if (OP == 20) asm volatile("v_med3_f32 %0, %0, %1, %2\n v_min3_f32 %1, %1, %2, %3\n v_med3_f32 %2, %2, %3, %0\n v_min3_f32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
       if (OP == 22) asm volatile("v_max_i32 %0, %0, %1\n v_min_i32 %1, %1, %2\n v_max_i32 %2, %2, %3\n v_min_i32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
       if (OP == 23) asm volatile("v_pk_min_u16 %0, %0, %1\n v_pk_max_u16 %1, %1, %2\n v_pk_min_u16 %2, %2, %3\n v_pk_max_u16 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 24) asm volatile("v_rndne_f32 %0, %0\n v_rndne_f32 %1, %1\n v_rndne_f32 %2, %2\n v_rndne_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 25) asm volatile("v_cvt_i32_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_i32_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 26) asm volatile("v_mad_u32_u24 %0, %0, %1, %2\n v_mad_u32_u24 %1, %1, %2, %3\n v_mad_u32_u24 %2, %2, %3, %0\n v_mad_u32_u24 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 27) asm volatile("v_and_b32 %0, %0, %1\n v_lshlrev_b32 %1, 1, %2\n v_and_b32 %2, %2, %3\n v_lshlrev_b32 %3, 1, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 28) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_lt_u32 vcc, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");
+      if (OP == 29) asm volatile("v_fract_f32 %0, %0\n v_fract_f32 %1, %1\n v_fract_f32 %2, %2\n v_fract_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 30) asm volatile("v_dot4_u32_u8 %0, %0, %1, %2\n v_dot4_u32_u8 %1, %1, %2, %3\n v_dot4_u32_u8 %2, %2, %3, %0\n v_dot4_u32_u8 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      if (OP == 31) asm volatile("v_mul_f32 %0, %0, %1\n v_sub_f32 %1, %1, %2\n v_mul_f32 %2, %2, %3\n v_sub_f32 %3, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
       if (OP == 13) asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
     }
   }
@@ -106,5 +114,13 @@ int main() {
   run<19>("v_min+v_max_f32", out, clk, blocks);
   run<20>("v_med3+v_min3_f32", out, clk, blocks);
   run<23>("v_pk_min/max_u16", out, clk, blocks);
+  run<24>("v_rndne_f32", out, clk, blocks);
+  run<25>("v_cvt_i32_f32", out, clk, blocks);
+  run<26>("v_mad_u32_u24", out, clk, blocks);
+  run<27>("v_and/v_lshlrev_b32", out, clk, blocks);
+  run<28>("v_cmp_lt_u32", out, clk, blocks);
+  run<29>("v_fract_f32", out, clk, blocks);
+  run<30>("v_dot4_u32_u8", out, clk, blocks);
+  run<31>("v_mul/v_sub_f32", out, clk, blocks);
   return 0;
 }
