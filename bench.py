@@ -594,16 +594,20 @@ def main():
         # HBM traffic of that kernel per launch from the newest committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes -- see the file's note); only
         # valid for the launch size it was taken at
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             newest = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
             pm = json.loads(newest.read_text())
             if pm.get("batch_stereo_frames") == Bu and dom in pm["kernels"]:
                 traffic = pm["kernels"][dom].get("bytes_per_launch", pm["kernels"][dom].get("bytes_per_launch_uncorrected"))
+                traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at this launch "
+                                  "size, committed with the tree -- NOT collected in this run (PMC passes cannot share a "
+                                  "process with the timed loop)" % newest.name)
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "traffic_source": traffic_source,
                            "algorithmic_bytes_per_launch": int(ab),
                            "algorithmic_bytes_are": "SURVEY 8(d) detect+angle+describe: image in + 56 B per keypoint out, "
                                                     "x %d images per launch" % n_img,

@@ -55,7 +55,15 @@ inline std::string hello(const std::string& path, int r) { return path + ".hello
 inline std::string rendezvous_default_path() {
   const char* tmp = std::getenv("TMPDIR");
   const std::string dir = std::string(tmp && *tmp ? tmp : "/tmp") + "/visnav_amd." + std::to_string((long)getuid());
-  mkdir(dir.c_str(), 0700);
+  (void)mkdir(dir.c_str(), 0700);
+  // a directory somebody else planted under the shared tmp, a symlink, or one that others can write to is refused:
+  // the empty path makes the rendezvous fail with a message instead of trusting files in it
+  struct stat sb;
+  if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & 0777) != 0700) {
+    std::fprintf(stderr, "visnav_amd: %s is not a directory owned by uid %ld with mode 0700 -- refusing it for the rendezvous\n",
+                 dir.c_str(), (long)getuid());
+    return std::string();
+  }
   const char* port = std::getenv("MASTER_PORT");
   return dir + "/nccl_id." + (port ? port : "0");
 }
@@ -76,6 +84,7 @@ inline bool file_rendezvous(const std::string& path, int rank, int world, void* 
     if (err) *err = what;
     return false;
   };
+  if (path.empty()) return fail("no usable rendezvous path (the per-user directory was refused; set VISNAV_AMD_NCCL_ID_FILE)");
   if (rank == 0) {
     file_rendezvous_cleanup(path, world);  // nothing of an earlier run survives rank 0's start
     std::vector<uint64_t> nonces(world, 0);

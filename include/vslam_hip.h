@@ -199,6 +199,9 @@ int vsl_frames_detect_describe(vsl_ctx* ctx, vsl_frames* f, int first, int n, in
  * Download calls do this implicitly; call it between vsl_frames_detect_describe and
  * vsl_frames_match when the match must see the patched bits. */
 int vsl_frames_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resolved);
+/* Diagnostic: how many times this store redid described ranges with the f64 kernel because an image's exact-rounding
+ * list overflowed (0 in normal operation; tests shrink "exact_list_cap" to get there). */
+int vsl_frames_exact_fallbacks(const vsl_frames* f);
 /* Diagnostic knob: width of that guard band (default 1e-12; tests widen it to exercise the path). */
 int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
 /* Diagnostic knobs for the parity tests (results never change, only which kernel path produces them):
@@ -219,6 +222,10 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "bow_keys64" (0/1)              vocabulary transform with 64-bit (id, feature) sort keys where 32 bits would do
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
  *                                   detected at the next synchronisation and the range is redone by the f64 kernel
+ *   "vo_chain_ticket" (0/1)         vsl_map_track: chain positions of the projection workgroups from an atomic ticket
+ *                                   (the rule for maps above 262 k landmarks) at every map size
+ *   "pending_desc_max" (default 64) describe launches a frame store queues without a resolve before it resolves them
+ *                                   itself (the launch that crosses the limit included)
  *   "select_bucket_cap" (default 128) fullest response bin the selection kernel's counting sort accepts; 0 = always
  *                                   the bitonic network */
 int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value);

@@ -54,6 +54,27 @@ def test_pmc_traffic_profile_matches_the_bench_launch_size():
     assert abs(k["bytes_per_launch"] - want) < 1e-3 * want
 
 
+def test_sq_counter_summaries_hold_physically_possible_values():
+    # a summary that folded two kernels into one row carried 53.6 resident waves per SIMD (the
+    # hardware holds 8) and 0.55 SIMD-cycles per vector instruction (a SIMD issues at most one per cycle).  Every
+    # committed summary from round 4 on is checked; the tool asserts the same when it writes one.
+    for p in sorted((ROOT / "profiles").glob("r*_sq_counters.json")):
+        if int(p.name[1:3]) < 4:
+            continue
+        doc = json.loads(p.read_text())
+        for name, k in doc["kernels"].items():
+            assert k.get("mean_resident_waves_per_simd", 0) <= 8.4, (p.name, name, k)
+            assert k.get("simd_cycles_per_valu_instruction", 9) >= 1.0, (p.name, name, k)
+    sys.path.insert(0, str(ROOT / "tools"))
+    import frame_sq_summary as fs
+    # whole kernel names: no substring hits across kernels, the two matcher instances apart
+    assert fs.row_name("(anonymous namespace)::match_select_kernel(int const*, int const*)") == "match_select"
+    assert fs.row_name("void select_kernel<false>(unsigned long const*, int*)") == "select"
+    assert fs.row_name("void hamming_mx_kernel<true>(unsigned long const*)") == "match_reverse"
+    assert fs.row_name("void hamming_mx_kernel<false>(unsigned long const*)") == "match_forward"
+    assert fs.row_name("exact_bits_kernel(unsigned char const*)") is None
+
+
 def test_bench_command_line_accepts_the_driver_flags():
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0

@@ -218,6 +218,44 @@ def test_overflow_in_an_earlier_range_is_redone_at_the_one_resolve(ctx, orc, vsl
     fr.close()
 
 
+def test_overflow_in_the_launch_that_forces_the_resolve_is_redone(ctx, orc, vsl, images):
+    # a caller that never resolves makes the frame store settle its queue by itself after 64
+    # launches.  That forced resolve used to run BEFORE the launch that triggered it was queued, so an exact-list
+    # overflow of that very launch was cleared together with the older ranges and its bits stayed unverified.  66
+    # unresolved launches on one slot, the 65th (the one that crosses the limit) with a list too small for its samples.
+    img = images["left"]
+    fr = vsl.Frames(ctx, 2, 752, 480, 1500, max_pairs=1)
+    fr.upload(0, np.stack([img, images["right"]]))
+    want = orc.detect_describe(img, 1500, True)[2]
+    try:
+        for k in range(66):
+            ctx.set_diagnostic("exact_list_cap", 0 if k == 64 else 16384)
+            fr.detect_describe(0, 1, 1500, True)
+            if k == 64:   # the forced resolve has run inside this call: slot 0 must be exact already
+                assert fr.exact_fallbacks() >= 1
+    finally:
+        ctx.set_diagnostic("exact_list_cap", 16384)
+    fr.resolve_ties()
+    assert np.array_equal(fr.keypoints(0)[2], want)
+    # and with the limit lowered the same thing after three launches, overflow in the last one
+    fr2 = vsl.Frames(ctx, 2, 752, 480, 1500, max_pairs=1)
+    fr2.upload(0, np.stack([images["right"], img]))
+    ctx.set_diagnostic("pending_desc_max", 2)
+    try:
+        fr2.detect_describe(0, 1, 1500, True)
+        fr2.detect_describe(1, 1, 1500, True)
+        ctx.set_diagnostic("exact_list_cap", 0)
+        n0 = fr2.exact_fallbacks()
+        fr2.detect_describe(1, 1, 1500, True)
+        assert fr2.exact_fallbacks() == n0 + 1
+    finally:
+        ctx.set_diagnostic("exact_list_cap", 16384)
+        ctx.set_diagnostic("pending_desc_max", 64)
+    assert np.array_equal(fr2.keypoints(1)[2], want)
+    fr.close()
+    fr2.close()
+
+
 def test_async_upload_and_event_handoff(ctx, orc, vsl, synth):
     # the streaming primitives of bench.py: a second context uploads into the idle one of two frame stores while the
     # first context computes on the other; vsl_event orders upload -> compute -> next upload on the device

@@ -216,6 +216,15 @@ def test_map_track_resolves_pending_ties_and_large_maps(vsl, ctx, orc, synth):
     for _ in range(3):
         got, n_proj = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
         assert n_proj == len(uv) and np.array_equal(got, exp)
+    # chain positions drawn from the atomic ticket (the rule above 256 workgroups = 262 k landmarks, forced here at
+    # 40 workgroups): same ordered output, call after call (the ticket word resets itself)
+    ctx.set_diagnostic("vo_chain_ticket", 1)
+    try:
+        for _ in range(3):
+            got, n_proj = m.track(fr, 0, pose, model, intr, 752, 480, 0.1, 20.0, 70, 1.2)
+            assert n_proj == len(uv) and np.array_equal(got, exp)
+    finally:
+        ctx.set_diagnostic("vo_chain_ticket", 0)
     left = synth.stereo_pair(6)[0]
     ctx.set_tie_eps(1e-3)   # ~1e-3 of the samples become "near ties": pending when track is called
     try:

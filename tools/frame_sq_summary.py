@@ -14,8 +14,36 @@ import pathlib
 import sys
 from collections import defaultdict
 
+import re
+
+# WHOLE kernel names (namespace / return type / parameter list stripped, template arguments kept): substring matching
+# used to fold match_select_kernel into "select" and both hamming_mx_kernel instances into one row
 NAMES = {"min_eig_response_kernel": "response", "select_kernel": "select", "describe_tile_kernel": "describe",
-         "hamming_mx_kernel": "match"}
+         "hamming_mx_kernel<false>": "match_forward", "hamming_mx_kernel<true>": "match_reverse",
+         "match_select_kernel": "match_select"}
+MAX_WAVES_PER_SIMD = 8   # gfx950: a figure above it means two kernels were folded into one row
+
+
+def kernel_id(full):
+    """'void (anonymous namespace)::hamming_mx_kernel<true>(unsigned long const*, ...)' -> 'hamming_mx_kernel<true>'."""
+    s = full.strip().strip('"')
+    depth, cut = 0, len(s)
+    for i, ch in enumerate(s):          # the parameter list starts at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and not s.startswith("(anonymous namespace)", i):
+            cut = i
+            break
+    s = s[:cut].replace("(anonymous namespace)::", "")
+    s = re.sub(r"^(void|int)\s+", "", s.strip())
+    return s.split("::")[-1].replace(" ", "")
+
+
+def row_name(full):
+    kid = kernel_id(full)     # with template arguments first (the two matcher instances), then the bare name
+    return NAMES.get(kid) or NAMES.get(kid.split("<")[0])
 
 
 def main():
@@ -24,15 +52,15 @@ def main():
     for f in (root / "fsq").rglob("*counter_collection.csv"):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                for key, name in NAMES.items():
-                    if key in row["Kernel_Name"]:
-                        acc[name][row["Counter_Name"]][(str(f), row["Dispatch_Id"])] += float(row["Counter_Value"])
+                name = row_name(row["Kernel_Name"])
+                if name:
+                    acc[name][row["Counter_Name"]][(str(f), row["Dispatch_Id"])] += float(row["Counter_Value"])
     dur = {}
     for f in (root / "kt1").rglob("*kernel_stats.csv"):
         for row in csv.DictReader(open(f, newline="")):
-            for key, name in NAMES.items():
-                if key in row["Name"]:
-                    dur[name] = float(row["AverageNs"])
+            name = row_name(row["Name"])
+            if name:
+                dur[name] = float(row["AverageNs"])
     doc = {"note": __doc__.split("->")[1].strip(), "clock_ghz_assumed": 2.4, "kernels": {}}
     for name, ctrs in acc.items():
         k = {c: round(sum(d.values()) / len(d) / 1e6, 3) for c, d in sorted(ctrs.items())}
@@ -44,6 +72,7 @@ def main():
                 k["simd_cycles_per_valu_instruction"] = round(cyc / k["SQ_INSTS_VALU"], 2)
             if "SQ_WAVE_CYCLES" in k:
                 k["mean_resident_waves_per_simd"] = round(4 * k["SQ_WAVE_CYCLES"] / cyc, 2)
+                assert k["mean_resident_waves_per_simd"] <= MAX_WAVES_PER_SIMD * 1.05, (name, k)
         if "SQ_WAVE_CYCLES" in k and k["SQ_WAVE_CYCLES"] > 0:
             for c, label in (("SQ_WAIT_INST_ANY", "wave_time_waiting_share"), ("SQ_ACTIVE_INST_VALU", "wave_time_valu_share"),
                              ("SQ_ACTIVE_INST_LDS", "wave_time_lds_share")):

@@ -663,6 +663,9 @@ class Frames:
         self.ctx._ck(self.ctx.L.vsl_frames_resolve_ties(self.ctx.h, self.h, C.byref(n)))
         return n.value
 
+    def exact_fallbacks(self):
+        return int(self.ctx.L.vsl_frames_exact_fallbacks(self.h))
+
     def match(self, slot_pairs, threshold=70, dist_2_best=1.2):
         sp = np.ascontiguousarray(slot_pairs, np.int32).reshape(-1, 2)
         self.ctx._ck(self.ctx.L.vsl_frames_match(self.ctx.h, self.h, sp.ctypes.data_as(i32p), len(sp),

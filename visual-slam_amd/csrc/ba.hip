@@ -2735,15 +2735,13 @@ extern "C" int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob
   rc = vsl_ba_session_create(ctx, prob, opt, first, count, &s);
   if (world > 1 && allreduce) {
     // rank-local failures (allocation, a bad range) are agreed on BEFORE the first data collective: MAX of a flag
-    double* flag = nullptr;
-    int frc = vsl_ctx_dscratch(ctx, 64, (void**)&flag);
-    const double mine = (rc || frc) ? 1.0 : 0.0;
+    double* flag = ctx->status_word;  // allocated with the context: never null, so the collective is always entered
+    int frc = 0;
+    const double mine = rc ? 1.0 : 0.0;
     double any = mine;
-    if (!frc) {
-      if (hipMemcpyAsync(flag, &mine, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) frc = VSL_ERR_HIP;
-    }
-    // (a rank that cannot even stage the flag still enters the collective with whatever the buffer holds: it is
-    // about to fail anyway and must not leave the others hanging)
+    if (hipMemcpyAsync(flag, &mine, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) frc = VSL_ERR_HIP;
+    // (a rank that cannot stage the flag still enters the collective with whatever the word holds: it is about to
+    // fail anyway and must not leave the others hanging)
     const int arc = allreduce(user, flag, 1, 1, (void*)ctx->stream);
     if (!arc && !frc && hipMemcpyAsync(&any, flag, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess)
       (void)hipStreamSynchronize(ctx->stream);

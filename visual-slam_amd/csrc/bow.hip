@@ -749,10 +749,9 @@ static int bow_score_launch(vsl_ctx* ctx, const uint32_t* q_ids, const double* q
       while (P < q_nnz + 1) P <<= 1;  // at least one 0xFFFFFFFF sentinel behind the query
       const size_t lds = 8 * (size_t)((q_nnz + 1) & ~1) + 4 * (size_t)P;
       if (lds > 64 * 1024) {
-        static bool attr_set = false;  // raising the limit is idempotent; racing threads set the same value
-        if (!attr_set) {
+        if (!ctx->bow_score_attr_set) {  // per context = per device (the attribute is a per-device setting)
           VSL_HIP(ctx, hipFuncSetAttribute((const void*)bow_score_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-          attr_set = true;
+          ctx->bow_score_attr_set = true;
         }
       }
       hipLaunchKernelGGL(bow_score_lds_kernel, dim3((m + 3) / 4), dim3(256), lds, ctx->stream, dqi, dqv, q_nnz, P, c_ids_dev,

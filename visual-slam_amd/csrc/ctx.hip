@@ -53,6 +53,13 @@ static int ctx_create_impl(int device, void* stream, bool borrow, vsl_ctx** out)
     }
     c->owns_stream = true;
   }
+  // the flag word of rank status exchanges lives as long as the context: a rank whose later allocations fail can still
+  // enter the agreement collective with a valid buffer (ba.hip, vsl_global_bundle_adjust)
+  if (hipMalloc((void**)&c->status_word, 64) != hipSuccess) {
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return vsl_fail(nullptr, VSL_ERR_NOMEM, "hipMalloc of the context's status word failed");
+  }
   *out = c;
   return VSL_OK;
 }
@@ -74,6 +81,7 @@ extern "C" int vsl_ctx_destroy(vsl_ctx* ctx) {
   }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+  if (ctx->status_word) (void)hipFree(ctx->status_word);
   if (ctx->bcr_jobs) (void)hipFree(ctx->bcr_jobs);
   if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
   if (ctx->hpinned) (void)hipHostFree(ctx->hpinned);
@@ -421,7 +429,7 @@ extern "C" int vsl_frames_download_keypoints(vsl_ctx* ctx, vsl_frames* f, int sl
         VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
       }
     } else {
-      f->ties_pending = false;
+      f->ties_settled();
     }
   }
   const int n = hdr[1];

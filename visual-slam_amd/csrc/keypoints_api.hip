@@ -22,6 +22,8 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "match_two_pass") ctx->match_two_pass = value != 0;
   else if (k == "k1_list_cap") ctx->k1_list_cap = value;
   else if (k == "exact_list_cap") ctx->exact_list_cap = value;
+  else if (k == "vo_chain_ticket") ctx->vo_chain_ticket = value;
+  else if (k == "pending_desc_max") ctx->pending_desc_max = value < 1 ? 1 : value;
   else if (k == "ba_schur_entries") ctx->ba_schur_entries = value != 0;
   else if (k == "ba_schur_atomics") ctx->ba_schur_atomics = value != 0;
   else if (k == "ba_force_dense") ctx->ba_force_dense = value != 0;
@@ -47,6 +49,10 @@ extern "C" int vsl_frames_resolve_ties(vsl_ctx* ctx, vsl_frames* f, int* n_resol
   if (!ctx || !f) return VSL_ERR_INVALID;
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   return vsl_resolve_ties(ctx, f, n_resolved);
+}
+
+extern "C" int vsl_frames_exact_fallbacks(const vsl_frames* f) {
+  return f ? f->exact_fallbacks : VSL_ERR_INVALID;
 }
 
 static int check_image(vsl_ctx* ctx, const uint8_t* img, int w, int h, size_t pitch) {
@@ -109,7 +115,7 @@ extern "C" int vsl_compute_angles(vsl_ctx* ctx, const uint8_t* img, int w, int h
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((rc = upload_corners(ctx, f, corners_xy, n))) return rc;
   if ((rc = vsl_launch_describe(ctx, f, 0, 1, rotate_features, 0))) return rc;
-  f->ties_pending = false;  // descriptors of this call are not returned
+  f->ties_settled();  // descriptors of this call are not returned
   VSL_HIP(ctx, hipMemsetAsync(f->tie_count, 0, sizeof(int32_t), ctx->stream));
   int n_out = 0;
   std::vector<double> xy(2 * (size_t)n);

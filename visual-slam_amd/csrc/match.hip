@@ -10,12 +10,17 @@
 //   (i, j = best(i)) is a match iff row i passes in direction a->b, column j passes in direction
 //   b->a and best_{b->a}(j) == i.  Matches are emitted in ascending i.
 //
-// Kernel design (gfx950): a 64-row tile per workgroup, one ROW per LANE (its 256-bit descriptor sits
-// in 8 VGPRs), columns split over the workgroup's waves.  A column descriptor is wave-uniform, so it
-// is fetched with scalar loads and used as SGPR operands of v_xor / v_bcnt -- no LDS traffic and no
-// cross-lane work in the inner loop.  (distance << 23 | column) is one 32-bit key: min() keeps the
-// best with the lowest-index tie-break, med3() keeps the runner-up.  Per-wave partials are merged
-// through LDS in column order.  Both directions and all pairs of a batch are one launch.
+// Kernels in this file, in the order a reader meets them:
+//   hamming_best2_kernel  the VALU popcount form (v_xor / v_bcnt on scalar-loaded columns, one row per lane): the
+//                         diagnostic third implementation ("match_use_valu"), kept as a cross-check of the other two;
+//   hamming_mfma_kernel   int8 matrix-core form, any descriptor count ("match_use_i8"; the default above 2048);
+//   hamming_mx_kernel     THE DEFAULT (<= 2048 descriptors per image): the Hamming matrix as exact 0 / +-1 products on
+//                         v_mfma_scale_f32_32x32x64_f8f6f4 (FP4, unit block scales), the accumulator started at the
+//                         ordered key 512 + row / 2048 so that a result register IS (distance, row) -- see the comment
+//                         block above it.  Launches of >= 8 pairs compute the matrix ONCE: forward pass a -> b,
+//                         match_select_kernel lists the columns some passing row points at, the <REVERSE> instance
+//                         scans those columns only (the reference's own order, keypoints.h:355-362);
+//   match_finalize_kernel threshold / ratio / cross-check and the ordered match list.
 //
 // Algorithmic bytes per pair: (n_a + n_b) * 32 B read + 8 B per match written.
 #include "vsl_common.h"

@@ -128,8 +128,13 @@ __global__ __launch_bounds__(1024) void compact_projection_kernel(const double* 
 // project_landmarks + the order-preserving compaction in ONE launch (vsl_map_track): a workgroup projects 1024 landmarks,
 // compacts them in landmark order, and takes its base offset from the chain of its predecessors' totals ("stream
 // scan": block b waits for block b - 1's running total, published as one 64-bit word (epoch << 32 | total) with
-// release / acquire at device scope -- no flags to reset between calls, the epoch changes).  Workgroups are dispatched
-// in index order and a map of 100 k landmarks is 100 workgroups on 256 compute units: a predecessor is always resident.
+// release / acquire at device scope -- no flags to reset between calls, the epoch changes).  Forward progress of the
+// wait: up to VO_CHAIN_RESIDENT_BLOCKS workgroups (one per compute unit: every one of them is resident from the start)
+// the hardware's index-order dispatch makes blockIdx the chain position; larger maps (> 262 k landmarks) draw their
+// chain position from an atomic ticket instead, so a workgroup only ever waits for workgroups that have STARTED --
+// the decoupled look-back rule -- whatever the dispatch order (the ticket word is reset by the workgroup that draws
+// the last one).
+#define VO_CHAIN_RESIDENT_BLOCKS 256
 struct PoseIntr {
   double v[16];  // pose (qx qy qz qw tx ty tz, pad) | intrinsics (8)
 };
@@ -137,10 +142,21 @@ __global__ __launch_bounds__(1024) void project_compact_kernel(PoseIntr pi, int 
                                                                const double* __restrict__ points, int n, double z_thr,
                                                                double* __restrict__ out_uv, int32_t* __restrict__ out_idx,
                                                                int32_t* __restrict__ n_out, unsigned long long* __restrict__ chain,
-                                                               unsigned int epoch) {
+                                                               unsigned int epoch, unsigned int* __restrict__ ticket) {
   __shared__ int wave_tot[16];
   __shared__ int base_s;
-  const int i = blockIdx.x * 1024 + threadIdx.x;
+  __shared__ unsigned int bid_s;
+  unsigned int bid = blockIdx.x;
+  if (ticket) {  // workgroup-uniform
+    if (threadIdx.x == 0) {
+      const unsigned int t = atomicAdd(ticket, 1u);
+      if (t == gridDim.x - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all drawn: ready for the next call
+      bid_s = t;
+    }
+    __syncthreads();
+    bid = bid_s;
+  }
+  const int i = (int)bid * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   bool ok = false;
   double u = 0, v = 0;
@@ -166,16 +182,16 @@ __global__ __launch_bounds__(1024) void project_compact_kernel(PoseIntr pi, int 
     int total = 0;
     for (int w = 0; w < 16; w++) total += wave_tot[w];
     unsigned long long prev = 0;
-    if (blockIdx.x > 0) {
+    if (bid > 0) {
       do {
-        prev = __hip_atomic_load(&chain[blockIdx.x - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        prev = __hip_atomic_load(&chain[bid - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       } while ((unsigned int)(prev >> 32) != epoch);
     }
     const int base = (int)(unsigned int)prev;
-    __hip_atomic_store(&chain[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned int)(base + total), __ATOMIC_RELEASE,
+    __hip_atomic_store(&chain[bid], ((unsigned long long)epoch << 32) | (unsigned int)(base + total), __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_AGENT);
     base_s = base;
-    if (blockIdx.x == gridDim.x - 1) *n_out = base + total;
+    if (bid == gridDim.x - 1) *n_out = base + total;
   }
   __syncthreads();
   if (ok) {
@@ -708,8 +724,11 @@ extern "C" int vsl_map_track_corners(vsl_map* m, vsl_frames* f, int slot, const 
     VSL_HIP(ctx, hipMemsetAsync(m->chain, 0, 8 * (size_t)m->chain_cap, ctx->stream));
     m->epoch = 1;
   }
+  // chain position = blockIdx while every workgroup is resident from the start, an atomic ticket beyond (kernel header);
+  // the ticket word is the last word of the chain allocation (zero between calls)
+  unsigned int* ticket = (n_blocks > VO_CHAIN_RESIDENT_BLOCKS || ctx->vo_chain_ticket) ? (unsigned int*)(m->chain + (m->chain_cap - 1)) : nullptr;
   hipLaunchKernelGGL(project_compact_kernel, dim3(n_blocks), dim3(1024), 0, ctx->stream, pi, cam_model, width, height, m->points, n,
-                     cam_z_threshold, m->out_uv, m->out_idx, m->counters, m->chain, m->epoch);
+                     cam_z_threshold, m->out_uv, m->out_idx, m->counters, m->chain, m->epoch, ticket);
   int32_t* mail = m->mailbox;
   const double max_dist_sq = sqrt_less_threshold(match_max_dist_2d);
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -725,7 +744,7 @@ extern "C" int vsl_map_track_corners(vsl_map* m, vsl_frames* f, int slot, const 
     // ties the usual way and match once more.
     if (!f->ties_pending) break;
     if (mail[1] == 0) {
-      f->ties_pending = false;
+      f->ties_settled();
       break;
     }
     if ((rc = vsl_resolve_ties(ctx, f, nullptr))) return rc;

@@ -62,6 +62,8 @@ struct vsl_ctx {
   size_t ba_arena_cap = 0;
   bool ba_arena_busy = false;
   bool select_attr_set = false;
+  bool bow_score_attr_set = false;  // per context, hence per device: hipFuncSetAttribute is a per-device setting
+  double* status_word = nullptr;    // 64 device bytes allocated with the context: the flag of status exchanges between ranks (never null in a live context)
   double tie_eps = 1e-12;  // rBRIEF near-tie guard band (describe.hip)
   bool match_use_i8 = false;            // diagnostic: int8 matrix-core matcher even where the FP4 one applies (<= 2048 features)
   bool match_no_stagger = false;        // diagnostic: all waves of a matcher workgroup in the same phase order (the pre-stagger kernel)
@@ -77,6 +79,8 @@ struct vsl_ctx {
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int describe_tile_min_images = 96;   // describe launches of at least this many images use the shared-tile kernel (measured break-even ~64 images; diagnostic: 1 forces it, 0 disables it)
   bool bow_keys64 = false;              // diagnostic: 64-bit sort keys in the BowVector assembly even where (id, feature) fits 32 bits
+  int vo_chain_ticket = 0;              // diagnostic: vsl_map_track draws chain positions from the atomic ticket at every map size
+  int pending_desc_max = 64;            // unresolved describe launches a frame store queues before it settles them itself (diagnostic: tests lower it)
   int exact_list_cap = VSL_EXACT_CAP;   // diagnostic: per-image exact-rounding list entries the describe kernels use (tests shrink it to hit the overflow fallback)
   int k1_list_cap = -1;                // diagnostic: per-wave LDS candidate slots in K1 (tests shrink it to hit the overflow path)
 };
@@ -151,6 +155,12 @@ struct vsl_frames {
     int first, n, rotate;
   };
   std::vector<DescRange> pending_desc;
+  // the guard's count was read as zero (or the descriptors are not handed out): nothing queued is left to verify.
+  // Every fast path that skips vsl_resolve_ties ends here, so stale ranges do not pile up frame after frame.
+  void ties_settled() {
+    ties_pending = false;
+    pending_desc.clear();
+  }
   int exact_fallbacks = 0;            // how often that fallback ran (diagnostic)
   bool store_response = false;  // K1 writes the fp32 response image only for the parity hook
   std::vector<int32_t> pair_cache;  // host copy of pair_slots (skip the upload when unchanged)
