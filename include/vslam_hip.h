@@ -218,6 +218,8 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "chol_one_ended" (0/1)          narrow-band Cholesky eliminated from the top only instead of from both ends
  *   "ba_force_dense" (0/1)          large bundle adjustment with the dense reduced camera system (no band ordering)
  *   "ba_schur_atomics" (0/1)        large-system Schur complement by fp64 atomics instead of the per-block gather
+ *   "ba_no_fused" (0/1)             local windows (<= 21 free cameras) by the operator-by-operator kernels instead of the
+ *                                   fused four-launch iteration (ba_fused.hip)
  *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks
  *   "bow_keys64" (0/1)              vocabulary transform with 64-bit (id, feature) sort keys where 32 bits would do
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is

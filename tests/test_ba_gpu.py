@@ -98,12 +98,14 @@ def test_schur_small_kernel_variants_at_local_ba_sizes(ctx, orc, synth, n_kf, n_
     arr = _arr(orc, d)
     assert 6 * arr.n_free == n
     ctx.set_diagnostic("ba_schur_entries", entries)
+    ctx.set_diagnostic("ba_no_fused", 1)   # the operator-by-operator kernels of ba.hip (the fused iteration has its own test)
     try:
         S, g, c = ctx.ba_linearize(arr)
         a_gpu = _arr(orc, d)
         s_gpu = ctx.bundle_adjust(a_gpu, max_iters=5)
     finally:
         ctx.set_diagnostic("ba_schur_entries", 0)
+        ctx.set_diagnostic("ba_no_fused", 0)
     eS, eg, ec = orc.ba_linearize(arr)
     assert c == pytest.approx(ec, rel=1e-12)
     assert np.allclose(S, eS, rtol=0, atol=1e-9 * np.abs(eS).max())
@@ -114,6 +116,77 @@ def test_schur_small_kernel_variants_at_local_ba_sizes(ctx, orc, synth, n_kf, n_
     assert s_gpu.iterations == s_cpu.iterations
     assert s_gpu.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
     assert np.allclose(a_gpu.poses, a_cpu.poses, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_kf,n_fixed_cams,n,n_lms", [(7, 2, 72, 1237), (10, 2, 108, 1237), (11, 1, 126, 1237), (2, 3, 6, 400),
+                                                       (4, 3, 30, 60), (9, 2, 96, 2500), (6, 4, 48, 3000), (8, 1, 90, 5000)])
+def test_fused_iteration_at_window_sizes(ctx, orc, synth, n_kf, n_fixed_cams, n, n_lms):
+    # ba_fused.hip: the four-launch LM iteration (Schur tiles on the f64 matrix unit, DPP / MFMA Cholesky with the
+    # right-hand side as an extra row).  Reduced systems from 6 to 126 unknowns -- 1, 2 and 3 tiles per wavefront, padded
+    # sizes that are and are not multiples of 16 (48, 96: the right-hand-side row opens a tile row of its own), ragged
+    # last chunks, a workgroup with fewer landmarks than a chunk -- against the oracle AND against the
+    # operator-by-operator path of ba.hip, same LM trajectory.
+    d = synth.ba_problem(300 + n, n_kf=n_kf, n_lms=n_lms)
+    d["cam_fixed"][:] = 0
+    d["cam_fixed"][:n_fixed_cams] = 1
+    a_f, a_o, a_cpu = _arr(orc, d), _arr(orc, d), _arr(orc, d)
+    assert 6 * a_f.n_free == n
+    s_f = ctx.bundle_adjust(a_f, max_iters=8)
+    ctx.set_diagnostic("ba_no_fused", 1)
+    try:
+        s_o = ctx.bundle_adjust(a_o, max_iters=8)
+    finally:
+        ctx.set_diagnostic("ba_no_fused", 0)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=8)
+    for s in (s_f, s_o):
+        assert s.initial_cost == pytest.approx(s_cpu.initial_cost, rel=1e-12)
+        assert (s.iterations, s.termination, s.successful_steps) == (s_cpu.iterations, s_cpu.termination, s_cpu.successful_steps)
+        assert s.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
+    # landmarks with two observations (one stereo pair) have a nearly unconstrained depth: after 8 iterations they follow
+    # the summation order (at n = 96 three of 1939 differ from the oracle by 9e-6 on the ba.hip path, 3e-5 on this one,
+    # with poses equal to 2e-13 and costs to 1e-15) -- 1e-6 where a third observation pins the depth, 1e-4 for all
+    well = np.bincount(d["obs_lm"], minlength=len(d["points"])) >= 3
+    for a in (a_f, a_o):
+        assert np.allclose(a.poses, a_cpu.poses, rtol=0, atol=1e-9)
+        assert np.allclose(a.points[well], a_cpu.points[well], rtol=0, atol=1e-6)
+        assert np.allclose(a.points, a_cpu.points, rtol=0, atol=1e-4)
+    fixed = d["cam_fixed"].astype(bool)
+    assert np.array_equal(a_f.poses[fixed], d["poses"][fixed])
+
+
+def test_fused_iteration_edge_cases(ctx, orc, synth):
+    # (a) landmarks without any observation and landmarks seen by fixed cameras only ride along untouched / move by
+    # their own 3 x 3 block; (b) a solved problem: the same (early) termination as the oracle;
+    # (c) a problem the fused kernels do not take (more than 64 cameras) falls through to ba.hip
+    d = synth.ba_problem(77, n_kf=5, n_lms=800, outlier_frac=0.0)
+    keep = np.ones(len(d["obs_lm"]), bool)
+    keep[d["obs_lm"] % 17 == 3] = False                                    # these landmarks lose all observations
+    keep[(d["obs_lm"] % 17 == 5) & (d["obs_cam"] >= 2)] = False            # these keep the fixed cameras' only
+    for k in ("obs_cam", "obs_lm"):
+        d[k] = d[k][keep]
+    d["obs_uv"] = d["obs_uv"][keep]
+    a_f, a_cpu = _arr(orc, d), _arr(orc, d)
+    s_f = ctx.bundle_adjust(a_f, max_iters=10)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=10)
+    assert (s_f.iterations, s_f.termination) == (s_cpu.iterations, s_cpu.termination)
+    assert s_f.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
+    assert np.allclose(a_f.points, a_cpu.points, rtol=0, atol=1e-6)
+    lost = np.arange(len(d["points"])) % 17 == 3
+    assert np.array_equal(a_f.points[lost], d["points"][lost])
+    # (b)
+    a2, a2c = _arr(orc, d), _arr(orc, d)
+    a2.poses[:], a2.points[:] = a_cpu.poses, a_cpu.points
+    a2c.poses[:], a2c.points[:] = a_cpu.poses, a_cpu.points
+    s2, s2c = ctx.bundle_adjust(a2, max_iters=5), orc.bundle_adjust(a2c, max_iters=5)
+    assert (s2.iterations, s2.termination) == (s2c.iterations, s2c.termination)
+    # (c) 66 cameras (60 of them fixed): more than the fused kernels keep in LDS
+    d3 = synth.ba_problem(78, n_kf=33, n_lms=600)
+    d3["cam_fixed"][:] = 0
+    d3["cam_fixed"][:60] = 1
+    a3, a3c = _arr(orc, d3), _arr(orc, d3)
+    assert a3.n_free == 6
+    s3, s3c = ctx.bundle_adjust(a3, max_iters=6), orc.bundle_adjust(a3c, max_iters=6)
+    assert s3.iterations == s3c.iterations and s3.final_cost == pytest.approx(s3c.final_cost, rel=1e-7)
 
 
 def test_linearize_partition_is_additive(ctx, orc, synth):

@@ -1,0 +1,1344 @@
+// ba_fused.hip -- the local-window bundle adjustment (6 * free cameras <= 126 unknowns after the Schur complement) as
+// FOUR launches and ONE host synchronisation per Levenberg-Marquardt iteration, with no per-observation array in
+// global memory at all.
+//
+// Replaces, for the sliding window of visnav::bundle_adjustment (include/visnav/map_utils.h:337-421, called from
+// src/slam.cpp optimize()), what ceres::Solve does per iteration with BundleAdjustmentReprojectionCostFunctor
+// (include/visnav/reprojection.h:81-105): evaluate residuals + Jacobian blocks, eliminate the landmarks (SPARSE_SCHUR),
+// solve the reduced camera system, back-substitute, evaluate the candidate.  Same optimisation problem, same restated
+// [upstream] Ceres step policy as vsl_bundle_adjust's operator-by-operator path in ba.hip (which stays the path of
+// large systems, of vsl_ba_linearize and of the "ba_no_fused" diagnostic) -- different data flow:
+//
+//   round 3:  linearize -> r / F / E (160 B per observation) in global memory, read back by Schur, back-substitution,
+//             model, per-camera blocks, column norms: 14 launches per iteration, >= 4.5 x the algorithmic bytes.
+//   here:     a workgroup owns a contiguous range of landmarks with <= 1024 observations, ONE THREAD PER OBSERVATION.
+//     1 baf_schur_kernel   loads the 28 B of an observation (camera, detected corner, static layout word), evaluates the
+//                          residual and the Jacobian blocks into REGISTERS, reduces E^T E / E^T r per landmark through
+//                          LDS and inverts the damped 3 x 3 blocks; the per-camera blocks F^T F, F^T r come from a
+//                          camera-major LDS copy of F and r; then, <= 29 landmarks at a time, W = F^T E and -Y = -W P^-1
+//                          are laid out as dense K-major operands in LDS (K = 3 columns per landmark, zeros where a camera
+//                          does not see a landmark, one extra row holding -P^-1 b) and the lower triangle of
+//                          -sum Y W^T -- the local window's reduced camera system is dense: every landmark is seen by most
+//                          cameras -- is accumulated as 16 x 16 tiles on v_mfma_f64_16x16x4_f64, tiles dealt to the 16
+//                          wavefronts, accumulators in registers over all chunks; the extra row delivers the right-hand
+//                          side.  Out: per-workgroup tile partials, camera-block partials, P^-1 and b per landmark (96 B).
+//                          (The first version gave every thread a 3 x 3 sub-block and walked the landmarks with slot-table
+//                          lookups: 75 % of the kernel in a latency-bound loop of 5 of the 16 wavefronts.)
+//     2 baf_finish_kernel  sums the partials in a fixed order, adds camera blocks and LM damping; gradient max-norm, cost.
+//     3 baf_chol_kernel    solves the reduced system: one workgroup, DPP-broadcast panel factorisation, MFMA trailing
+//                          update, the forward substitution folded into the factorisation (comment at the kernel).
+//     4 baf_step_kernel    re-evaluates the blocks (cheaper than storing them), back-substitutes the landmark steps,
+//                          accumulates the model cost change and the step / parameter norms, writes the candidate
+//                          parameters and evaluates the cost there; its per-workgroup partials land in pinned host
+//                          memory, the host adds them in workgroup order and takes the decision.
+//   Every structural quantity (workgroup ranges, chunks, camera-major ranks, visibility masks) is fixed over the LM
+//   iterations of a solve and is laid out once on the host (bf_plan).  All reductions run in a fixed order: a solve is
+//   bit-reproducible run to run.
+//
+// Algorithmic bytes per LM iteration: n_obs * 24 + n_lms * 24 + n_cams * 56 + 128 in;
+// (6C)^2 * 8 + 6C * 8 + n_lms * 96 out.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "ba_device.h"
+#include "vsl_common.h"
+
+namespace {
+
+#define BF_THREADS 1024
+#define BF_WAVES (BF_THREADS / 64)
+#define BF_OBS_CAP 1024  // observations of a workgroup (one per thread)
+#define BF_LMW 128       // landmarks of a workgroup
+#define BF_R 14336       // doubles of the shared work region: staging [1024][9] / camera-major [1024][14] / the two dense operands
+#define BF_CAMS 64       // cameras of the problem
+#define BF_MAXCH 16      // chunks per workgroup
+#define BF_TILES 3       // 16 x 16 tiles per wavefront: 36 lower tiles at 128 padded unknowns / 16 wavefronts
+#define BF_INFO 48       // ints per workgroup record: lm0, n_lm, obs0, n_obs, n_chunks, chunk boundaries [17], camera offsets [23]
+#define BF_INFO_CB 5
+#define BF_INFO_CAM 22
+
+typedef double bf_v4d __attribute__((ext_vector_type(4)));
+
+// static word of an observation: camera-major rank in the workgroup (10) | landmark in chunk (5) << 10 | chunk (4) << 15 |
+// landmark in workgroup (7) << 19 | free camera (1) << 26
+__host__ __device__ inline unsigned bf_pack(unsigned rank, unsigned li, unsigned chunk, unsigned lml, unsigned is_free) {
+  return rank | (li << 10) | (chunk << 15) | (lml << 19) | (is_free << 26);
+}
+
+struct BfArgs {
+  BaDims D;
+  int NP;     // unknowns + the right-hand-side row, padded to whole tiles: 16 * ((n + 16) / 16)
+  int NPs;    // row stride of the K-major operands (doubles): = 16 mod 32, so the four k-groups of an operand read spread over the banks
+  int NT;     // NP / 16
+  int T;      // lower tiles: NT (NT + 1) / 2
+  const double* poses;
+  const double* points;
+  const double* intr;
+  const int* cam_intr;
+  const int* cam_free;
+  const int* obs_cam;
+  const double* obs_uv;
+  const unsigned* obs_meta;
+  const int* lm_start;
+  const unsigned* lm_pres;  // bit c: free camera c observes the landmark
+  const int* wg_info;
+  const double* scale_c;
+  double* scale_l;   // written by the INIT pass, read afterwards
+  double* Pinv;
+  double* bl;
+  double* S_part;    // [G][T][256]: tiles in accumulator layout (lane * 4 + q)
+  double* hc_part;   // [G][nfree][27]: upper triangle of F^T F (21) | F^T r (6)
+  double* sc_part;   // [G][2]: cost | max |landmark gradient|
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// What both per-iteration kernels start with: the workgroup's cameras / landmarks into LDS, this thread's observation
+// evaluated at (poses, points) into registers -- robustified and Jacobi-scaled like ba_linearize_kernel does it.
+struct BfObs {
+  double r[2], F[12], E[6];
+  double cost;
+  int fc, cam, lml;
+  unsigned meta;
+  bool have;
+};
+
+struct BfShared {
+  double* cam_s;   // [BF_CAMS][12] R | t
+  double* intr_s;  // [16]
+  double* scc_s;   // [128]
+  double* pts_s;   // [BF_LMW][3]
+  double* scl_s;   // [BF_LMW][3]
+  int* lmo_s;      // [BF_LMW + 1]
+  int* camk_s;     // [BF_CAMS]
+  int* camf_s;     // [BF_CAMS]
+};
+
+template <bool INIT>
+__device__ __forceinline__ void bf_load(const BfArgs& a, const BfShared& sh, int lm0, int n_lm, int obs0, int n_obs,
+                                        BfObs& o, double* uv) {
+  const BaDims& D = a.D;
+  const int tid = threadIdx.x;
+  if (tid < D.C) {
+    const double* T = a.poses + 7 * (size_t)tid;
+    double Rt[12];
+    quat_R(T, Rt);
+    Rt[9] = T[4];
+    Rt[10] = T[5];
+    Rt[11] = T[6];
+#pragma unroll
+    for (int j = 0; j < 12; j++) sh.cam_s[12 * tid + j] = Rt[j];
+    sh.camk_s[tid] = a.cam_intr[tid];
+    sh.camf_s[tid] = a.cam_free[tid];
+  }
+  if (tid < 16) sh.intr_s[tid] = a.intr[tid];
+  if (tid < D.n) sh.scc_s[tid] = INIT ? 1.0 : a.scale_c[tid];
+  if (tid < n_lm) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      sh.pts_s[3 * tid + j] = a.points[3 * (size_t)(lm0 + tid) + j];
+      sh.scl_s[3 * tid + j] = INIT ? 1.0 : a.scale_l[3 * (size_t)(lm0 + tid) + j];
+    }
+  }
+  if (tid <= n_lm) sh.lmo_s[tid] = a.lm_start[lm0 + tid] - obs0;
+  o.have = tid < n_obs;
+  o.cam = 0;
+  o.meta = bf_pack(0, 0, 15, 0, 0);
+  uv[0] = uv[1] = 0.0;
+  if (o.have) {
+    const size_t i = (size_t)obs0 + tid;
+    o.cam = a.obs_cam[i];
+    o.meta = a.obs_meta[i];
+    uv[0] = a.obs_uv[2 * i];
+    uv[1] = a.obs_uv[2 * i + 1];
+  }
+  o.lml = (int)((o.meta >> 19) & 0x7Fu);
+}
+
+__device__ __forceinline__ void bf_eval(const BfArgs& a, const BfShared& sh, BfObs& o, const double* uv) {
+  const BaDims& D = a.D;
+  o.r[0] = o.r[1] = 0.0;
+  o.cost = 0.0;
+  o.fc = -1;
+#pragma unroll
+  for (int j = 0; j < 12; j++) o.F[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) o.E[j] = 0.0;
+  if (!o.have) return;
+  const int k = sh.camk_s[o.cam];
+  o.fc = sh.camf_s[o.cam];
+  residual_blocks_Rt(k ? D.model1 : D.model0, sh.intr_s + 8 * k, sh.cam_s + 12 * o.cam, sh.pts_s + 3 * o.lml, uv, o.r, o.F,
+                     o.E, true);
+  const double s = o.r[0] * o.r[0] + o.r[1] * o.r[1];
+  double rho0 = s, rho1 = 1.0;
+  if (D.use_huber) huber(s, D.huber, rho0, rho1);
+  o.cost = 0.5 * rho0;
+  const double sr = sqrt(rho1);
+  o.r[0] = o.r[0] * sr;
+  o.r[1] = o.r[1] * sr;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const double sc = o.fc >= 0 ? sh.scc_s[6 * o.fc + j] : 1.0;
+    o.F[j] = o.F[j] * sr * sc;
+    o.F[6 + j] = o.F[6 + j] * sr * sc;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const double sc = sh.scl_s[3 * o.lml + j];
+    o.E[j] = o.E[j] * sr * sc;
+    o.E[3 + j] = o.E[3 + j] * sr * sc;
+  }
+}
+
+// lower tile t = ti (ti + 1) / 2 + tj, tj <= ti
+__device__ __forceinline__ void bf_tile_coords(int t, int& ti, int& tj) {
+  ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (ti * (ti + 1) / 2 > t) ti--;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+  tj = t - ti * (ti + 1) / 2;
+}
+
+#ifdef BF_TIMING
+#define BF_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); tp[q] += t2 - tt; tt = t2; }
+#else
+#define BF_STAMP(q)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Launch 1 of an iteration (INIT = false), and the Jacobi-scaling pass of a solve (INIT = true: unscaled blocks, only
+// the column norms -- scale_l per landmark written directly, the camera blocks' diagonal for scale_c -- and the cost).
+// TPW = 16 x 16 tiles per wavefront (1 up to 80 padded unknowns, 2 up to 112, 3 at 128): a template parameter because the
+// operand look-ahead of the tile loop is paid in registers per tile.
+template <bool INIT, int TPW>
+__global__ __launch_bounds__(BF_THREADS) void baf_schur_kernel(BfArgs a, double inv_radius) {
+  __shared__ double R[BF_R];  // 112 KB: (1) staging [obs][9] = E^T E | E^T r, (2) camera-major [rank][14] = F | r, (3) Yd | Wd
+  __shared__ double cam_s[BF_CAMS * 12];
+  __shared__ double intr_s[16];
+  __shared__ double scc_s[128];
+  __shared__ double pts_s[BF_LMW * 3];
+  __shared__ double scl_s[BF_LMW * 3];
+  __shared__ double pib_s[BF_LMW * 12];  // P^-1 (9) | -P^-1 b (3) per landmark
+  __shared__ int lmo_s[BF_LMW + 1];
+  __shared__ int camk_s[BF_CAMS];
+  __shared__ int camf_s[BF_CAMS];
+  __shared__ int cb_s[BF_MAXCH + 1];
+  __shared__ int camoff_s[24];
+  __shared__ unsigned pres_s[BF_LMW];
+  __shared__ double red_s[2][BF_WAVES];
+  static_assert(BF_OBS_CAP * 14 <= BF_R, "the camera-major view must fit the work region");
+  const BaDims& D = a.D;
+  const int tid = threadIdx.x, bid = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = D.n;
+  const int* info = a.wg_info + BF_INFO * (size_t)bid;
+  const int lm0 = info[0], n_lm = info[1], obs0 = info[2], n_obs = info[3], n_ch = info[4];
+  const BfShared sh = {cam_s, intr_s, scc_s, pts_s, scl_s, lmo_s, camk_s, camf_s};
+#ifdef BF_TIMING
+  long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
+#endif
+  BfObs o;
+  double uv[2];
+  bf_load<INIT>(a, sh, lm0, n_lm, obs0, n_obs, o, uv);
+  if (tid <= BF_MAXCH) cb_s[tid] = info[BF_INFO_CB + tid];
+  if (tid <= D.nfree) camoff_s[tid] = info[BF_INFO_CAM + tid];
+  if (tid < n_lm) pres_s[tid] = a.lm_pres[lm0 + tid];
+  __syncthreads();
+  BF_STAMP(0)
+  bf_eval(a, sh, o, uv);
+  {
+    double* st = R + 9 * tid;  // (idle threads write zeros nobody reads: a landmark's range covers real observations only)
+    const double* e = o.E;
+    st[0] = e[0] * e[0] + e[3] * e[3];
+    st[1] = e[0] * e[1] + e[3] * e[4];
+    st[2] = e[0] * e[2] + e[3] * e[5];
+    st[3] = e[1] * e[1] + e[4] * e[4];
+    st[4] = e[1] * e[2] + e[4] * e[5];
+    st[5] = e[2] * e[2] + e[5] * e[5];
+#pragma unroll
+    for (int x = 0; x < 3; x++) st[6 + x] = e[x] * o.r[0] + e[3 + x] * o.r[1];
+  }
+  {
+    const double cs = wave_sum(o.cost);
+    if (lane == 0) red_s[0][wave] = cs;
+  }
+  __syncthreads();
+  BF_STAMP(1)
+  // per landmark: P = sum E^T E, b = sum E^T r in observation order; damped inverse
+  double gl = 0.0;
+  if (tid < n_lm) {
+    double P6[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+    const int i0 = lmo_s[tid], i1 = lmo_s[tid + 1];
+    for (int i = i0; i < i1; i++) {
+      const double* st = R + 9 * i;
+#pragma unroll
+      for (int q = 0; q < 6; q++) P6[q] += st[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) bb[q] += st[6 + q];
+    }
+    if (INIT) {
+      // Jacobi scaling of the landmark columns ([upstream] Ceres jacobi_scaling): 1 / (1 + sqrt(column norm^2))
+      a.scale_l[3 * (size_t)(lm0 + tid)] = 1.0 / (1.0 + sqrt(P6[0]));
+      a.scale_l[3 * (size_t)(lm0 + tid) + 1] = 1.0 / (1.0 + sqrt(P6[3]));
+      a.scale_l[3 * (size_t)(lm0 + tid) + 2] = 1.0 / (1.0 + sqrt(P6[5]));
+    } else {
+      double P[9] = {P6[0], P6[1], P6[2], P6[1], P6[3], P6[4], P6[2], P6[4], P6[5]};
+      // LM damping: diag = clamp(column norm^2, 1e-6, 1e32) / radius (the Jacobian of a rejected step is unchanged, so
+      // recomputing the clamp here IS keeping it)
+      P[0] += fmin(fmax(P6[0], 1e-6), 1e32) * inv_radius;
+      P[4] += fmin(fmax(P6[3], 1e-6), 1e32) * inv_radius;
+      P[8] += fmin(fmax(P6[5], 1e-6), 1e32) * inv_radius;
+      double Pi[9];
+      const bool ok = i1 > i0 && inv3(P, Pi);
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        Pi[q] = ok ? Pi[q] : 0.0;  // a singular block contributes nothing (Y = 0) and its landmark does not move
+        pib_s[12 * tid + q] = Pi[q];
+        a.Pinv[9 * (size_t)(lm0 + tid) + q] = Pi[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double v = ok ? bb[q] : 0.0;
+        a.bl[3 * (size_t)(lm0 + tid) + q] = v;
+        pib_s[12 * tid + 9 + q] = -(Pi[3 * q] * bb[0] + Pi[3 * q + 1] * bb[1] + Pi[3 * q + 2] * bb[2]);
+        gl = fmax(gl, fabs(bb[q] / scl_s[3 * tid + q]));  // gradient of the UNSCALED problem
+      }
+    }
+  }
+  {
+    const double gm = wave_max(gl);
+    if (lane == 0) red_s[1][wave] = gm;
+  }
+  __syncthreads();  // staging is dead from here on
+  BF_STAMP(2)
+  // per-camera blocks: F | r of the free-camera observations in camera-major order, then thread (camera, entry) walks
+  // its camera's run -- addresses are affine in the loop counter, the loads pipeline
+  const bool is_free = ((o.meta >> 26) & 1u) != 0;
+  if (is_free) {
+    double* f = R + 14 * (size_t)(o.meta & 0x3FFu);
+#pragma unroll
+    for (int j = 0; j < 12; j++) f[j] = o.F[j];
+    f[12] = o.r[0];
+    f[13] = o.r[1];
+  }
+  __syncthreads();
+  if (tid < 27 * D.nfree) {
+    const int c = tid / 27, e = tid - 27 * c;
+    int ia = 0, ib = 12;  // entry (ia, ib) of F^T F, or F^T r (ib = 12)
+    if (e < 21) {
+      int rem = e;
+      while (rem >= 6 - ia) {
+        rem -= 6 - ia;
+        ia++;
+      }
+      ib = ia + rem;
+    } else {
+      ia = e - 21;
+    }
+    const int ib1 = e < 21 ? ib + 6 : 13;
+    double acc = 0.0;
+    const int k1 = camoff_s[c + 1];
+    int k = camoff_s[c];
+    for (; k + 4 <= k1; k += 4) {  // the loads of four observations in flight, the sum in observation order
+      double t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double* f = R + 14 * (k + u);
+        t[u] = f[ia] * f[ib] + f[6 + ia] * f[ib1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc += t[u];
+    }
+    for (; k < k1; k++) {
+      const double* f = R + 14 * k;
+      acc += f[ia] * f[ib] + f[6 + ia] * f[ib1];
+    }
+    a.hc_part[((size_t)bid * D.nfree + c) * 27 + e] = acc;
+  }
+  if (tid == 0) {
+    double cs = 0.0, gm = 0.0;
+    for (int w = 0; w < BF_WAVES; w++) {
+      cs += red_s[0][w];
+      gm = fmax(gm, red_s[1][w]);
+    }
+    a.sc_part[2 * bid] = cs;
+    a.sc_part[2 * bid + 1] = gm;
+  }
+  if (INIT) return;
+  __syncthreads();  // the camera-major view is dead: the region becomes the two dense operands
+  BF_STAMP(3)
+  const int NPs = a.NPs, NP = a.NP, T = a.T;
+  const int kq = lane >> 4, l16 = lane & 15;
+  bf_v4d acc[TPW];
+  int aoff[TPW], boff[TPW];
+#pragma unroll
+  for (int s = 0; s < TPW; s++) {
+    acc[s] = (bf_v4d){0.0, 0.0, 0.0, 0.0};
+    int ti = 0, tj = 0;
+    if (wave + BF_WAVES * s < T) bf_tile_coords(wave + BF_WAVES * s, ti, tj);
+    aoff[s] = kq * NPs + 16 * ti + l16;  // Yd rows of the tile's row block
+    boff[s] = kq * NPs + 16 * tj + l16;  // Wd rows of its column block
+  }
+  const int my_ch = (int)((o.meta >> 15) & 0xFu), my_li = (int)((o.meta >> 10) & 0x1Fu);
+  const int rowcam[2] = {lane / 6, (lane + 64) / 6};  // free camera of the two operand rows this lane zero-fills
+  for (int c = 0; c < n_ch; c++) {
+    const int l_a = cb_s[c], lc = cb_s[c + 1] - l_a;
+    const int KP = (3 * lc + 3) & ~3;
+    double* Yd = R;
+    double* Wd = R + (size_t)KP * NPs;
+    // zeros where a free camera does not see a landmark (static mask), in the padding rows / columns and in Wd's
+    // right-hand-side row; everything else is written by the thread that owns the value -- disjoint, one barrier
+    for (int k = wave; k < KP; k += BF_WAVES) {  // k is wave-uniform, the rows are the lanes (NP <= 128: two per lane)
+      const int li = k / 3;
+      const unsigned pm = li < lc ? pres_s[l_a + li] : 0u;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int row = lane + 64 * h;
+        if (row < NP) {
+          const bool vis = row < n && ((pm >> rowcam[h]) & 1u) != 0;
+          const bool visy = vis || (row == n && li < lc);
+          if (!visy) Yd[k * NPs + row] = 0.0;
+          if (!vis) Wd[k * NPs + row] = 0.0;
+        }
+      }
+    }
+    if (is_free && my_ch == c) {
+      const double* Pi = pib_s + 12 * o.lml;
+      const int base = 3 * my_li * NPs + 6 * o.fc;
+#pragma unroll
+      for (int x = 0; x < 6; x++) {
+        double w[3];
+#pragma unroll
+        for (int y = 0; y < 3; y++) w[y] = o.F[x] * o.E[y] + o.F[6 + x] * o.E[3 + y];
+#pragma unroll
+        for (int y = 0; y < 3; y++) {
+          Wd[base + y * NPs + x] = w[y];
+          Yd[base + y * NPs + x] = -(w[0] * Pi[y] + w[1] * Pi[3 + y] + w[2] * Pi[6 + y]);
+        }
+      }
+    }
+    if (tid >= l_a && tid < l_a + lc) {  // the landmark's own thread: row n of Yd = -P^-1 b
+#pragma unroll
+      for (int y = 0; y < 3; y++) Yd[(3 * (tid - l_a) + y) * NPs + n] = pib_s[12 * tid + 9 + y];
+    }
+    __syncthreads();
+    BF_STAMP(4)
+    {
+      int k0 = 0;
+      constexpr int AHEAD = TPW == 1 ? 4 : (TPW == 2 ? 2 : 1);  // steps whose operands are in flight before the first matrix instruction
+      for (; k0 + 4 * AHEAD <= KP; k0 += 4 * AHEAD) {
+        double ya[AHEAD][TPW], wb[AHEAD][TPW];
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++)
+#pragma unroll
+          for (int s = 0; s < TPW; s++)
+            if (wave + BF_WAVES * s < T) {  // wave-uniform
+              ya[u][s] = Yd[(k0 + 4 * u) * NPs + aoff[s]];
+              wb[u][s] = Wd[(k0 + 4 * u) * NPs + boff[s]];
+            }
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++)
+#pragma unroll
+          for (int s = 0; s < TPW; s++)
+            if (wave + BF_WAVES * s < T) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[u][s], wb[u][s], acc[s], 0, 0, 0);
+      }
+      for (; k0 < KP; k0 += 4) {
+#pragma unroll
+        for (int s = 0; s < TPW; s++)
+          if (wave + BF_WAVES * s < T)
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Yd[k0 * NPs + aoff[s]], Wd[k0 * NPs + boff[s]], acc[s], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    BF_STAMP(5)
+  }
+#pragma unroll
+  for (int s = 0; s < TPW; s++)
+    if (wave + BF_WAVES * s < T)
+      *(bf_v4d*)(a.S_part + (((size_t)bid * T + wave + BF_WAVES * s) * 256 + 4 * lane)) = acc[s];
+  BF_STAMP(6)
+#ifdef BF_TIMING
+  if (tid == 0 && (bid == 0 || bid == 100))
+    printf("schur wg %d (lms %d obs %d chunks %d) ticks: load %lld eval+stage %lld landmarks %lld camera blocks %lld operand writes %lld mfma %lld epilogue %lld\n",
+           bid, n_lm, n_obs, n_ch, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
+#endif
+}
+
+// entry (a, b), a <= b, of the upper triangle of a 6 x 6 block, row-major
+__device__ __forceinline__ int bf_tri6(int a, int b) { return 6 * a - a * (a - 1) / 2 + (b - a); }
+
+// Launch 2: S = tile partials summed in workgroup order (the strictly upper tiles are mirror images) + camera blocks +
+// LM damping of the camera diagonal; right-hand side and |g_c / scale| per unknown; cost and landmark gradient norm by
+// the last workgroup.  Scalars go to the pinned mailbox: [0] cost, [1] max landmark gradient, gabs[0 .. n) camera part.
+// Every sum is 16 slices of <= BF_PER partials whose loads are all in flight at once (a plain loop over 128 partials was
+// a chain of 128 dependent round trips: 46 us), added in slice order -- fixed.
+#define BF_PER 16  // partials per slice: G <= 256 -> 16 slices; larger G loops
+template <int STRIDE_IS_TILE>
+__device__ __forceinline__ double bf_slice_sum(const double* __restrict__ p, size_t stride, int g_begin, int g_end) {
+  double v = 0;
+  for (int g = g_begin; g < g_end; g += BF_PER) {
+    double t[BF_PER];
+#pragma unroll
+    for (int u = 0; u < BF_PER; u++) t[u] = g + u < g_end ? p[(size_t)(g + u) * stride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < BF_PER; u++) v += t[u];
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void baf_finish_kernel(int n, int nfree, int G, int T, const double* __restrict__ S_part,
+                                                         const double* __restrict__ hc_part,
+                                                         const double* __restrict__ sc_part,
+                                                         const double* __restrict__ scale_c, double inv_radius,
+                                                         double* __restrict__ S, double* __restrict__ rhs,
+                                                         double* __restrict__ host_out, double* __restrict__ host_gabs) {
+  __shared__ double sh[16][17];
+  __shared__ double sh2[16][17];
+  const int nS = (n * n + 15) / 16, nV = (n + 15) / 16;
+  const int per = (G + 15) / 16;
+  const int e = threadIdx.x & 15, c = threadIdx.x >> 4;
+  const int g_a = min(G, c * per), g_b = min(G, (c + 1) * per);
+  if ((int)blockIdx.x < nS) {
+    const int idx = blockIdx.x * 16 + e;
+    double v = 0, hd = 0;
+    if (idx < n * n) {
+      const int i = idx / n, j = idx - i * n;
+      int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
+      if (ti < tj) {
+        int t = ti; ti = tj; tj = t;
+        t = ii; ii = jj; jj = t;
+      }
+      // accumulator layout of v_mfma_f64_16x16x4_f64: element q of lane l is D[(l >> 4) + 4 q][l & 15]
+      const size_t off = (size_t)(ti * (ti + 1) / 2 + tj) * 256 + 4 * (16 * (ii & 3) + jj) + (ii >> 2);
+      v = bf_slice_sum<1>(S_part + off, (size_t)T * 256, g_a, g_b);
+      if (i / 6 == j / 6) {
+        const int a = i % 6, b = j % 6;
+        const int k = (i / 6) * 27 + bf_tri6(min(a, b), max(a, b));
+        hd = bf_slice_sum<0>(hc_part + k, (size_t)nfree * 27, g_a, g_b);
+      }
+    }
+    sh[c][e] = v;
+    sh2[c][e] = hd;
+    __syncthreads();
+    if (c == 0 && idx < n * n) {
+      double t = 0, h = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        t += sh[k][e];
+        h += sh2[k][e];
+      }
+      const int i = idx / n, j = idx - i * n;
+      t += h;
+      if (i == j) t += fmin(fmax(h, 1e-6), 1e32) * inv_radius;
+      S[idx] = t;
+    }
+    return;
+  }
+  if ((int)blockIdx.x < nS + nV) {  // right-hand side: row n of the tile row tn, + g_c
+    const int x = (blockIdx.x - nS) * 16 + e;
+    double ry = 0, gc = 0;
+    if (x < n) {
+      const int tn = n >> 4, in = n & 15;
+      const size_t off = (size_t)(tn * (tn + 1) / 2 + (x >> 4)) * 256 + 4 * (16 * (in & 3) + (x & 15)) + (in >> 2);
+      ry = bf_slice_sum<1>(S_part + off, (size_t)T * 256, g_a, g_b);
+      gc = bf_slice_sum<0>(hc_part + (x / 6) * 27 + 21 + x % 6, (size_t)nfree * 27, g_a, g_b);
+    }
+    sh[c][e] = ry;
+    sh2[c][e] = gc;
+    __syncthreads();
+    if (c == 0 && x < n) {
+      double t = 0, g = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        t += sh[k][e];
+        g += sh2[k][e];
+      }
+      rhs[x] = t + g;
+      host_gabs[x] = fabs(g / scale_c[x]);  // gradient of the UNSCALED problem, camera part
+    }
+    return;
+  }
+  // scalars: one partial per thread and round, LDS tree in a fixed shape
+  __shared__ double cs_s[256], gl_s[256];
+  double cs = 0, gl = 0;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    cs += sc_part[2 * g];
+    gl = fmax(gl, sc_part[2 * g + 1]);
+  }
+  cs_s[threadIdx.x] = cs;
+  gl_s[threadIdx.x] = gl;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      cs_s[threadIdx.x] += cs_s[threadIdx.x + o];
+      gl_s[threadIdx.x] = fmax(gl_s[threadIdx.x], gl_s[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    host_out[0] = cs_s[0];
+    host_out[1] = gl_s[0];
+  }
+}
+
+// the Jacobi-scaling pass's second launch: scale_c = 1 / (1 + sqrt(diag H)) (workgroups 0 .. nV), initial cost (the last)
+__global__ __launch_bounds__(256) void baf_init_finish_kernel(int n, int nfree, int G, const double* __restrict__ hc_part,
+                                                              const double* __restrict__ sc_part,
+                                                              double* __restrict__ scale_c, double* __restrict__ host_out) {
+  __shared__ double sh[16][17];
+  __shared__ double cs_s[256];
+  const int nV = (n + 15) / 16, per = (G + 15) / 16;
+  if ((int)blockIdx.x < nV) {
+    const int e = threadIdx.x & 15, c = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + e;
+    double h = 0;
+    if (x < n) {
+      const int a = x % 6;
+      h = bf_slice_sum<0>(hc_part + (x / 6) * 27 + bf_tri6(a, a), (size_t)nfree * 27, min(G, c * per), min(G, (c + 1) * per));
+    }
+    sh[c][e] = h;
+    __syncthreads();
+    if (c == 0 && x < n) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) t += sh[k][e];
+      scale_c[x] = 1.0 / (1.0 + sqrt(t));
+    }
+    return;
+  }
+  double cs = 0;
+  for (int g = threadIdx.x; g < G; g += 256) cs += sc_part[2 * g];
+  cs_s[threadIdx.x] = cs;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) cs_s[threadIdx.x] += cs_s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    host_out[0] = cs_s[0];
+    host_out[1] = 0.0;
+  }
+}
+
+// Launch 3: dc = -(S^-1 rhs) for n <= 127 by ONE workgroup, everything in LDS.
+//
+// The solve is a serial chain of n pivots whatever one does; what this kernel shortens is the work per pivot
+// (ba_chol_small_kernel of ba.hip, the round-2 solver that the other paths keep: 50 us at n = 72, of which 41 % in the
+// two substitutions):
+//   * the right-hand side rides along as one more ROW of the matrix (row R below the last panel): the Cholesky
+//     factorisation of [S b; b^T .] leaves y = L^-1 b in that row -- the forward substitution costs nothing;
+//   * 16-column panels.  A wavefront keeps the 16 x 16 diagonal block one row per lane of each 16-lane DPP row (all four
+//     rows of the wavefront hold a copy) and ONE PANEL ROW PER LANE next to it; a pivot step is: broadcast of the pivot
+//     (v_mov_b64_dpp row_newbcast), rsq + two Newton steps, and per remaining column ONE v_fmac_f64_dpp for the
+//     diagonal block and one for the panel row -- the neighbour's factor entry arrives as the DPP operand, no LDS, no
+//     readlane, no barrier.  Every wavefront that has panel rows runs the same stream (factoring the diagonal block
+//     redundantly), so factorisation and panel solve of a panel are one pass of ~400 instructions;
+//   * the trailing update as 16 x 16 tiles on v_mfma_f64_16x16x4_f64 (four instructions per tile), tiles dealt to the
+//     16 wavefronts: two barriers per panel;
+//   * backward substitution by one wavefront without workgroup barriers: per panel the 16 x 16 transposed solve on DPP
+//     broadcasts again, then one batched update of the remaining columns.
+// flag = 0 if a pivot is not positive / finite.
+#define CS_LD 129   // row stride (doubles): one matrix row per lane is conflict-free (2 dwords per lane and bank)
+#define CS_ROWS 129 // 128 matrix rows + the right-hand-side row
+
+template <int J>
+__device__ __forceinline__ double cs_bcast(double v) {  // lane J of every 16-lane row -> all lanes of the row
+  double r;
+  // (two wait states between a VALU write and a DPP read of the same register: the compiler does not see into the asm)
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+  return r;
+}
+template <int K, bool NOP>
+__device__ __forceinline__ void cs_fmac_bcast(double& acc, double bsrc, double own) {  // acc -= bsrc[lane K of the row] * own
+  if (NOP)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
+  else
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
+}
+
+template <int J>
+struct CsCol {  // pivot step J of a panel: d = the diagonal block's row of this lane, p = its panel row
+  static __device__ __forceinline__ void run(double (&d)[16], double (&p)[16], double* inv_out, bool& good) {
+    const double dj = cs_bcast<J>(d[J]);
+    if (!(dj > 0.0) || !isfinite(dj)) good = false;
+    // 1 / sqrt by the hardware estimate and two Newton steps (an IEEE sqrt + divide is ~200 dependent instructions)
+    double iv = __builtin_amdgcn_rsq(dj);
+    iv = iv * (1.5 - 0.5 * dj * iv * iv);
+    iv = iv * (1.5 - 0.5 * dj * iv * iv);
+    if (inv_out) inv_out[J] = iv;  // (lane J of wavefront 0 only: the pointer is null elsewhere)
+    const double lj = d[J] * iv;  // lane J: sqrt(pivot); lanes below: l(i, J)
+    const double pj = p[J] * iv;
+    d[J] = lj;
+    p[J] = pj;
+    upd<J + 1>(d, p, lj, pj);
+    CsCol<J + 1>::run(d, p, inv_out, good);
+  }
+  template <int K>
+  static __device__ __forceinline__ void upd(double (&d)[16], double (&p)[16], double lj, double pj) {
+    if constexpr (K < 16) {
+      cs_fmac_bcast<K, K == J + 1>(d[K], lj, lj);  // d(i, K) -= l(K, J) l(i, J)
+      cs_fmac_bcast<K, false>(p[K], lj, pj);       // p(r, K) -= l(K, J) l(r, J)
+      upd<K + 1>(d, p, lj, pj);
+    }
+  }
+};
+template <>
+struct CsCol<16> {
+  static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double*, bool&) {}
+};
+
+template <int J>
+struct CsBack {  // step J (descending) of the transposed 16 x 16 solve: c[k] = l(k, lane) of the diagonal block
+  static __device__ __forceinline__ void run(double& tp, double& x, const double (&c)[16], double ivl, int dr) {
+    const double xj = tp * ivl;          // meaningful in lane J
+    if (dr == J) x = xj;
+    cs_fmac_bcast<J, true>(tp, xj, c[J]);  // t(lane) -= x_J l(J, lane)  (lanes >= J: c[J] = 0 or already solved)
+    if constexpr (J > 0) CsBack<J - 1>::run(tp, x, c, ivl, dr);
+  }
+};
+
+__global__ __launch_bounds__(BF_THREADS) void baf_chol_kernel(int n, const double* __restrict__ S,
+                                                              const double* __restrict__ rhs, double* __restrict__ dc,
+                                                              int* __restrict__ ok_flag) {
+  __shared__ double A[CS_ROWS * CS_LD];  // 133 KB
+  __shared__ double inv_s[128];
+  __shared__ double t_s[128];
+  __shared__ double xs_s[16];
+  __shared__ int fail_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = 16 * ((n + 15) / 16);  // row of the right-hand side; rows n .. R - 1 are identity padding
+  const int NPANEL = R / 16;
+  // load: rows 0 .. R (wave-strided), columns by lane
+  for (int i = wave; i <= R; i += BF_WAVES) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int j = lane + 64 * h;
+      if (j < R) {
+        double v;
+        if (i < n)
+          v = j < n ? S[(size_t)i * n + j] : 0.0;
+        else if (i < R)
+          v = i == j ? 1.0 : 0.0;
+        else
+          v = j < n ? rhs[j] : 0.0;
+        A[i * CS_LD + j] = v;
+      }
+    }
+  }
+  if (tid == 0) fail_s = 0;
+  __syncthreads();
+  const int kq = lane >> 4, l16 = lane & 15;
+  for (int pn = 0; pn < NPANEL; pn++) {
+    const int c0 = 16 * pn;
+    const int r0 = c0 + 16;               // first panel row
+    const int nrow = R - r0 + 1;          // panel rows, the right-hand side included (>= 1)
+    if (wave * 64 < nrow) {               // wave-uniform
+      const int prow = r0 + wave * 64 + lane;
+      const bool valid = prow <= R;
+      double d[16], p[16];
+      const double* drow = A + (c0 + l16) * CS_LD + c0;
+      const double* pr = A + min(prow, R) * CS_LD + c0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        d[k] = drow[k];
+        p[k] = valid ? pr[k] : 0.0;
+      }
+      bool good = true;
+      CsCol<0>::run(d, p, (wave == 0 && lane == 0) ? inv_s + c0 : (double*)nullptr, good);
+      if (wave == 0 && lane < 16) {
+        double* dw = A + (c0 + lane) * CS_LD + c0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) dw[k] = k <= lane ? d[k] : 0.0;  // L_d, zeros above the diagonal
+      }
+      if (valid) {
+        double* pw = A + prow * CS_LD + c0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) pw[k] = p[k];
+      }
+      if (!good) fail_s = 1;
+    }
+    __syncthreads();
+    if (fail_s) break;  // workgroup-uniform
+    // trailing update: rows / columns r0 .. R in 16 x 16 tiles (the tile column that holds column R is never needed)
+    const int ntr = (R - r0) / 16 + 1;
+    const int ntiles = ntr * (ntr + 1) / 2;
+    for (int t = wave; t < ntiles; t += BF_WAVES) {
+      int ti, tj;
+      bf_tile_coords(t, ti, tj);
+      if (tj == ntr - 1) continue;  // wave-uniform
+      const int R0 = r0 + 16 * ti, C0 = r0 + 16 * tj;
+      const int ra = min(R0 + l16, R), rb = C0 + l16;
+      bf_v4d acc;
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[q] = A[min(R0 + kq + 4 * q, R) * CS_LD + C0 + l16];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-A[ra * CS_LD + c0 + 4 * m + kq], A[rb * CS_LD + c0 + 4 * m + kq], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int row = R0 + kq + 4 * q;
+        if (row <= R) A[row * CS_LD + C0 + l16] = acc[q];
+      }
+    }
+    __syncthreads();
+  }
+  const bool good = fail_s == 0;
+  if (tid == 0) *ok_flag = good ? 1 : 0;
+  if (!good || wave != 0) return;
+  // L^T x = y (y = row R), one wavefront, panels in descending order
+  t_s[lane] = lane < R ? A[R * CS_LD + lane] : 0.0;
+  t_s[lane + 64] = lane + 64 < R ? A[R * CS_LD + lane + 64] : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (int pn = NPANEL - 1; pn >= 0; pn--) {
+    const int c0 = 16 * pn;
+    double c[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) c[k] = A[(c0 + k) * CS_LD + c0 + l16];  // l(k, lane); zero for k < lane (written so above)
+    double tp = t_s[c0 + l16], x = 0.0;
+    const double ivl = inv_s[c0 + l16];
+    CsBack<15>::run(tp, x, c, ivl, l16);
+    if (lane < 16) {
+      xs_s[lane] = x;
+      t_s[c0 + lane] = x;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // the columns in front of the panel lose l(c0 + k, col) x_k
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int col = lane + 64 * h;
+      if (col < c0) {
+        double t = t_s[col];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t -= A[(c0 + k) * CS_LD + col] * xs_s[k];
+        t_s[col] = t;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane < n) dc[lane] = -t_s[lane];
+  if (lane + 64 < n) dc[lane + 64] = -t_s[lane + 64];
+}
+
+// Launch 4: the step.  delta_l = -P^-1 (b_l + sum_obs E^T F delta_c); model cost change -(J d)^T (r + J d / 2); candidate
+// = Plus(x, step .* scale); cost at the candidate.  step_part[5 * workgroup ..] = [model, candidate cost, |step|^2,
+// |x|^2, non-finite count] in pinned host memory.
+__global__ __launch_bounds__(BF_THREADS) void baf_step_kernel(BfArgs a, const double* __restrict__ dc,
+                                                              double* __restrict__ cand_poses,
+                                                              double* __restrict__ cand_points,
+                                                              double* __restrict__ step_part) {
+  __shared__ double stage_v[BF_OBS_CAP * 3];
+  __shared__ double cam_s[BF_CAMS * 12];
+  __shared__ double camc_s[BF_CAMS * 12];  // candidate cameras
+  __shared__ double intr_s[16];
+  __shared__ double scc_s[128];
+  __shared__ double dc_s[128];
+  __shared__ double pts_s[BF_LMW * 3];
+  __shared__ double scl_s[BF_LMW * 3];
+  __shared__ double cpt_s[BF_LMW * 3];
+  __shared__ double dl_s[BF_LMW * 3];
+  __shared__ int lmo_s[BF_LMW + 1];
+  __shared__ int camk_s[BF_CAMS];
+  __shared__ int camf_s[BF_CAMS];
+  __shared__ double red_s[BF_WAVES][5];
+  const BaDims& D = a.D;
+  const int tid = threadIdx.x, bid = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = D.n;
+  const int* info = a.wg_info + BF_INFO * (size_t)bid;
+  const int lm0 = info[0], n_lm = info[1], obs0 = info[2], n_obs = info[3];
+  const BfShared sh = {cam_s, intr_s, scc_s, pts_s, scl_s, lmo_s, camk_s, camf_s};
+  BfObs o;
+  double uv[2];
+  bf_load<false>(a, sh, lm0, n_lm, obs0, n_obs, o, uv);
+  double step2 = 0.0, x2 = 0.0, bad = 0.0;
+  if (tid < n) {
+    const double v = dc[tid];
+    dc_s[tid] = v;
+    if (!isfinite(v)) bad = 1.0;
+  }
+  if (tid < D.C) {  // candidate cameras (every workgroup needs them; workgroup 0 publishes them and owns their norms)
+    const int fc = a.cam_free[tid];
+    const double* T = a.poses + 7 * (size_t)tid;
+    double c7[7];
+    double s2 = 0.0, xx = 0.0;
+    if (fc < 0) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) c7[j] = T[j];
+    } else {
+      double d[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        d[j] = dc[6 * fc + j] * a.scale_c[6 * fc + j];
+        s2 += d[j] * d[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 7; j++) xx += T[j] * T[j];
+      se3_plus(T, d, c7);
+    }
+    double Rt[12];
+    quat_R(c7, Rt);
+    Rt[9] = c7[4];
+    Rt[10] = c7[5];
+    Rt[11] = c7[6];
+#pragma unroll
+    for (int j = 0; j < 12; j++) camc_s[12 * tid + j] = Rt[j];
+    if (bid == 0) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) cand_poses[7 * (size_t)tid + j] = c7[j];
+      step2 += s2;
+      x2 += xx;
+    }
+  }
+  double Pi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+  if (tid < n_lm) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) Pi[q] = a.Pinv[9 * (size_t)(lm0 + tid) + q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) bl[q] = a.bl[3 * (size_t)(lm0 + tid) + q];
+  }
+  __syncthreads();
+  bf_eval(a, sh, o, uv);
+  double u0 = 0.0, u1 = 0.0;
+  if (o.fc >= 0) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      u0 += o.F[j] * dc_s[6 * o.fc + j];
+      u1 += o.F[6 + j] * dc_s[6 * o.fc + j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) stage_v[3 * tid + j] = o.E[j] * u0 + o.E[3 + j] * u1;
+  __syncthreads();
+  if (tid < n_lm) {
+    double t[3] = {bl[0], bl[1], bl[2]};
+    for (int i = lmo_s[tid]; i < lmo_s[tid + 1]; i++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) t[j] += stage_v[3 * i + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double v = -(Pi[3 * j] * t[0] + Pi[3 * j + 1] * t[1] + Pi[3 * j + 2] * t[2]);
+      if (!isfinite(v)) bad = 1.0;
+      dl_s[3 * tid + j] = v;
+      const double dd = v * scl_s[3 * tid + j];
+      step2 += dd * dd;
+      const double xv = pts_s[3 * tid + j];
+      x2 += xv * xv;
+      const double cp = xv + dd;
+      cpt_s[3 * tid + j] = cp;
+      cand_points[3 * (size_t)(lm0 + tid) + j] = cp;
+    }
+  }
+  __syncthreads();
+  double model = 0.0, ccost = 0.0;
+  if (o.have) {
+    double m0 = u0, m1 = u1;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      m0 += o.E[j] * dl_s[3 * o.lml + j];
+      m1 += o.E[3 + j] * dl_s[3 * o.lml + j];
+    }
+    model = -(m0 * (o.r[0] + m0 / 2.0) + m1 * (o.r[1] + m1 / 2.0));
+    const int k = camk_s[o.cam];
+    double rc[2];
+    residual_blocks_Rt(k ? D.model1 : D.model0, intr_s + 8 * k, camc_s + 12 * o.cam, cpt_s + 3 * o.lml, uv, rc, nullptr,
+                       nullptr, false);
+    const double s = rc[0] * rc[0] + rc[1] * rc[1];
+    double rho0 = s, rho1 = 1.0;
+    if (D.use_huber) huber(s, D.huber, rho0, rho1);
+    ccost = 0.5 * rho0;
+  }
+  double v5[5] = {model, ccost, step2, x2, bad};
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    const double w = wave_sum(v5[q]);
+    if (lane == 0) red_s[wave][q] = w;
+  }
+  __syncthreads();
+  if (tid < 5) {
+    double t = 0;
+    for (int w = 0; w < BF_WAVES; w++) t += red_s[w][tid];
+    step_part[5 * (size_t)bid + tid] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+double bf_now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct BfPlan {
+  int G = 0, nfree = 0, NP = 0, NPs = 0, lc_max = 0;
+  std::vector<int> cam_free, lm_start, wg_info, s_cam;
+  std::vector<int> perm;  // sorted position -> caller observation index
+  std::vector<unsigned> meta, pres;
+  std::vector<double> s_uv;
+};
+
+// Lays the problem out for the fused kernels; false when it does not fit them (the caller takes the general path).
+bool bf_plan(const vsl_ba_problem* p, BfPlan& pl) {
+  const int C = p->n_cams, L = p->n_lms, O = p->n_obs;
+  if (C > BF_CAMS) return false;
+  pl.cam_free.assign(C, -1);
+  int nfree = 0;
+  for (int c = 0; c < C; c++)
+    if (!p->cam_fixed[c]) pl.cam_free[c] = nfree++;
+  pl.nfree = nfree;
+  if (nfree < 1 || 6 * nfree > 126) return false;
+  const int n = 6 * nfree;
+  pl.NP = 16 * ((n + 16) / 16);  // the unknowns and the right-hand-side row, in whole tiles
+  pl.NPs = (pl.NP % 32 == 16) ? pl.NP : pl.NP + 16;
+  pl.lc_max = std::min(31, (((BF_R / 2) / pl.NPs) & ~3) / 3);  // K = 3 columns per landmark, padded to the matrix instruction's 4
+  // observations sorted by landmark (stable)
+  pl.lm_start.assign(L + 1, 0);
+  for (int i = 0; i < O; i++) pl.lm_start[p->obs_lm[i] + 1]++;
+  for (int l = 0; l < L; l++) pl.lm_start[l + 1] += pl.lm_start[l];
+  pl.perm.resize(O);
+  {
+    std::vector<int> fill(pl.lm_start.begin(), pl.lm_start.end() - 1);
+    for (int i = 0; i < O; i++) pl.perm[fill[p->obs_lm[i]]++] = i;
+  }
+  pl.s_cam.resize(O);
+  pl.s_uv.resize(2 * (size_t)O);
+  for (int q = 0; q < O; q++) {
+    const int i = pl.perm[q];
+    pl.s_cam[q] = p->obs_cam[i];
+    pl.s_uv[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
+    pl.s_uv[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
+  }
+  // per landmark: which free cameras see it; a camera seeing a landmark twice would write one operand entry twice
+  pl.pres.assign(L, 0u);
+  for (int l = 0; l < L; l++) {
+    const int a = pl.lm_start[l], b = pl.lm_start[l + 1];
+    if (b - a > 64) return false;
+    unsigned m = 0;
+    for (int q = a; q < b; q++) {
+      const int fc = pl.cam_free[pl.s_cam[q]];
+      if (fc < 0) continue;
+      if (m & (1u << fc)) return false;
+      m |= 1u << fc;
+    }
+    pl.pres[l] = m;
+  }
+  // workgroups: contiguous landmark ranges balanced by observation count, one thread per observation
+  int G0 = std::max(1, std::min(256, (O + 319) / 320));
+  if ((O + G0 - 1) / G0 > 960) G0 = (O + 959) / 960;
+  pl.meta.assign(O, 0u);
+  pl.wg_info.clear();
+  int l = 0, g = 0;
+  std::vector<int> cnt(nfree + 1);
+  while (l < L) {
+    const long long target = (long long)O * (g + 1) / G0;  // cumulative observations this workgroup should reach
+    int rec[BF_INFO] = {0};
+    const int lm0 = l, obs0 = pl.lm_start[l];
+    int n_ch = 0, ch_lm = 0;
+    while (l < L) {
+      const int a = pl.lm_start[l], b = pl.lm_start[l + 1];
+      const bool wg_has = l > lm0;
+      if (wg_has && (b - obs0 > BF_OBS_CAP || l - lm0 >= BF_LMW)) break;
+      if (wg_has && a >= target && g + 1 < G0) break;
+      if (ch_lm >= pl.lc_max) {  // the chunk is full
+        if (n_ch + 1 >= BF_MAXCH) break;  // the next workgroup takes this landmark
+        n_ch++;
+        rec[BF_INFO_CB + n_ch] = l - lm0;
+        ch_lm = 0;
+      }
+      for (int q = a; q < b; q++)
+        pl.meta[q] = bf_pack(0, (unsigned)ch_lm, (unsigned)n_ch, (unsigned)(l - lm0), pl.cam_free[pl.s_cam[q]] >= 0 ? 1u : 0u);
+      ch_lm++;
+      l++;
+    }
+    n_ch++;
+    const int obs1 = pl.lm_start[l];
+    rec[0] = lm0;
+    rec[1] = l - lm0;
+    rec[2] = obs0;
+    rec[3] = obs1 - obs0;
+    rec[4] = n_ch;
+    for (int c = n_ch; c <= BF_MAXCH; c++) rec[BF_INFO_CB + c] = l - lm0;
+    if (rec[3] > BF_OBS_CAP) return false;  // (a single landmark has <= 64 observations: a logic guard)
+    // camera-major ranks of the free-camera observations of this workgroup
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int q = obs0; q < obs1; q++) {
+      const int fc = pl.cam_free[pl.s_cam[q]];
+      if (fc >= 0) cnt[fc + 1]++;
+    }
+    for (int c = 0; c < nfree; c++) cnt[c + 1] += cnt[c];
+    for (int c = 0; c <= nfree; c++) rec[BF_INFO_CAM + c] = cnt[c];
+    for (int q = obs0; q < obs1; q++) {
+      const int fc = pl.cam_free[pl.s_cam[q]];
+      if (fc >= 0) pl.meta[q] |= (unsigned)cnt[fc]++;
+    }
+    pl.wg_info.insert(pl.wg_info.end(), rec, rec + BF_INFO);
+    g++;
+  }
+  pl.G = g;
+  return g > 0;
+}
+
+#define BF_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return vsl_fail(ctx, VSL_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+struct ArenaLoan {  // the context's cached BA arena, or a private allocation when that one is lent out
+  vsl_ctx* ctx = nullptr;
+  void* p = nullptr;
+  bool owned = false, lent = false;
+  ~ArenaLoan() {
+    if (owned && p) (void)hipFree(p);
+    if (lent) ctx->ba_arena_busy = false;
+  }
+};
+
+}  // namespace
+
+// handled = 0: the problem does not fit the fused kernels (nothing was done); otherwise the solve ran (rc tells how).
+int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary,
+                       int* handled) {
+  *handled = 0;
+  const double t_start = bf_now_ms();
+  BfPlan pl;
+  if (!bf_plan(prob, pl)) return VSL_OK;
+  *handled = 1;
+  BF_HIP(hipSetDevice(ctx->device));
+  BaDims D;
+  D.C = prob->n_cams;
+  D.L = prob->n_lms;
+  D.O = prob->n_obs;
+  D.nfree = pl.nfree;
+  D.n = 6 * pl.nfree;
+  D.model0 = prob->cam_model[0];
+  D.model1 = prob->cam_model[1];
+  D.use_huber = opt->use_huber;
+  D.huber = opt->huber_parameter;
+  const int n = D.n, G = pl.G, NT = pl.NP / 16, T = NT * (NT + 1) / 2;
+  const size_t C = D.C, L = D.L, O = D.O;
+  // one arena
+  struct Want {
+    void** p;
+    size_t bytes;
+  };
+  double *poses, *cand_poses, *points, *cand_points, *intr, *obs_uv, *scale_c, *scale_l, *Pinv, *bl, *S_part, *hc_part,
+      *sc_part, *S, *rhs, *dc;
+  int *cam_intr, *cam_free, *obs_cam, *lm_start, *wg_info;
+  unsigned *obs_meta, *lm_pres;
+  std::vector<Want> want = {{(void**)&poses, 56 * C}, {(void**)&cand_poses, 56 * C}, {(void**)&points, 24 * L},
+                            {(void**)&cand_points, 24 * L}, {(void**)&intr, 128}, {(void**)&obs_uv, 16 * O},
+                            {(void**)&scale_c, 8 * 128}, {(void**)&scale_l, 24 * L}, {(void**)&Pinv, 72 * L},
+                            {(void**)&bl, 24 * L}, {(void**)&S_part, 2048 * (size_t)T * G},
+                            {(void**)&hc_part, 216 * (size_t)pl.nfree * G}, {(void**)&sc_part, 16 * (size_t)G},
+                            {(void**)&S, 8 * (size_t)n * n}, {(void**)&rhs, 8 * 128}, {(void**)&dc, 8 * 128},
+                            {(void**)&cam_intr, 4 * C}, {(void**)&cam_free, 4 * C}, {(void**)&obs_cam, 4 * O},
+                            {(void**)&lm_start, 4 * (L + 1)}, {(void**)&wg_info, 4 * (size_t)BF_INFO * G},
+                            {(void**)&obs_meta, 4 * O}, {(void**)&lm_pres, 4 * L}};
+  size_t total = 0;
+  for (auto& w : want) total += (std::max<size_t>(w.bytes, 8) + 255) & ~(size_t)255;
+  ArenaLoan loan;
+  loan.ctx = ctx;
+  if (ctx->ba_arena_busy) {
+    BF_HIP(hipMalloc(&loan.p, total));
+    loan.owned = true;
+  } else {
+    if (ctx->ba_arena_cap < total) {
+      BF_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
+      ctx->ba_arena = nullptr;
+      ctx->ba_arena_cap = 0;
+      const size_t cap = total + total / 4;
+      BF_HIP(hipMalloc(&ctx->ba_arena, cap));
+      ctx->ba_arena_cap = cap;
+    }
+    loan.p = ctx->ba_arena;
+    ctx->ba_arena_busy = true;
+    loan.lent = true;
+  }
+  {
+    size_t off = 0;
+    for (auto& w : want) {
+      *w.p = (char*)loan.p + off;
+      off += (std::max<size_t>(w.bytes, 8) + 255) & ~(size_t)255;
+    }
+  }
+  // pinned mailbox the kernels write their scalars into: [0] cost, [1] max |landmark gradient|, [2] (int) Cholesky ok,
+  // [4 .. 132) |camera gradient| per unknown, [132 .. 132 + 5 G) step partials
+  const size_t mail_doubles = 132 + 5 * (size_t)G;
+  if (ctx->ba_mail_cap < mail_doubles) {
+    BF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ba_mail) (void)hipHostFree(ctx->ba_mail);
+    ctx->ba_mail = nullptr;
+    ctx->ba_mail_cap = 0;
+    const size_t cap = mail_doubles + 5 * 256;
+    BF_HIP(hipHostMalloc((void**)&ctx->ba_mail, 8 * cap, hipHostMallocMapped | hipHostMallocCoherent));
+    ctx->ba_mail_cap = cap;
+  }
+  volatile double* mail = ctx->ba_mail;
+  volatile int* chol_ok = (volatile int*)(ctx->ba_mail + 2);
+  volatile double* gabs = ctx->ba_mail + 4;
+  volatile double* step_part = ctx->ba_mail + 132;
+  auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+  };
+  BF_HIP(up(poses, prob->poses, 56 * C));
+  BF_HIP(up(points, prob->points, 24 * L));
+  BF_HIP(up(intr, prob->intr, 128));
+  BF_HIP(up(cam_intr, prob->cam_intr, 4 * C));
+  BF_HIP(up(cam_free, pl.cam_free.data(), 4 * C));
+  BF_HIP(up(obs_cam, pl.s_cam.data(), 4 * O));
+  BF_HIP(up(obs_uv, pl.s_uv.data(), 16 * O));
+  BF_HIP(up(obs_meta, pl.meta.data(), 4 * O));
+  BF_HIP(up(lm_start, pl.lm_start.data(), 4 * (L + 1)));
+  BF_HIP(up(lm_pres, pl.pres.data(), 4 * L));
+  BF_HIP(up(wg_info, pl.wg_info.data(), 4 * (size_t)BF_INFO * G));
+
+  BfArgs a;
+  a.D = D;
+  a.NP = pl.NP;
+  a.NPs = pl.NPs;
+  a.NT = NT;
+  a.T = T;
+  a.poses = poses;
+  a.points = points;
+  a.intr = intr;
+  a.cam_intr = cam_intr;
+  a.cam_free = cam_free;
+  a.obs_cam = obs_cam;
+  a.obs_uv = obs_uv;
+  a.obs_meta = obs_meta;
+  a.lm_start = lm_start;
+  a.lm_pres = lm_pres;
+  a.wg_info = wg_info;
+  a.scale_c = scale_c;
+  a.scale_l = scale_l;
+  a.Pinv = Pinv;
+  a.bl = bl;
+  a.S_part = S_part;
+  a.hc_part = hc_part;
+  a.sc_part = sc_part;
+
+  vsl_ba_summary sum;
+  memset(&sum, 0, sizeof(sum));
+  const bool prof_was = ctx->profiling;
+  double base_ms[3];
+  for (int k = 0; k < 3; k++) base_ms[k] = ctx->stage_ms[VSL_STAGE_BA_LIN + k];
+
+  // Jacobi scaling from the unscaled Jacobian + the initial cost
+  {
+    VslStage s(ctx, VSL_STAGE_BA_LIN);
+    hipLaunchKernelGGL((baf_schur_kernel<true, 1>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, 0.0);
+    hipLaunchKernelGGL(baf_init_finish_kernel, dim3((n + 15) / 16 + 1), dim3(256), 0, ctx->stream, n, pl.nfree, G, hc_part,
+                       sc_part, scale_c, ctx->ba_mail);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  BF_HIP(hipStreamSynchronize(ctx->stream));  // (the uploads above read host vectors of the plan: they are done now)
+  double cost = mail[0];
+  sum.initial_cost = cost;
+
+  double radius = 1e4, decrease_factor = 2.0;
+  int iteration = 0, invalid = 0;
+  sum.termination = 0;
+  if (opt->verbosity >= 2)
+    fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, cost);
+  while (true) {
+    if (iteration >= opt->max_num_iterations) { sum.termination = 0; break; }
+    // the whole iteration is enqueued without waiting; the gradient norm of the CURRENT point comes back with it
+    // (it is a by-product of the Schur kernel), so the gradient-tolerance test is taken before the iteration counts
+    const double inv_radius = 1.0 / radius;
+    {
+      VslStage s(ctx, VSL_STAGE_BA_SCHUR);
+      if (T <= BF_WAVES)
+        hipLaunchKernelGGL((baf_schur_kernel<false, 1>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, inv_radius);
+      else if (T <= 2 * BF_WAVES)
+        hipLaunchKernelGGL((baf_schur_kernel<false, 2>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, inv_radius);
+      else
+        hipLaunchKernelGGL((baf_schur_kernel<false, 3>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, inv_radius);
+      hipLaunchKernelGGL(baf_finish_kernel, dim3((n * n + 15) / 16 + (n + 15) / 16 + 1), dim3(256), 0, ctx->stream, n, pl.nfree,
+                         G, T, S_part, hc_part, sc_part, scale_c, inv_radius, S, rhs, ctx->ba_mail, ctx->ba_mail + 4);
+      VSL_CHECK_LAUNCH(ctx);
+    }
+    {
+      VslStage s(ctx, VSL_STAGE_BA_SOLVE);
+      hipLaunchKernelGGL(baf_chol_kernel, dim3(1), dim3(BF_THREADS), 0, ctx->stream, n, S, rhs, dc, (int*)(ctx->ba_mail + 2));
+      VSL_CHECK_LAUNCH(ctx);
+    }
+    {
+      VslStage s(ctx, VSL_STAGE_BA_LIN);
+      hipLaunchKernelGGL(baf_step_kernel, dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, dc, cand_poses, cand_points,
+                         ctx->ba_mail + 132);
+      VSL_CHECK_LAUNCH(ctx);
+    }
+    BF_HIP(hipStreamSynchronize(ctx->stream));
+    double gmax = mail[1];
+    for (int x = 0; x < n; x++) gmax = std::max(gmax, (double)gabs[x]);
+    if (gmax <= 1e-10) { sum.termination = 2; break; }
+    if (radius <= 1e-32) { sum.termination = 4; break; }
+    iteration++;
+    double model_change = 0, cand_cost = 0, step2 = 0, x2 = 0, bad = 0;
+    for (int g = 0; g < G; g++) {  // workgroup order: fixed
+      model_change += step_part[5 * g];
+      cand_cost += step_part[5 * g + 1];
+      step2 += step_part[5 * g + 2];
+      x2 += step_part[5 * g + 3];
+      bad += step_part[5 * g + 4];
+    }
+    const double step_norm = sqrt(step2), x_norm = sqrt(x2);
+    const bool ok = *chol_ok != 0 && bad == 0.0 && model_change > 0.0;
+    if (!ok) {
+      if (++invalid >= 5) { sum.termination = 4; break; }
+      radius *= 0.5;
+      if (opt->verbosity >= 2) fprintf(stderr, "%4d  invalid step, radius %.3e\n", iteration, radius);
+      continue;
+    }
+    invalid = 0;
+    if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 3; break; }
+    const double cost_change = cost - cand_cost;
+    if (fabs(cost_change) <= 1e-6 * cost) { sum.termination = 1; break; }
+    const double rel = cost_change / model_change;
+    if (opt->verbosity >= 2)
+      fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", iteration, cand_cost, cost_change, gmax, step_norm, rel, radius);
+    if (rel > 1e-3) {
+      cost = cand_cost;
+      std::swap(poses, cand_poses);
+      std::swap(points, cand_points);
+      a.poses = poses;
+      a.points = points;
+      sum.successful_steps++;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3));
+      radius = std::min(1e16, radius);
+      decrease_factor = 2.0;
+    } else {
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+    }
+  }
+  sum.iterations = iteration;
+  sum.final_cost = cost;
+  BF_HIP(hipMemcpyAsync(prob->poses, poses, 56 * C, hipMemcpyDeviceToHost, ctx->stream));
+  BF_HIP(hipMemcpyAsync(prob->points, points, 24 * L, hipMemcpyDeviceToHost, ctx->stream));
+  BF_HIP(hipStreamSynchronize(ctx->stream));
+  double ms;
+  int64_t cnt;
+  vsl_ctx_stage_ms(ctx, VSL_STAGE_BA_LIN, &ms, &cnt);  // drains the pending stage events
+  sum.linearize_ms = ctx->stage_ms[VSL_STAGE_BA_LIN] - base_ms[0];
+  sum.schur_ms = ctx->stage_ms[VSL_STAGE_BA_SCHUR] - base_ms[1];
+  sum.solve_ms = ctx->stage_ms[VSL_STAGE_BA_SOLVE] - base_ms[2];
+  vsl_ctx_set_profiling(ctx, prof_was ? 1 : 0);
+  sum.total_ms = bf_now_ms() - t_start;
+  if (opt->verbosity >= 1)
+    fprintf(stderr, "vsl BA: iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n", sum.iterations,
+            sum.initial_cost, sum.final_cost, sum.termination, sum.total_ms);
+  if (summary) *summary = sum;
+  return VSL_OK;
+}

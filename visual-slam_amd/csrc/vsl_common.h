@@ -61,6 +61,9 @@ struct vsl_ctx {
   void* ba_arena = nullptr;
   size_t ba_arena_cap = 0;
   bool ba_arena_busy = false;
+  // pinned, device-mapped mailbox of the fused local-BA iteration (ba_fused.hip): kernels post their scalars there
+  double* ba_mail = nullptr;
+  size_t ba_mail_cap = 0;  // doubles
   bool select_attr_set = false;
   bool bow_score_attr_set = false;  // per context, hence per device: hipFuncSetAttribute is a per-device setting
   double* status_word = nullptr;    // 64 device bytes allocated with the context: the flag of status exchanges between ranks (never null in a live context)
@@ -76,6 +79,7 @@ struct vsl_ctx {
   bool chol_no_fused = false;           // diagnostic: band Cholesky as one launch per panel step instead of the fused single-launch kernel
   bool ba_force_dense = false;          // diagnostic: dense reduced camera system even where the band form applies
   bool ba_schur_atomics = false;        // diagnostic: large-system Schur complement by fp64 atomics (one wavefront per landmark) instead of the per-block gather
+  bool ba_no_fused = false;             // diagnostic: local windows by the operator-by-operator kernels of ba.hip instead of the fused iteration (ba_fused.hip)
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int describe_tile_min_images = 96;   // describe launches of at least this many images use the shared-tile kernel (measured break-even ~64 images; diagnostic: 1 forces it, 0 disables it)
   bool bow_keys64 = false;              // diagnostic: 64-bit sort keys in the BowVector assembly even where (id, feature) fits 32 bits
@@ -86,6 +90,11 @@ struct vsl_ctx {
 };
 
 int vsl_fail(vsl_ctx* ctx, int code, const char* fmt, ...);
+
+// ba_fused.hip: the local-window LM loop in four launches per iteration; *handled = 0 when the problem does not fit it
+int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary, int* handled);
+// ba.hip: dc = -(S^-1 rhs) for n <= 128 by one workgroup (enqueued); *ok_flag (device-visible memory) = 1 / 0
+int vsl_ba_chol_small_launch(vsl_ctx* ctx, int n, const double* S, const double* rhs, double* dc, int* ok_flag);
 
 #define VSL_HIP(ctx, call)                                                                        \
   do {                                                                                            \
