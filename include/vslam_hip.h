@@ -91,7 +91,9 @@ enum {
   VSL_STAGE_BA_SOLVE = 7, /* reduced camera system Cholesky + back-subst.     */
   VSL_STAGE_BOW_TRANSFORM = 8,
   VSL_STAGE_BOW_SCORE = 9,
-  VSL_STAGE_COUNT = 10
+  VSL_STAGE_BA_FINISH = 10, /* fused local BA: sum of the per-workgroup partials + damping   */
+  VSL_STAGE_BA_STEP = 11,   /* fused local BA: back-substitution, model change, candidate    */
+  VSL_STAGE_COUNT = 12
 };
 int vsl_ctx_set_profiling(vsl_ctx* ctx, int enabled);
 int vsl_ctx_stage_ms(vsl_ctx* ctx, int stage, double* total_ms, int64_t* launches);
@@ -407,6 +409,9 @@ int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduce, void* us
  * count, rank `rank` owns one, prob->poses / prob->points updated in place on every rank. */
 int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
                              vsl_allreduce_fn allreduce, void* user, int rank, int world, vsl_ba_summary* summary);
+/* Diagnostic: storage of the reduced camera system in the last solve the general path (vsl_bundle_adjust beyond the
+ * local window, sessions, vsl_global_bundle_adjust) set up on this context: doubles of S, band form or dense, bandwidth. */
+int vsl_ctx_last_ba_layout(vsl_ctx* ctx, int64_t* s_elems, int* banded, int* bandwidth);
 /* Plain synchronous copy on the context's device (kind 0 host->device, 1 device->host, 2 device->device): for
  * callers that hold device pointers handed out by this library (all-reduce callbacks). */
 int vsl_ctx_memcpy(vsl_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);

@@ -26,7 +26,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 STAGES = ["response", "select", "describe", "match", "match_finalize", "ba_linearize", "ba_schur",
-          "ba_solve", "bow_transform", "bow_score"]
+          "ba_solve", "bow_transform", "bow_score", "ba_finish", "ba_step"]
 
 OK = 0
 ERR = {-1: "VSL_ERR_INVALID", -2: "VSL_ERR_HIP", -3: "VSL_ERR_NOMEM", -4: "VSL_ERR_CAPACITY",
@@ -143,6 +143,12 @@ class Context:
 
     def set_profiling(self, on):
         self._ck(self.L.vsl_ctx_set_profiling(self.h, int(on)))
+
+    def last_ba_layout(self):
+        """(doubles of S, banded, bandwidth) of the last general-path bundle adjustment set up on this context."""
+        e, b, w = C.c_int64(), C.c_int(), C.c_int()
+        self._ck(self.L.vsl_ctx_last_ba_layout(self.h, C.byref(e), C.byref(b), C.byref(w)))
+        return e.value, bool(b.value), w.value
 
     def reset_profiling(self):
         self._ck(self.L.vsl_ctx_reset_profiling(self.h))

@@ -1483,6 +1483,10 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       st.s_elems = (size_t)D.n * (bws + 1) + 64;  // + slack: the diagonal kernels read (never use) a few entries past a row
     }
   }
+  // (diagnostic read-out for benchmarks: vsl_ctx_last_ba_layout)
+  ctx->last_ba_s_elems = (int64_t)st.s_elems;
+  ctx->last_ba_banded = st.banded ? 1 : 0;
+  ctx->last_ba_bw = st.bw;
   tr.lap("free cameras + band order");
   // sort observations by landmark (stable: keeps the caller's order inside a landmark)
   std::vector<int> lm_start(D.L + 1, 0);
@@ -2569,6 +2573,14 @@ extern "C" int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob
   rc = vsl_ba_session_solve(s, allreduce, user, world, opt->max_num_iterations, opt->verbosity, prob->poses, prob->points, summary);
   vsl_ba_session_destroy(s);
   return rc;
+}
+
+extern "C" int vsl_ctx_last_ba_layout(vsl_ctx* ctx, int64_t* s_elems, int* banded, int* bandwidth) {
+  if (!ctx) return VSL_ERR_INVALID;
+  if (s_elems) *s_elems = ctx->last_ba_s_elems;
+  if (banded) *banded = ctx->last_ba_banded;
+  if (bandwidth) *bandwidth = ctx->last_ba_bw;
+  return VSL_OK;
 }
 
 // Plain copies for callers that hold device pointers of this library (the all-reduce callbacks of the tests):

@@ -12,7 +12,7 @@
 //   round 3:  linearize -> r / F / E (160 B per observation) in global memory, read back by Schur, back-substitution,
 //             model, per-camera blocks, column norms: 14 launches per iteration, >= 4.5 x the algorithmic bytes.
 //   here:     a workgroup owns a contiguous range of landmarks with <= 1024 observations, ONE THREAD PER OBSERVATION.
-//     1 baf_schur_kernel   loads the 28 B of an observation (camera, detected corner, static layout word), evaluates the
+//     1 baf_schur_kernel   loads the 20 B of an observation (detected corner, static layout word with the camera), evaluates the
 //                          residual and the Jacobian blocks into REGISTERS, reduces E^T E / E^T r per landmark through
 //                          LDS and inverts the damped 3 x 3 blocks; the per-camera blocks F^T F, F^T r come from a
 //                          camera-major LDS copy of F and r; then, <= 29 landmarks at a time, W = F^T E and -Y = -W P^-1
@@ -61,9 +61,9 @@ namespace {
 typedef double bf_v4d __attribute__((ext_vector_type(4)));
 
 // static word of an observation: camera-major rank in the workgroup (10) | landmark in chunk (5) << 10 | chunk (4) << 15 |
-// landmark in workgroup (7) << 19 | free camera (1) << 26
-__host__ __device__ inline unsigned bf_pack(unsigned rank, unsigned li, unsigned chunk, unsigned lml, unsigned is_free) {
-  return rank | (li << 10) | (chunk << 15) | (lml << 19) | (is_free << 26);
+// landmark in workgroup (7) << 19 | camera (6) << 26
+__host__ __device__ inline unsigned bf_pack(unsigned rank, unsigned li, unsigned chunk, unsigned lml, unsigned cam) {
+  return rank | (li << 10) | (chunk << 15) | (lml << 19) | (cam << 26);
 }
 
 struct BfArgs {
@@ -77,7 +77,6 @@ struct BfArgs {
   const double* intr;
   const int* cam_intr;
   const int* cam_free;
-  const int* obs_cam;
   const double* obs_uv;
   const unsigned* obs_meta;
   const int* lm_start;
@@ -157,11 +156,11 @@ __device__ __forceinline__ void bf_load(const BfArgs& a, const BfShared& sh, int
   uv[0] = uv[1] = 0.0;
   if (o.have) {
     const size_t i = (size_t)obs0 + tid;
-    o.cam = a.obs_cam[i];
     o.meta = a.obs_meta[i];
     uv[0] = a.obs_uv[2 * i];
     uv[1] = a.obs_uv[2 * i + 1];
   }
+  o.cam = (int)(o.meta >> 26);
   o.lml = (int)((o.meta >> 19) & 0x7Fu);
 }
 
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(BF_THREADS) void baf_schur_kernel(BfArgs a, double 
   BF_STAMP(2)
   // per-camera blocks: F | r of the free-camera observations in camera-major order, then thread (camera, entry) walks
   // its camera's run -- addresses are affine in the loop counter, the loads pipeline
-  const bool is_free = ((o.meta >> 26) & 1u) != 0;
+  const bool is_free = o.fc >= 0;  // (idle threads: -1)
   if (is_free) {
     double* f = R + 14 * (size_t)(o.meta & 0x3FFu);
 #pragma unroll
@@ -500,69 +499,52 @@ __global__ __launch_bounds__(256) void baf_finish_kernel(int n, int nfree, int G
                                                          const double* __restrict__ scale_c, double inv_radius,
                                                          double* __restrict__ S, double* __restrict__ rhs,
                                                          double* __restrict__ host_out, double* __restrict__ host_gabs) {
+  // A workgroup sums 16 CONSECUTIVE doubles of the tile partials (128 contiguous bytes per partial: the first version
+  // walked the partials entry by entry of S, 8 bytes out of every 32 -- FETCH_SIZE 45 MB for 8 MB of partials) and
+  // scatters the sums to the entries of S they are: element q of lane l of tile (ti, tj) is
+  // D[16 ti + (l >> 4) + 4 q][16 tj + (l & 15)], mirrored for the tiles below the diagonal; row n is the right-hand side.
   __shared__ double sh[16][17];
   __shared__ double sh2[16][17];
-  const int nS = (n * n + 15) / 16, nV = (n + 15) / 16;
+  const int nR = T * 16;  // workgroups over the raw tile elements
   const int per = (G + 15) / 16;
   const int e = threadIdx.x & 15, c = threadIdx.x >> 4;
   const int g_a = min(G, c * per), g_b = min(G, (c + 1) * per);
-  if ((int)blockIdx.x < nS) {
-    const int idx = blockIdx.x * 16 + e;
+  if ((int)blockIdx.x < nR) {
+    const int raw = blockIdx.x * 16 + e;
+    const int tile = raw >> 8, l = (raw & 255) >> 2, q = raw & 3;
+    int ti, tj;
+    bf_tile_coords(tile, ti, tj);
+    const int i = 16 * ti + (l >> 4) + 4 * q, j = 16 * tj + (l & 15);
+    const bool in_S = i < n && j < n, is_rhs = i == n && j < n;
     double v = 0, hd = 0;
-    if (idx < n * n) {
-      const int i = idx / n, j = idx - i * n;
-      int ti = i >> 4, tj = j >> 4, ii = i & 15, jj = j & 15;
-      if (ti < tj) {
-        int t = ti; ti = tj; tj = t;
-        t = ii; ii = jj; jj = t;
-      }
-      // accumulator layout of v_mfma_f64_16x16x4_f64: element q of lane l is D[(l >> 4) + 4 q][l & 15]
-      const size_t off = (size_t)(ti * (ti + 1) / 2 + tj) * 256 + 4 * (16 * (ii & 3) + jj) + (ii >> 2);
-      v = bf_slice_sum<1>(S_part + off, (size_t)T * 256, g_a, g_b);
-      if (i / 6 == j / 6) {
-        const int a = i % 6, b = j % 6;
-        const int k = (i / 6) * 27 + bf_tri6(min(a, b), max(a, b));
-        hd = bf_slice_sum<0>(hc_part + k, (size_t)nfree * 27, g_a, g_b);
-      }
+    if (in_S || is_rhs) v = bf_slice_sum<1>(S_part + raw, (size_t)T * 256, g_a, g_b);
+    int hk = -1;
+    if (in_S && i / 6 == j / 6) {
+      const int a = i % 6, b = j % 6;
+      hk = (i / 6) * 27 + bf_tri6(min(a, b), max(a, b));
+    } else if (is_rhs) {
+      hk = (j / 6) * 27 + 21 + j % 6;  // g_c
     }
+    if (hk >= 0) hd = bf_slice_sum<0>(hc_part + hk, (size_t)nfree * 27, g_a, g_b);
     sh[c][e] = v;
     sh2[c][e] = hd;
     __syncthreads();
-    if (c == 0 && idx < n * n) {
+    if (c == 0 && (in_S || is_rhs)) {
       double t = 0, h = 0;
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         t += sh[k][e];
         h += sh2[k][e];
       }
-      const int i = idx / n, j = idx - i * n;
-      t += h;
-      if (i == j) t += fmin(fmax(h, 1e-6), 1e32) * inv_radius;
-      S[idx] = t;
-    }
-    return;
-  }
-  if ((int)blockIdx.x < nS + nV) {  // right-hand side: row n of the tile row tn, + g_c
-    const int x = (blockIdx.x - nS) * 16 + e;
-    double ry = 0, gc = 0;
-    if (x < n) {
-      const int tn = n >> 4, in = n & 15;
-      const size_t off = (size_t)(tn * (tn + 1) / 2 + (x >> 4)) * 256 + 4 * (16 * (in & 3) + (x & 15)) + (in >> 2);
-      ry = bf_slice_sum<1>(S_part + off, (size_t)T * 256, g_a, g_b);
-      gc = bf_slice_sum<0>(hc_part + (x / 6) * 27 + 21 + x % 6, (size_t)nfree * 27, g_a, g_b);
-    }
-    sh[c][e] = ry;
-    sh2[c][e] = gc;
-    __syncthreads();
-    if (c == 0 && x < n) {
-      double t = 0, g = 0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        t += sh[k][e];
-        g += sh2[k][e];
+      if (is_rhs) {
+        rhs[j] = t + h;
+        host_gabs[j] = fabs(h / scale_c[j]);  // gradient of the UNSCALED problem, camera part
+      } else {
+        t += h;
+        if (i == j) t += fmin(fmax(h, 1e-6), 1e32) * inv_radius;
+        S[(size_t)i * n + j] = t;
+        if (ti != tj) S[(size_t)j * n + i] = t;
       }
-      rhs[x] = t + g;
-      host_gabs[x] = fabs(g / scale_c[x]);  // gradient of the UNSCALED problem, camera part
     }
     return;
   }
@@ -977,73 +959,99 @@ double bf_now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// The static layout of a solve, written straight into ONE pinned host block that goes to the device with ONE copy
+// (eleven pageable hipMemcpyAsync calls were 0.15 ms, the std::vector passes of the first version 0.9 ms at 157 k
+// observations):  [poses | points | intr | cam_intr | cam_free | obs_uv | obs_meta | lm_start | lm_pres | wg_info].
+struct BfLayout {
+  size_t poses, points, intr, cam_intr, cam_free, obs_uv, obs_meta, lm_start, lm_pres, wg_info, bytes;
+  int g_cap;
+};
+BfLayout bf_layout(int C, int L, int O) {
+  BfLayout y;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return at;
+  };
+  y.poses = take(56 * (size_t)C);
+  y.points = take(24 * (size_t)L);
+  y.intr = take(128);
+  y.cam_intr = take(4 * (size_t)C);
+  y.cam_free = take(4 * (size_t)C);
+  y.obs_uv = take(16 * (size_t)O);
+  y.obs_meta = take(4 * (size_t)O);
+  y.lm_start = take(4 * ((size_t)L + 1));
+  y.lm_pres = take(4 * (size_t)L);
+  // workgroups: <= 256 by observation count, + whatever the per-workgroup caps (128 landmarks, 16 chunks) force
+  y.g_cap = 256 + O / 512 + L / 16 + 16;
+  y.wg_info = take(4 * (size_t)BF_INFO * y.g_cap);
+  y.bytes = off;
+  return y;
+}
+
 struct BfPlan {
   int G = 0, nfree = 0, NP = 0, NPs = 0, lc_max = 0;
-  std::vector<int> cam_free, lm_start, wg_info, s_cam;
-  std::vector<int> perm;  // sorted position -> caller observation index
-  std::vector<unsigned> meta, pres;
-  std::vector<double> s_uv;
 };
 
-// Lays the problem out for the fused kernels; false when it does not fit them (the caller takes the general path).
-bool bf_plan(const vsl_ba_problem* p, BfPlan& pl) {
+// Lays the problem out for the fused kernels into `blk`; false when it does not fit them (the caller takes the general path).
+bool bf_plan(const vsl_ba_problem* p, const BfLayout& y, char* blk, BfPlan& pl) {
   const int C = p->n_cams, L = p->n_lms, O = p->n_obs;
-  if (C > BF_CAMS) return false;
-  pl.cam_free.assign(C, -1);
+  int* cam_free = (int*)(blk + y.cam_free);
   int nfree = 0;
-  for (int c = 0; c < C; c++)
-    if (!p->cam_fixed[c]) pl.cam_free[c] = nfree++;
+  for (int c = 0; c < C; c++) cam_free[c] = p->cam_fixed[c] ? -1 : nfree++;
   pl.nfree = nfree;
   if (nfree < 1 || 6 * nfree > 126) return false;
   const int n = 6 * nfree;
   pl.NP = 16 * ((n + 16) / 16);  // the unknowns and the right-hand-side row, in whole tiles
   pl.NPs = (pl.NP % 32 == 16) ? pl.NP : pl.NP + 16;
   pl.lc_max = std::min(31, (((BF_R / 2) / pl.NPs) & ~3) / 3);  // K = 3 columns per landmark, padded to the matrix instruction's 4
-  // observations sorted by landmark (stable)
-  pl.lm_start.assign(L + 1, 0);
-  for (int i = 0; i < O; i++) pl.lm_start[p->obs_lm[i] + 1]++;
-  for (int l = 0; l < L; l++) pl.lm_start[l + 1] += pl.lm_start[l];
-  pl.perm.resize(O);
-  {
-    std::vector<int> fill(pl.lm_start.begin(), pl.lm_start.end() - 1);
-    for (int i = 0; i < O; i++) pl.perm[fill[p->obs_lm[i]]++] = i;
+  memcpy(blk + y.poses, p->poses, 56 * (size_t)C);
+  memcpy(blk + y.points, p->points, 24 * (size_t)L);
+  memcpy(blk + y.intr, p->intr, 128);
+  memcpy(blk + y.cam_intr, p->cam_intr, 4 * (size_t)C);
+  // observations by landmark (stable).  The reference's own order (map_utils.h:373: landmarks, then their observations)
+  // -- what include/visnav_amd/bundle_adjustment.h hands over -- is sorted already: one copy, no scatter
+  int* lm_start = (int*)(blk + y.lm_start);
+  unsigned* meta = (unsigned*)(blk + y.obs_meta);
+  double* s_uv = (double*)(blk + y.obs_uv);
+  memset(lm_start, 0, 4 * ((size_t)L + 1));
+  bool sorted = true;
+  for (int i = 0; i < O; i++) {
+    lm_start[p->obs_lm[i] + 1]++;
+    if (i > 0 && p->obs_lm[i] < p->obs_lm[i - 1]) sorted = false;
   }
-  pl.s_cam.resize(O);
-  pl.s_uv.resize(2 * (size_t)O);
-  for (int q = 0; q < O; q++) {
-    const int i = pl.perm[q];
-    pl.s_cam[q] = p->obs_cam[i];
-    pl.s_uv[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
-    pl.s_uv[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
-  }
-  // per landmark: which free cameras see it; a camera seeing a landmark twice would write one operand entry twice
-  pl.pres.assign(L, 0u);
-  for (int l = 0; l < L; l++) {
-    const int a = pl.lm_start[l], b = pl.lm_start[l + 1];
-    if (b - a > 64) return false;
-    unsigned m = 0;
-    for (int q = a; q < b; q++) {
-      const int fc = pl.cam_free[pl.s_cam[q]];
-      if (fc < 0) continue;
-      if (m & (1u << fc)) return false;
-      m |= 1u << fc;
+  for (int l = 0; l < L; l++) lm_start[l + 1] += lm_start[l];
+  if (sorted) {
+    memcpy(s_uv, p->obs_uv, 16 * (size_t)O);
+    for (int i = 0; i < O; i++) meta[i] = (unsigned)p->obs_cam[i] << 26;
+  } else {
+    unsigned* fill = (unsigned*)(blk + y.lm_pres);  // borrowed as the scatter cursor; rewritten below
+    for (int l = 0; l < L; l++) fill[l] = (unsigned)lm_start[l];
+    for (int i = 0; i < O; i++) {
+      const unsigned q = fill[p->obs_lm[i]]++;
+      meta[q] = (unsigned)p->obs_cam[i] << 26;
+      s_uv[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
+      s_uv[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
     }
-    pl.pres[l] = m;
   }
   // workgroups: contiguous landmark ranges balanced by observation count, one thread per observation
+  unsigned* pres = (unsigned*)(blk + y.lm_pres);
+  int* wg_info = (int*)(blk + y.wg_info);
   int G0 = std::max(1, std::min(256, (O + 319) / 320));
   if ((O + G0 - 1) / G0 > 960) G0 = (O + 959) / 960;
-  pl.meta.assign(O, 0u);
-  pl.wg_info.clear();
   int l = 0, g = 0;
-  std::vector<int> cnt(nfree + 1);
+  int cnt[BF_CAMS + 1];
   while (l < L) {
+    if (g >= y.g_cap) return false;
     const long long target = (long long)O * (g + 1) / G0;  // cumulative observations this workgroup should reach
-    int rec[BF_INFO] = {0};
-    const int lm0 = l, obs0 = pl.lm_start[l];
+    int* rec = wg_info + (size_t)BF_INFO * g;
+    memset(rec, 0, 4 * BF_INFO);
+    const int lm0 = l, obs0 = lm_start[l];
     int n_ch = 0, ch_lm = 0;
     while (l < L) {
-      const int a = pl.lm_start[l], b = pl.lm_start[l + 1];
+      const int a = lm_start[l], b = lm_start[l + 1];
+      if (b - a > 64) return false;
       const bool wg_has = l > lm0;
       if (wg_has && (b - obs0 > BF_OBS_CAP || l - lm0 >= BF_LMW)) break;
       if (wg_has && a >= target && g + 1 < G0) break;
@@ -1053,13 +1061,23 @@ bool bf_plan(const vsl_ba_problem* p, BfPlan& pl) {
         rec[BF_INFO_CB + n_ch] = l - lm0;
         ch_lm = 0;
       }
-      for (int q = a; q < b; q++)
-        pl.meta[q] = bf_pack(0, (unsigned)ch_lm, (unsigned)n_ch, (unsigned)(l - lm0), pl.cam_free[pl.s_cam[q]] >= 0 ? 1u : 0u);
+      // which free cameras see the landmark; a camera seeing it twice would write one operand entry twice
+      unsigned m = 0;
+      const unsigned word = bf_pack(0, (unsigned)ch_lm, (unsigned)n_ch, (unsigned)(l - lm0), 0);
+      for (int q = a; q < b; q++) {
+        const int fc = cam_free[meta[q] >> 26];
+        if (fc >= 0) {
+          if (m & (1u << fc)) return false;
+          m |= 1u << fc;
+        }
+        meta[q] |= word;
+      }
+      pres[l] = m;
       ch_lm++;
       l++;
     }
     n_ch++;
-    const int obs1 = pl.lm_start[l];
+    const int obs1 = lm_start[l];
     rec[0] = lm0;
     rec[1] = l - lm0;
     rec[2] = obs0;
@@ -1068,18 +1086,17 @@ bool bf_plan(const vsl_ba_problem* p, BfPlan& pl) {
     for (int c = n_ch; c <= BF_MAXCH; c++) rec[BF_INFO_CB + c] = l - lm0;
     if (rec[3] > BF_OBS_CAP) return false;  // (a single landmark has <= 64 observations: a logic guard)
     // camera-major ranks of the free-camera observations of this workgroup
-    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int c = 0; c <= nfree; c++) cnt[c] = 0;
     for (int q = obs0; q < obs1; q++) {
-      const int fc = pl.cam_free[pl.s_cam[q]];
+      const int fc = cam_free[meta[q] >> 26];
       if (fc >= 0) cnt[fc + 1]++;
     }
     for (int c = 0; c < nfree; c++) cnt[c + 1] += cnt[c];
     for (int c = 0; c <= nfree; c++) rec[BF_INFO_CAM + c] = cnt[c];
     for (int q = obs0; q < obs1; q++) {
-      const int fc = pl.cam_free[pl.s_cam[q]];
-      if (fc >= 0) pl.meta[q] |= (unsigned)cnt[fc]++;
+      const int fc = cam_free[meta[q] >> 26];
+      if (fc >= 0) meta[q] |= (unsigned)cnt[fc]++;
     }
-    pl.wg_info.insert(pl.wg_info.end(), rec, rec + BF_INFO);
     g++;
   }
   pl.G = g;
@@ -1109,11 +1126,39 @@ struct ArenaLoan {  // the context's cached BA arena, or a private allocation wh
 int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary,
                        int* handled) {
   *handled = 0;
+  if (prob->n_cams > BF_CAMS) return VSL_OK;
   const double t_start = bf_now_ms();
-  BfPlan pl;
-  if (!bf_plan(prob, pl)) return VSL_OK;
-  *handled = 1;
+  const bool trace = getenv("VSL_BA_TRACE") != nullptr;  // phase times on stderr (developer aid)
+  double t_lap = t_start;
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const double t = bf_now_ms();
+    fprintf(stderr, "  [fused ba] %-32s %8.3f ms\n", what, t - t_lap);
+    t_lap = t;
+  };
   BF_HIP(hipSetDevice(ctx->device));
+  const size_t C = prob->n_cams, L = prob->n_lms, O = prob->n_obs;
+  const BfLayout y = bf_layout((int)C, (int)L, (int)O);
+  // the pinned block: the plan first, the kernels' mailbox behind it (one allocation, device-mapped)
+  //   mailbox: [0] cost, [1] max |landmark gradient|, [2] (int) Cholesky ok, [4 .. 132) |camera gradient| per unknown,
+  //            [132 .. 132 + 5 G) step partials
+  const size_t mail_doubles = 132 + 5 * (size_t)y.g_cap;
+  const size_t pin_bytes = y.bytes + 8 * mail_doubles;
+  if (ctx->ba_pin_cap < pin_bytes) {
+    BF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
+    ctx->ba_pin = nullptr;
+    ctx->ba_pin_cap = 0;
+    const size_t cap = pin_bytes + pin_bytes / 4;
+    BF_HIP(hipHostMalloc((void**)&ctx->ba_pin, cap, hipHostMallocMapped | hipHostMallocCoherent));
+    ctx->ba_pin_cap = cap;
+  }
+  char* blk = (char*)ctx->ba_pin;
+  double* mailbox = (double*)(blk + y.bytes);
+  BfPlan pl;
+  if (!bf_plan(prob, y, blk, pl)) return VSL_OK;
+  *handled = 1;
+  lap("plan");
   BaDims D;
   D.C = prob->n_cams;
   D.L = prob->n_lms;
@@ -1125,25 +1170,18 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   D.use_huber = opt->use_huber;
   D.huber = opt->huber_parameter;
   const int n = D.n, G = pl.G, NT = pl.NP / 16, T = NT * (NT + 1) / 2;
-  const size_t C = D.C, L = D.L, O = D.O;
-  // one arena
+  // one arena: the uploaded block, then what the kernels produce
   struct Want {
     void** p;
     size_t bytes;
   };
-  double *poses, *cand_poses, *points, *cand_points, *intr, *obs_uv, *scale_c, *scale_l, *Pinv, *bl, *S_part, *hc_part,
-      *sc_part, *S, *rhs, *dc;
-  int *cam_intr, *cam_free, *obs_cam, *lm_start, *wg_info;
-  unsigned *obs_meta, *lm_pres;
-  std::vector<Want> want = {{(void**)&poses, 56 * C}, {(void**)&cand_poses, 56 * C}, {(void**)&points, 24 * L},
-                            {(void**)&cand_points, 24 * L}, {(void**)&intr, 128}, {(void**)&obs_uv, 16 * O},
+  char* dblk;
+  double *cand_poses, *cand_points, *scale_c, *scale_l, *Pinv, *bl, *S_part, *hc_part, *sc_part, *S, *rhs, *dc;
+  std::vector<Want> want = {{(void**)&dblk, y.bytes}, {(void**)&cand_poses, 56 * C}, {(void**)&cand_points, 24 * L},
                             {(void**)&scale_c, 8 * 128}, {(void**)&scale_l, 24 * L}, {(void**)&Pinv, 72 * L},
                             {(void**)&bl, 24 * L}, {(void**)&S_part, 2048 * (size_t)T * G},
                             {(void**)&hc_part, 216 * (size_t)pl.nfree * G}, {(void**)&sc_part, 16 * (size_t)G},
-                            {(void**)&S, 8 * (size_t)n * n}, {(void**)&rhs, 8 * 128}, {(void**)&dc, 8 * 128},
-                            {(void**)&cam_intr, 4 * C}, {(void**)&cam_free, 4 * C}, {(void**)&obs_cam, 4 * O},
-                            {(void**)&lm_start, 4 * (L + 1)}, {(void**)&wg_info, 4 * (size_t)BF_INFO * G},
-                            {(void**)&obs_meta, 4 * O}, {(void**)&lm_pres, 4 * L}};
+                            {(void**)&S, 8 * (size_t)n * n}, {(void**)&rhs, 8 * 128}, {(void**)&dc, 8 * 128}};
   size_t total = 0;
   for (auto& w : want) total += (std::max<size_t>(w.bytes, 8) + 255) & ~(size_t)255;
   ArenaLoan loan;
@@ -1172,36 +1210,14 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
       off += (std::max<size_t>(w.bytes, 8) + 255) & ~(size_t)255;
     }
   }
-  // pinned mailbox the kernels write their scalars into: [0] cost, [1] max |landmark gradient|, [2] (int) Cholesky ok,
-  // [4 .. 132) |camera gradient| per unknown, [132 .. 132 + 5 G) step partials
-  const size_t mail_doubles = 132 + 5 * (size_t)G;
-  if (ctx->ba_mail_cap < mail_doubles) {
-    BF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->ba_mail) (void)hipHostFree(ctx->ba_mail);
-    ctx->ba_mail = nullptr;
-    ctx->ba_mail_cap = 0;
-    const size_t cap = mail_doubles + 5 * 256;
-    BF_HIP(hipHostMalloc((void**)&ctx->ba_mail, 8 * cap, hipHostMallocMapped | hipHostMallocCoherent));
-    ctx->ba_mail_cap = cap;
-  }
-  volatile double* mail = ctx->ba_mail;
-  volatile int* chol_ok = (volatile int*)(ctx->ba_mail + 2);
-  volatile double* gabs = ctx->ba_mail + 4;
-  volatile double* step_part = ctx->ba_mail + 132;
-  auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
-  };
-  BF_HIP(up(poses, prob->poses, 56 * C));
-  BF_HIP(up(points, prob->points, 24 * L));
-  BF_HIP(up(intr, prob->intr, 128));
-  BF_HIP(up(cam_intr, prob->cam_intr, 4 * C));
-  BF_HIP(up(cam_free, pl.cam_free.data(), 4 * C));
-  BF_HIP(up(obs_cam, pl.s_cam.data(), 4 * O));
-  BF_HIP(up(obs_uv, pl.s_uv.data(), 16 * O));
-  BF_HIP(up(obs_meta, pl.meta.data(), 4 * O));
-  BF_HIP(up(lm_start, pl.lm_start.data(), 4 * (L + 1)));
-  BF_HIP(up(lm_pres, pl.pres.data(), 4 * L));
-  BF_HIP(up(wg_info, pl.wg_info.data(), 4 * (size_t)BF_INFO * G));
+  volatile double* mail = mailbox;
+  volatile int* chol_ok = (volatile int*)(mailbox + 2);
+  volatile double* gabs = mailbox + 4;
+  volatile double* step_part = mailbox + 132;
+  // ONE copy: everything up to the used part of the workgroup records
+  BF_HIP(hipMemcpyAsync(dblk, blk, y.wg_info + 4 * (size_t)BF_INFO * G, hipMemcpyHostToDevice, ctx->stream));
+  double* poses = (double*)(dblk + y.poses);
+  double* points = (double*)(dblk + y.points);
 
   BfArgs a;
   a.D = D;
@@ -1211,15 +1227,14 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   a.T = T;
   a.poses = poses;
   a.points = points;
-  a.intr = intr;
-  a.cam_intr = cam_intr;
-  a.cam_free = cam_free;
-  a.obs_cam = obs_cam;
-  a.obs_uv = obs_uv;
-  a.obs_meta = obs_meta;
-  a.lm_start = lm_start;
-  a.lm_pres = lm_pres;
-  a.wg_info = wg_info;
+  a.intr = (const double*)(dblk + y.intr);
+  a.cam_intr = (const int*)(dblk + y.cam_intr);
+  a.cam_free = (const int*)(dblk + y.cam_free);
+  a.obs_uv = (const double*)(dblk + y.obs_uv);
+  a.obs_meta = (const unsigned*)(dblk + y.obs_meta);
+  a.lm_start = (const int*)(dblk + y.lm_start);
+  a.lm_pres = (const unsigned*)(dblk + y.lm_pres);
+  a.wg_info = (const int*)(dblk + y.wg_info);
   a.scale_c = scale_c;
   a.scale_l = scale_l;
   a.Pinv = Pinv;
@@ -1231,18 +1246,21 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   vsl_ba_summary sum;
   memset(&sum, 0, sizeof(sum));
   const bool prof_was = ctx->profiling;
-  double base_ms[3];
-  for (int k = 0; k < 3; k++) base_ms[k] = ctx->stage_ms[VSL_STAGE_BA_LIN + k];
+  // summary: linearize_ms = scaling pass + step kernels, schur_ms = Schur + finish kernels, solve_ms = the Cholesky
+  const int st_of[5] = {VSL_STAGE_BA_LIN, VSL_STAGE_BA_SCHUR, VSL_STAGE_BA_SOLVE, VSL_STAGE_BA_FINISH, VSL_STAGE_BA_STEP};
+  double base_ms[5];
+  for (int k = 0; k < 5; k++) base_ms[k] = ctx->stage_ms[st_of[k]];
 
   // Jacobi scaling from the unscaled Jacobian + the initial cost
   {
     VslStage s(ctx, VSL_STAGE_BA_LIN);
     hipLaunchKernelGGL((baf_schur_kernel<true, 1>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, 0.0);
     hipLaunchKernelGGL(baf_init_finish_kernel, dim3((n + 15) / 16 + 1), dim3(256), 0, ctx->stream, n, pl.nfree, G, hc_part,
-                       sc_part, scale_c, ctx->ba_mail);
+                       sc_part, scale_c, mailbox);
     VSL_CHECK_LAUNCH(ctx);
   }
-  BF_HIP(hipStreamSynchronize(ctx->stream));  // (the uploads above read host vectors of the plan: they are done now)
+  BF_HIP(hipStreamSynchronize(ctx->stream));
+  lap("arena + upload + scaling pass");
   double cost = mail[0];
   sum.initial_cost = cost;
 
@@ -1264,19 +1282,23 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
         hipLaunchKernelGGL((baf_schur_kernel<false, 2>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, inv_radius);
       else
         hipLaunchKernelGGL((baf_schur_kernel<false, 3>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, inv_radius);
-      hipLaunchKernelGGL(baf_finish_kernel, dim3((n * n + 15) / 16 + (n + 15) / 16 + 1), dim3(256), 0, ctx->stream, n, pl.nfree,
-                         G, T, S_part, hc_part, sc_part, scale_c, inv_radius, S, rhs, ctx->ba_mail, ctx->ba_mail + 4);
+      VSL_CHECK_LAUNCH(ctx);
+    }
+    {
+      VslStage s(ctx, VSL_STAGE_BA_FINISH);
+      hipLaunchKernelGGL(baf_finish_kernel, dim3(16 * T + 1), dim3(256), 0, ctx->stream, n, pl.nfree,
+                         G, T, S_part, hc_part, sc_part, scale_c, inv_radius, S, rhs, mailbox, mailbox + 4);
       VSL_CHECK_LAUNCH(ctx);
     }
     {
       VslStage s(ctx, VSL_STAGE_BA_SOLVE);
-      hipLaunchKernelGGL(baf_chol_kernel, dim3(1), dim3(BF_THREADS), 0, ctx->stream, n, S, rhs, dc, (int*)(ctx->ba_mail + 2));
+      hipLaunchKernelGGL(baf_chol_kernel, dim3(1), dim3(BF_THREADS), 0, ctx->stream, n, S, rhs, dc, (int*)(mailbox + 2));
       VSL_CHECK_LAUNCH(ctx);
     }
     {
-      VslStage s(ctx, VSL_STAGE_BA_LIN);
+      VslStage s(ctx, VSL_STAGE_BA_STEP);
       hipLaunchKernelGGL(baf_step_kernel, dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, dc, cand_poses, cand_points,
-                         ctx->ba_mail + 132);
+                         mailbox + 132);
       VSL_CHECK_LAUNCH(ctx);
     }
     BF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1325,16 +1347,20 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   }
   sum.iterations = iteration;
   sum.final_cost = cost;
+  lap("LM loop");
   BF_HIP(hipMemcpyAsync(prob->poses, poses, 56 * C, hipMemcpyDeviceToHost, ctx->stream));
   BF_HIP(hipMemcpyAsync(prob->points, points, 24 * L, hipMemcpyDeviceToHost, ctx->stream));
   BF_HIP(hipStreamSynchronize(ctx->stream));
   double ms;
   int64_t cnt;
   vsl_ctx_stage_ms(ctx, VSL_STAGE_BA_LIN, &ms, &cnt);  // drains the pending stage events
-  sum.linearize_ms = ctx->stage_ms[VSL_STAGE_BA_LIN] - base_ms[0];
-  sum.schur_ms = ctx->stage_ms[VSL_STAGE_BA_SCHUR] - base_ms[1];
-  sum.solve_ms = ctx->stage_ms[VSL_STAGE_BA_SOLVE] - base_ms[2];
+  double dms[5];
+  for (int k = 0; k < 5; k++) dms[k] = ctx->stage_ms[st_of[k]] - base_ms[k];
+  sum.linearize_ms = dms[0] + dms[4];
+  sum.schur_ms = dms[1] + dms[3];
+  sum.solve_ms = dms[2];
   vsl_ctx_set_profiling(ctx, prof_was ? 1 : 0);
+  lap("download");
   sum.total_ms = bf_now_ms() - t_start;
   if (opt->verbosity >= 1)
     fprintf(stderr, "vsl BA: iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n", sum.iterations,

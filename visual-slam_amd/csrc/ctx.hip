@@ -84,7 +84,7 @@ extern "C" int vsl_ctx_destroy(vsl_ctx* ctx) {
   if (ctx->status_word) (void)hipFree(ctx->status_word);
   if (ctx->bcr_jobs) (void)hipFree(ctx->bcr_jobs);
   if (ctx->ba_arena) (void)hipFree(ctx->ba_arena);
-  if (ctx->ba_mail) (void)hipHostFree(ctx->ba_mail);
+  if (ctx->ba_pin) (void)hipHostFree(ctx->ba_pin);
   if (ctx->hpinned) (void)hipHostFree(ctx->hpinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

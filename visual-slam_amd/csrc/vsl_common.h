@@ -62,8 +62,10 @@ struct vsl_ctx {
   size_t ba_arena_cap = 0;
   bool ba_arena_busy = false;
   // pinned, device-mapped mailbox of the fused local-BA iteration (ba_fused.hip): kernels post their scalars there
-  double* ba_mail = nullptr;
-  size_t ba_mail_cap = 0;  // doubles
+  int64_t last_ba_s_elems = 0;  // layout of the reduced camera system of the last general-path solve set up on this context
+  int last_ba_banded = 0, last_ba_bw = 0;
+  void* ba_pin = nullptr;   // [plan of the solve | mailbox]: one copy carries the plan to the device
+  size_t ba_pin_cap = 0;    // bytes
   bool select_attr_set = false;
   bool bow_score_attr_set = false;  // per context, hence per device: hipFuncSetAttribute is a per-device setting
   double* status_word = nullptr;    // 64 device bytes allocated with the context: the flag of status exchanges between ranks (never null in a live context)
