@@ -203,6 +203,63 @@ def ba_traffic(workload, kernels):
         return None, {}, None
 
 
+def global_ba_multi_rank(args, vsl, ctx, synth, vdist, rank, world, backend):
+    """BASELINE configs[4] over `world` ranks: the one place the path has a real exchange step.  Every
+    rank linearises and Schur-reduces its landmark range, ONE packed SUM all-reduce per LM iteration carries the band of
+    the reduced camera system (RCCL over xGMI with backend nccl; gloo through host memory in rehearsals), every rank
+    solves it redundantly.  Replaces the single ceres::Solve of global_bundle_adjustment
+    (include/visnav/loop_closure_utils.h:672-748).  Called by ALL ranks; returns the dict on every rank."""
+    import torch
+    ba_dist = importlib.import_module("visual_slam_amd.ba_dist")
+    ddev = "cuda" if backend == "nccl" else "cpu"
+    dg = synth.ba_problem(5, n_kf=args.gba_kf, n_lms=args.gba_lms, loop_radius=200.0 * args.gba_kf / 500.0, max_range=15.0)
+
+    def mk_g():
+        return vsl.BaArrays.from_dict(dg)
+
+    ba_dist.bundle_adjust_distributed(vsl, ctx, mk_g(), max_iters=1)   # warm-up: allocations, code objects, communicator
+    times = {}
+    own = {}
+    last = None
+    for iters in (3, 12, 3, 12):  # best of two per length (the one-off set-up jitters by a few ms)
+        a = mk_g()
+        vdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sg = ba_dist.bundle_adjust_distributed(vsl, ctx, a, max_iters=iters)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        vdist.barrier()
+        dt = vdist.max_over_ranks(time.perf_counter() - t0, device=ddev)   # MAX over ranks
+        if iters not in times or dt < times[iters][0]:
+            times[iters] = (dt, sg.iterations)
+            own[iters] = mine
+        last = (sg, a)
+    (t3, i3), (t12, i12) = times[3], times[12]
+    per_rank = vdist.gather_over_ranks((own[12] - own[3]) / max(i12 - i3, 1), device=ddev)
+    s_elems, banded, bw = ctx.last_ba_layout()
+    n_red = 6 * int((dg["cam_fixed"] == 0).sum())
+    # the world-1 reference: every rank solves the whole problem alone (no collective) -- same LM trajectory expected
+    a1 = mk_g()
+    s1 = ba_dist.bundle_adjust_distributed(vsl, ctx, a1, max_iters=12, solo=True)
+    sg, a = last
+    return {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d, %s"
+                        % (len(dg["poses"]), int(dg["cam_fixed"].sum()), len(dg["points"]), len(dg["obs_cam"]), n_red, n_red,
+                           ("band form, half bandwidth %d" % bw) if banded else "dense"),
+            "world": world, "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (host memory: a rehearsal, not xGMI)"),
+            "partition": "landmarks in contiguous ranges balanced by observation count, poses replicated; every rank factorises "
+                         "the all-reduced system redundantly",
+            "ms_per_lm_iteration_marginal": round(1e3 * (t12 - t3) / max(i12 - i3, 1), 3),
+            "per_rank_ms_per_iteration": [round(1e3 * t, 3) for t in per_rank],
+            "ms_total_12_iterations_incl_setup": round(1e3 * t12, 1), "iterations": i12,
+            "allreduce_bytes_per_iteration": int(8 * (s_elems + 3 * n_red + 2)),
+            "collectives_per_iteration": "1 SUM of [S band | rhs | diag H | g_c | cost] + 1 SUM of 8 scalars (+ 1 scalar MAX after an accepted step)",
+            "final_cost": sg.final_cost, "final_cost_world1": s1.final_cost,
+            "final_cost_rel_diff_vs_world1": abs(sg.final_cost - s1.final_cost) / s1.final_cost,
+            "iterations_world1": s1.iterations,
+            "max_pose_diff_vs_world1": float(np.abs(a.poses - a1.poses).max())}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -401,6 +458,8 @@ def main():
     ap.add_argument("--no-ba", dest="ba", action="store_false", help="skip the local-BA ms/iter measurement")
     ap.add_argument("--no-gba", dest="gba", action="store_false",
                     help="skip the global-BA ms/iter measurement (BASELINE configs[4] scale, one rank)")
+    ap.add_argument("--gba-kf", type=int, default=500, help="keyframes of the global-BA problem (configs[4]: 500 = 1000 cameras)")
+    ap.add_argument("--gba-lms", type=int, default=100000, help="landmark candidates of the global-BA problem (configs[4]: 100000)")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false",
                     help="skip the single-stream end-to-end run of the headless next_step pipeline")
     ap.add_argument("--e2e-frames", type=int, default=640, help="frames of the rendered lap of the end-to-end legs")
@@ -542,6 +601,11 @@ def main():
     ctx, frames = units[0][1], units[0][2]
     if not (nk.min() > 0 and nm.min() > 0):
         raise SystemExit("benchmark produced empty outputs: keypoints %s matches %s" % (nk.min(), nm.min()))
+
+    # ---- N > 1: the global-BA leg over all ranks (the J^T J all-reduce of BASELINE configs[4]); N = 1 runs it further down
+    gba_multi = None
+    if args.gba and world > 1:
+        gba_multi = global_ba_multi_rank(args, vsl, ctx, synth, vdist, rank, world, backend)
 
     out = None
     if rank == 0:
@@ -765,7 +829,7 @@ def main():
         # through the step-wise session API (the multi-GPU path at world size 1): marginal time per LM iteration
         if args.gba and world == 1:
             ba_dist = importlib.import_module("visual_slam_amd.ba_dist")
-            dg = synth.ba_problem(5, n_kf=500, n_lms=100000, loop_radius=200.0, max_range=15.0)
+            dg = synth.ba_problem(5, n_kf=args.gba_kf, n_lms=args.gba_lms, loop_radius=200.0 * args.gba_kf / 500.0, max_range=15.0)
 
             def mk_g():
                 return vsl.BaArrays.from_dict(dg)
@@ -821,6 +885,9 @@ def main():
                                              "56 B per camera + 128 in; %d doubles of S + rhs + 96 B per landmark out" % s_doubles,
                     "note": "latency- and fp64-compute-bound, not bandwidth-bound: the solve is log2(n / B) dependent levels of "
                             "dense 224-block factorisations (DESIGN 8.4)"}
+
+        if gba_multi is not None:
+            out["global_ba"] = gba_multi
 
         # ---- BoW (K8 / K9) at the reference's vocabulary shape; the vocabulary file also serves the end-to-end legs
         voc_path = None

@@ -209,3 +209,32 @@ def test_global_ba_full_size_properties(vsl, orc, synth):
     assert (s_one.iterations, s_one.termination) == (s_band.iterations, s_band.termination)
     assert s_one.final_cost == pytest.approx(s_band.final_cost, rel=1e-9)
     c.close()
+
+
+def test_bench_gpus_2_runs_the_global_ba_all_reduce_leg():
+    # `python bench.py --gpus N` must carry BASELINE configs[4] THROUGH THE COLLECTIVE at N > 1 -- the
+    # global-BA leg used to be gated to world == 1, so the one exchange step of the path (the J^T J all-reduce) was in no
+    # command the driver runs.  Two ranks (gloo: host-memory all-reduce; RCCL needs one GPU per rank) sharing the one GPU
+    # of the box, a reduced problem (60 keyframes) and a short frame loop: n_gpus 2 AND global_ba.world 2, the final cost
+    # equal to the world-1 solve of the same problem to 1e-9, the same LM trajectory.
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["VSL_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "32",
+                        "--scenes", "8", "--passes", "1", "--cpu-frames", "0", "--stream-seconds", "0", "--no-ba", "--no-e2e",
+                        "--no-bow", "--gen-workers", "2", "--gba-kf", "60", "--gba-lms", "6000", "--profile-steps", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank"]["frames_per_s"]) == 2 and d["value"] > 0
+    g = d["global_ba"]
+    assert g["world"] == 2 and len(g["per_rank_ms_per_iteration"]) == 2
+    assert g["allreduce_bytes_per_iteration"] > 8 * 6 * 118     # at least the right-hand side of the 118 free cameras
+    assert g["iterations"] == g["iterations_world1"]
+    assert g["final_cost_rel_diff_vs_world1"] <= 1e-9
+    assert g["max_pose_diff_vs_world1"] <= 1e-7
+    assert g["ms_per_lm_iteration_marginal"] > 0

@@ -65,7 +65,7 @@ def _make_allreduce(pkg, ctx, group):
 
 
 def bundle_adjust_distributed(pkg, ctx, arr, use_huber=True, huber=1.0, max_iters=20, verbosity=0, group=None,
-                              collectives_at_world_one=False):
+                              collectives_at_world_one=False, solo=False):
     """arr: flattened problem (same object as Context.bundle_adjust takes), identical on every rank.
     Optimises arr.poses / arr.points in place on every rank; returns a summary namespace.
 
@@ -74,7 +74,8 @@ def bundle_adjust_distributed(pkg, ctx, arr, use_huber=True, huber=1.0, max_iter
     import torch
     import torch.distributed as dist
 
-    distributed = dist.is_available() and dist.is_initialized()
+    # solo: this rank solves the whole problem by itself, no collective (the world-1 reference of a multi-rank run)
+    distributed = dist.is_available() and dist.is_initialized() and not solo
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
     handle = ctx.stream()  # None = the device's default (null) stream
