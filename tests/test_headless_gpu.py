@@ -265,3 +265,29 @@ def test_benchmark_lap_with_the_reference_default_branches(benchmark_lap, tmp_pa
     assert open_loop["loops_closed"] == 0 and open_loop["ate_rmse_m"] > 1.0
     assert closed["loops_closed"] >= 1 and closed["global_ba_runs"] >= 1 and closed["stage_ms_total"]["global_ba"] > 0
     assert closed["ate_rmse_m"] < 0.6 * open_loop["ate_rmse_m"], (closed["ate_rmse_m"], open_loop["ate_rmse_m"])
+
+
+def test_a_natural_loop_closes_under_the_reference_defaults(tmp_path_factory, vsl, synth):
+    # a lap with REAL accumulated drift closes its loop with the reference's default-on branches and
+    # nothing else -- no --inject-drift, no --force-loop, no --num-consistency override (src/slam.cpp:244-247, :1219-1258:
+    # detect_loop_closure -> loop_closure -> global BA).  The larger room of bench.py's `end_to_end_natural_loop` leg:
+    # half extents 8 x 3 x 8 m, radius 6 m, 6 cm per frame = a 628-frame lap, 720 frames rendered; the BoW database yields
+    # the candidates, three consecutive consistent detections close the loop, the global BA runs, the trajectory error
+    # stays below the open-loop figure.
+    sq = importlib.import_module("visual_slam_amd.synth_sequence")
+    d = tmp_path_factory.mktemp("natural_lap")
+    sq.render_sequence(str(d), n_frames=720, seed=1, step_m=0.06, radius=6.0, workers=8, look_deg=90.0,
+                       room_half=(8.0, 3.0, 8.0), px_per_m=60.0)
+    voc = tmp_path_factory.mktemp("voc") / "voc_k10_L6.txt"
+    synth.write_vocabulary_text(str(voc), 10, 6, *synth.vocabulary_arrays(7, 10, 6))
+    flags = ["--relocalization", "--loop-closure", "--voc-path", str(voc), "--fused"]
+    out = _run(d, *flags)
+    assert out["frames"] == 720 and out["keyframes"] >= 30
+    assert out["loops_closed"] >= 1 and out["global_ba_runs"] >= 1, out
+    assert out["ate_rmse_m"] < 0.08, out
+    opened = _run(d, "--relocalization", "--voc-path", str(voc), "--fused")     # loop closure off: the drift is there
+    assert opened["loops_closed"] == 0
+    assert out["ate_rmse_m"] < opened["ate_rmse_m"], (out["ate_rmse_m"], opened["ate_rmse_m"])
+    # the run is reproducible (the loop-closing stages included)
+    again = _run(d, *flags)
+    assert (again["loops_closed"], again["keyframes"], again["ate_rmse_m"]) == (out["loops_closed"], out["keyframes"], out["ate_rmse_m"])

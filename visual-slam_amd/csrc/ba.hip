@@ -1896,7 +1896,8 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
   if (rc) return rc;
   if (!opt) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_bundle_adjust: options are null");
   VSL_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->ba_no_fused) {  // local windows: the fused iteration (ba_fused.hip); everything else continues below
+  static const bool env_no_fused = getenv("VSL_BA_NO_FUSED") != nullptr;  // same switch for applications without a diagnostics hook
+  if (!ctx->ba_no_fused && !env_no_fused) {  // local windows: the fused iteration (ba_fused.hip); everything else continues below
     int handled = 0;
     rc = vsl_ba_fused_solve(ctx, prob, opt, summary, &handled);
     if (rc || handled) return rc;
