@@ -1038,7 +1038,10 @@ bool bf_plan(const vsl_ba_problem* p, const BfLayout& y, char* blk, BfPlan& pl) 
   // workgroups: contiguous landmark ranges balanced by observation count, one thread per observation
   unsigned* pres = (unsigned*)(blk + y.lm_pres);
   int* wg_info = (int*)(blk + y.wg_info);
-  int G0 = std::max(1, std::min(256, (O + 319) / 320));
+  // (as many workgroups as compute units as soon as each gets ~100 observations: the per-workgroup cost is the tile
+  // products on the fp64 matrix unit, proportional to its landmarks -- a 25 k-observation window on 78 workgroups
+  // spent 49 us in this kernel, on 256 it is the fixed costs only)
+  int G0 = std::max(1, std::min(256, (O + 95) / 96));
   if ((O + G0 - 1) / G0 > 960) G0 = (O + 959) / 960;
   int l = 0, g = 0;
   int cnt[BF_CAMS + 1];
