@@ -223,6 +223,8 @@ int vsl_ctx_set_tie_eps(vsl_ctx* ctx, double eps);
  *   "ba_no_fused" (0/1)             local windows (<= 21 free cameras) by the operator-by-operator kernels instead of the
  *                                   fused four-launch iteration (ba_fused.hip)
  *   "ba_schur_entries" (0/1)        small-system Schur kernel with single-entry ownership instead of 3 x 3 sub-blocks
+ *   "bow_no_wg_score" (0/1)         L1 scoring of <= 256 candidates by the wave-per-candidate kernel instead of the
+ *                                   workgroup-per-candidate one
  *   "bow_keys64" (0/1)              vocabulary transform with 64-bit (id, feature) sort keys where 32 bits would do
  *   "exact_list_cap" (0..16384)     per-image exact-rounding list entries of the describe kernels; an overflow is
  *                                   detected at the next synchronisation and the range is redone by the f64 kernel

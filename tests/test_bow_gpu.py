@@ -151,6 +151,45 @@ def test_bow_database_scores_equal_the_pairwise_scores(ctx, vsl, orc, synth, orb
     db.close()
 
 
+def test_score_kernel_forms_agree_bit_for_bit(ctx, orc):
+    # round 4: <= 256 candidates of <= 4096 words against a query of <= 4096 words take the workgroup-per-candidate
+    # kernel (one round of searches by 1024 threads, ordered sum by one wavefront); anything else the wave-per-candidate
+    # kernel.  Both against the oracle, bit for bit: candidate lengths around the staging limits (1, 1023, 1024, 1025,
+    # 4096, 4097 -- the last one sends the whole batch to the other kernel), heavy and empty overlaps, the diagnostic switch.
+    rng = np.random.default_rng(14)
+    q_ids = np.sort(rng.choice(10 ** 6, 3000, replace=False)).astype(np.uint32)
+    q_vals = rng.random(3000)
+    q_vals /= q_vals.sum()
+
+    def cand(n, share):
+        ids = rng.choice(10 ** 6, n, replace=False).astype(np.uint32)
+        k = min(int(share * n), len(q_ids))
+        ids[:k] = rng.choice(q_ids, k, replace=False)
+        ids = np.unique(ids)
+        v = rng.random(len(ids))
+        return ids, v / v.sum()
+
+    base = [cand(n, sh) for n, sh in ((1, 1.0), (1023, 0.5), (1024, 0.0), (1025, 0.9), (2500, 0.3), (4000, 0.7))]
+    base.append((np.zeros(0, np.uint32), np.zeros(0)))
+    for extra in ([], [cand(4300, 0.5)]):          # with the long candidate no batch member may use the workgroup form
+        cands = base + extra
+        exp = np.array([orc.bow_score_l1(q_ids, q_vals, c[0], c[1]) for c in cands])
+        got = ctx.bow_score_batch(q_ids, q_vals, cands)
+        assert np.array_equal(_bits(got), _bits(exp))
+        ctx.set_diagnostic("bow_no_wg_score", 1)
+        try:
+            got2 = ctx.bow_score_batch(q_ids, q_vals, cands)
+        finally:
+            ctx.set_diagnostic("bow_no_wg_score", 0)
+        assert np.array_equal(_bits(got2), _bits(exp))
+    # a query beyond the workgroup form's 4096 words
+    q2 = np.sort(rng.choice(10 ** 6, 5000, replace=False)).astype(np.uint32)
+    v2 = rng.random(5000)
+    v2 /= v2.sum()
+    got = ctx.bow_score_batch(q2, v2, base)
+    assert np.array_equal(_bits(got), _bits(np.array([orc.bow_score_l1(q2, v2, c[0], c[1]) for c in base])))
+
+
 def test_score_with_a_query_too_large_for_lds(ctx, orc):
     # > 8192 query words: the global-memory kernel; and exactly at the LDS kernel's limit
     rng = np.random.default_rng(4)

@@ -54,6 +54,7 @@ struct vsl_bowdb {
   int64_t* off = nullptr;      // [cap_vecs + 1]
   int64_t cap_entries = 0, n_entries = 0;
   int cap_vecs = 0, n_vecs = 0;
+  int max_nnz = 0;             // longest stored vector (the workgroup form of the scoring kernel stages a whole candidate)
 };
 
 namespace {
@@ -381,6 +382,81 @@ __global__ __launch_bounds__(256) void bow_score_lds_kernel(const uint32_t* __re
     }
   }
   if (lane == 0) scores[cand] = -score / 2.0;
+}
+
+// K9 for FEW candidates (m <= BOW_WG_MAX_M = 256: loop-closure / relocalisation queries score ~100 keyframes): one WORKGROUP
+// per candidate instead of one wavefront.  The wave-per-candidate kernel above is latency at that size (20 us at M = 100:
+// 25 workgroups on 256 compute units, a lone wave per SIMD walking six rounds of 11 dependent LDS searches); here the 1024
+// threads of a workgroup take one candidate word each, ONE round of searches, the terms go to LDS and a single wavefront
+// adds the matched ones in ascending word order (the reference's order, ScoringObject.cpp:23-68; a query and a
+// candidate share tens to hundreds of words, so the ordered part is short).
+#define BOW_WG_THREADS 1024
+#define BOW_WG_TERMS 4096     // candidate words a workgroup stages
+#define BOW_WG_Q_MAX 4096     // query words (48 KB + 16 KB of search keys)
+#define BOW_WG_MAX_M 256      // one round of workgroups on the chip (measured: M = 100 20 -> 11 us; M = 1000 21 -> 31 us with this form)
+__global__ __launch_bounds__(BOW_WG_THREADS) void bow_score_wg_kernel(const uint32_t* __restrict__ q_ids, const double* __restrict__ q_vals,
+                                                                      int q_nnz, int P, const uint32_t* __restrict__ c_ids,
+                                                                      const double* __restrict__ c_vals, const int64_t* __restrict__ off,
+                                                                      const int32_t* __restrict__ idx, double* __restrict__ scores) {
+  __shared__ double qv[BOW_WG_Q_MAX];
+  __shared__ uint32_t qi[2 * BOW_WG_Q_MAX];  // padded to the power of two P <= 8192 with 0xFFFFFFFF
+  __shared__ double term_s[BOW_WG_TERMS];
+  __shared__ unsigned long long hit_s[BOW_WG_TERMS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vec = idx ? idx[blockIdx.x] : (int)blockIdx.x;
+  const int64_t a = off[vec];
+  const int len = (int)(off[vec + 1] - a);  // <= BOW_WG_TERMS (the host checks)
+  // the candidate's words are requested before the query is staged: one round trip for both
+  uint32_t id[BOW_WG_TERMS / BOW_WG_THREADS];
+  double wv[BOW_WG_TERMS / BOW_WG_THREADS];
+#pragma unroll
+  for (int u = 0; u < BOW_WG_TERMS / BOW_WG_THREADS; u++) {
+    const int i = u * BOW_WG_THREADS + tid;
+    id[u] = i < len ? c_ids[a + i] : 0xFFFFFFFFu;
+    wv[u] = i < len ? c_vals[a + i] : 0.0;
+  }
+  for (int i = tid; i < P; i += BOW_WG_THREADS) qi[i] = i < q_nnz ? q_ids[i] : 0xFFFFFFFFu;
+  for (int i = tid; i < q_nnz; i += BOW_WG_THREADS) qv[i] = q_vals[i];
+  __syncthreads();
+  const int rounds = (len + BOW_WG_THREADS - 1) / BOW_WG_THREADS;
+#pragma unroll
+  for (int u = 0; u < BOW_WG_TERMS / BOW_WG_THREADS; u++) {
+    if (u < rounds) {  // workgroup-uniform
+      int lo = 0;
+      for (int step = P >> 1; step >= 1; step >>= 1)
+        if (qi[lo + step - 1] < id[u]) lo += step;
+      const bool hit = id[u] != 0xFFFFFFFFu && qi[lo] == id[u];
+      double t = 0.0;
+      if (hit) {
+        const double vi = qv[lo], wi = wv[u];
+        t = fabs(vi - wi) - fabs(vi) - fabs(wi);
+      }
+      term_s[u * BOW_WG_THREADS + tid] = t;
+      const unsigned long long mk = __ballot(hit);
+      if (lane == 0) hit_s[u * (BOW_WG_THREADS / 64) + wave] = mk;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  double score = 0.0;
+  const int chunks = (len + 63) / 64;  // <= 64: lane c holds the hit mask of chunk c, chunks without a hit are never visited
+  const unsigned long long my_mask = lane < chunks ? hit_s[lane] : 0ull;
+  unsigned long long live = __ballot(my_mask != 0ull);
+  const int mlo = (int)(uint32_t)my_mask, mhi = (int)(uint32_t)(my_mask >> 32);
+  while (live) {
+    const int c = __builtin_ctzll(live);
+    live &= live - 1;
+    unsigned long long mk = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, c) << 32) | (uint32_t)__builtin_amdgcn_readlane(mlo, c);
+    const double t = term_s[64 * c + lane];
+    const int tlo = __builtin_bit_cast(int2, t).x, thi = __builtin_bit_cast(int2, t).y;
+    while (mk) {
+      const int l = __builtin_ctzll(mk);
+      mk &= mk - 1;
+      const int2 v = make_int2(__builtin_amdgcn_readlane(tlo, l), __builtin_amdgcn_readlane(thi, l));
+      score += __builtin_bit_cast(double, v);
+    }
+  }
+  if (lane == 0) scores[blockIdx.x] = -score / 2.0;
 }
 
 // Queries too large for LDS (> BOW_Q_LDS_MAX words): the query stays in global memory.
@@ -725,7 +801,7 @@ extern "C" int vsl_bow_transform(vsl_ctx* ctx, const vsl_voc* voc, const uint8_t
 // query upload + kernel + score download; the candidates are already on the device
 static int bow_score_launch(vsl_ctx* ctx, const uint32_t* q_ids, const double* q_vals, int q_nnz, const uint32_t* c_ids_dev,
                             const double* c_vals_dev, const int64_t* off_dev, const int32_t* idx_dev, int m, uint8_t* qscratch,
-                            double* scores) {
+                            double* scores, int max_cand_nnz) {
   // qscratch (device): q_vals (8Q) | scores (8M) | q_ids (4Q)
   const size_t Q = (size_t)q_nnz, M = (size_t)m;
   double* dqv = (double*)qscratch;
@@ -744,7 +820,17 @@ static int bow_score_launch(vsl_ctx* ctx, const uint32_t* q_ids, const double* q
   }
   {
     VslStage st(ctx, VSL_STAGE_BOW_SCORE);
-    if (q_nnz <= BOW_Q_LDS_MAX) {
+    bool wg_form = false;
+    if (m <= BOW_WG_MAX_M && q_nnz <= BOW_WG_Q_MAX && !ctx->bow_no_wg_score) {
+      // every candidate must fit a workgroup's staging (the offsets live on the device: the callers pass the bound)
+      wg_form = max_cand_nnz >= 0 && max_cand_nnz <= BOW_WG_TERMS;
+    }
+    if (wg_form) {
+      int P = 1;
+      while (P < q_nnz + 1) P <<= 1;
+      hipLaunchKernelGGL(bow_score_wg_kernel, dim3(m), dim3(BOW_WG_THREADS), 0, ctx->stream, dqi, dqv, q_nnz, P, c_ids_dev, c_vals_dev,
+                         off_dev, idx_dev, dsc);
+    } else if (q_nnz <= BOW_Q_LDS_MAX) {
       int P = 1;
       while (P < q_nnz + 1) P <<= 1;  // at least one 0xFFFFFFFF sentinel behind the query
       const size_t lds = 8 * (size_t)((q_nnz + 1) & ~1) + 4 * (size_t)P;
@@ -798,7 +884,9 @@ extern "C" int vsl_bow_score_batch(vsl_ctx* ctx, const uint32_t* q_ids, const do
     VSL_HIP(ctx, hipMemcpyAsync(dci, c_ids, 4 * T, hipMemcpyHostToDevice, ctx->stream));
   }
   VSL_HIP(ctx, hipMemcpyAsync(dof, off64.data(), 8 * (M + 1), hipMemcpyHostToDevice, ctx->stream));
-  return bow_score_launch(ctx, q_ids, q_vals, q_nnz, dci, dcv, dof, nullptr, m, qs, scores);
+  int max_nnz = 0;
+  for (int i = 0; i < m; i++) max_nnz = std::max(max_nnz, c_offsets[i + 1] - c_offsets[i]);
+  return bow_score_launch(ctx, q_ids, q_vals, q_nnz, dci, dcv, dof, nullptr, m, qs, scores, max_nnz);
 }
 
 // ------------------------------------------------------------------------------------------------ vsl_bowdb
@@ -871,6 +959,7 @@ extern "C" int vsl_bowdb_append(vsl_ctx* ctx, vsl_bowdb* db, const uint32_t* ids
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sources are the caller's (pageable) arrays
   if (index_out) *index_out = db->n_vecs;
   db->n_vecs++;
+  db->max_nnz = std::max(db->max_nnz, nnz);
   return VSL_OK;
 }
 
@@ -902,5 +991,5 @@ extern "C" int vsl_bowdb_score(vsl_ctx* ctx, const vsl_bowdb* db, const uint32_t
     didx = (int32_t*)(qs + 8 * (Q + M) + 4 * Q + ((4 - ((8 * (Q + M) + 4 * Q) & 3)) & 3));
     VSL_HIP(ctx, hipMemcpyAsync(didx, cand_index, 4 * M, hipMemcpyHostToDevice, ctx->stream));
   }
-  return bow_score_launch(ctx, q_ids, q_vals, q_nnz, db->ids, db->vals, db->off, didx, m, qs, scores);
+  return bow_score_launch(ctx, q_ids, q_vals, q_nnz, db->ids, db->vals, db->off, didx, m, qs, scores, db->max_nnz);
 }
