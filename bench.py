@@ -458,6 +458,7 @@ def main():
     ap.add_argument("--no-ba", dest="ba", action="store_false", help="skip the local-BA ms/iter measurement")
     ap.add_argument("--no-gba", dest="gba", action="store_false",
                     help="skip the global-BA ms/iter measurement (BASELINE configs[4] scale, one rank)")
+    ap.add_argument("--gba-timeout", type=float, default=600.0, help="watchdog of the multi-rank global-BA leg, seconds")
     ap.add_argument("--gba-kf", type=int, default=500, help="keyframes of the global-BA problem (configs[4]: 500 = 1000 cameras)")
     ap.add_argument("--gba-lms", type=int, default=100000, help="landmark candidates of the global-BA problem (configs[4]: 100000)")
     ap.add_argument("--no-e2e", dest="e2e", action="store_false",
@@ -603,11 +604,6 @@ def main():
     ctx, frames = units[0][1], units[0][2]
     if not (nk.min() > 0 and nm.min() > 0):
         raise SystemExit("benchmark produced empty outputs: keypoints %s matches %s" % (nk.min(), nm.min()))
-
-    # ---- N > 1: the global-BA leg over all ranks (the J^T J all-reduce of BASELINE configs[4]); N = 1 runs it further down
-    gba_multi = None
-    if args.gba and world > 1:
-        gba_multi = global_ba_multi_rank(args, vsl, ctx, synth, vdist, rank, world, backend)
 
     out = None
     if rank == 0:
@@ -888,9 +884,6 @@ def main():
                     "note": "latency- and fp64-compute-bound, not bandwidth-bound: the solve is log2(n / B) dependent levels of "
                             "dense 224-block factorisations (DESIGN 8.4)"}
 
-        if gba_multi is not None:
-            out["global_ba"] = gba_multi
-
         # ---- BoW (K8 / K9) at the reference's vocabulary shape; the vocabulary file also serves the end-to-end legs
         voc_path = None
         if (args.bow or args.e2e) and world == 1:
@@ -1088,6 +1081,31 @@ def main():
                     "frames": v["frames"], "keyframes": v["keyframes"], "frames_per_s": v["frames_per_s"], "best_of_runs": 3,
                     "ms_per_frame": v["ms_per_frame"], "ate_rmse_m": v["ate_rmse_m"], "stage_ms_total": v["stage_ms_total"],
                     "cpu_oracle_frames_per_s": vc.get("frames_per_s"), "cpu_oracle_ate_rmse_m": vc.get("ate_rmse_m")}
+    # ---- N > 1: the global-BA leg over ALL ranks (the J^T J all-reduce of BASELINE configs[4]; N = 1 ran it above).  It
+    # is the last thing before the line is printed, under a watchdog: if a collective does not come back (a rank lost, a
+    # communicator that never forms) rank 0 still prints the frame-pipeline line -- with the failure named -- and every
+    # rank leaves.
+    if args.gba and world > 1:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["global_ba"] = {"error": "the multi-rank global-BA leg did not finish within %d s; the line carries the "
+                                             "replicated frame pipeline only" % args.gba_timeout, "world": world}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.gba_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            gba_multi = global_ba_multi_rank(args, vsl, ctx, synth, vdist, rank, world, backend)
+        except Exception as e:  # a rank-local failure: say so in the line, do not lose the frame-pipeline figure
+            gba_multi = {"error": "%s: %s" % (type(e).__name__, e), "world": world}
+        dog.cancel()
+        if rank == 0:
+            out["global_ba"] = gba_multi
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     for _, c, f in units:

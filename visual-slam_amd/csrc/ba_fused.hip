@@ -409,6 +409,7 @@ __global__ __launch_bounds__(BF_THREADS) void baf_schur_kernel(BfArgs a, double 
         }
       }
     }
+    BF_STAMP(7)
     if (is_free && my_ch == c) {
       const double* Pi = pib_s + 12 * o.lml;
       const int base = 3 * my_li * NPs + 6 * o.fc;
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(BF_THREADS) void baf_schur_kernel(BfArgs a, double 
         }
       }
     }
+    BF_STAMP(3)
     if (tid >= l_a && tid < l_a + lc) {  // the landmark's own thread: row n of Yd = -P^-1 b
 #pragma unroll
       for (int y = 0; y < 3; y++) Yd[(3 * (tid - l_a) + y) * NPs + n] = pib_s[12 * tid + 9 + y];
@@ -466,8 +468,8 @@ __global__ __launch_bounds__(BF_THREADS) void baf_schur_kernel(BfArgs a, double 
   BF_STAMP(6)
 #ifdef BF_TIMING
   if (tid == 0 && (bid == 0 || bid == 100))
-    printf("schur wg %d (lms %d obs %d chunks %d) ticks: load %lld eval+stage %lld landmarks %lld camera blocks %lld operand writes %lld mfma %lld epilogue %lld\n",
-           bid, n_lm, n_obs, n_ch, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
+    printf("schur wg %d (lms %d obs %d chunks %d) ticks: load %lld eval+stage %lld landmarks %lld camera blocks+W/Y %lld zero fill %lld barrier after operands %lld mfma %lld epilogue %lld\n",
+           bid, n_lm, n_obs, n_ch, tp[0], tp[1], tp[2], tp[3], tp[7], tp[4], tp[5], tp[6]);
 #endif
 }
 
