@@ -194,7 +194,7 @@ def ba_traffic(workload, kernels):
         per = {}
         for k, v in w["kernels"].items():
             base = k.split("<")[0]
-            if base in kernels:
+            if base in kernels and "<true" not in k:   # (<true, .> is the once-per-solve scaling pass of the Schur kernel)
                 per[base] = per.get(base, 0) + v["bytes_per_dispatch"]
         src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same problem, committed with the "
                "tree -- NOT collected in this run" % newest.name)

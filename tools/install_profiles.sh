@@ -3,7 +3,7 @@
 #   bash tools/install_profiles.sh r03
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/refresh
 cp $O/bench_line.json profiles/${R}_bench_line.json
 cp $(ls $O/kt1/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_1stream.csv
@@ -15,6 +15,7 @@ cp $O/${R}_e2e_kernel_stats.json $O/${R}_e2e_kernel_stats.csv profiles/
 cp $O/${R}_stages_e2e_kernel_stats.json profiles/${R}_e2e_loop_closing_stages_kernel_stats.json
 cp $O/${R}_stages_e2e_kernel_stats.csv profiles/${R}_e2e_loop_closing_stages_kernel_stats.csv
 python tools/pmc_summary.py $O profiles/${R}_pmc_traffic.json 512
+[ -f $O/${R}_ba_pmc_traffic.json ] && cp $O/${R}_ba_pmc_traffic.json profiles/${R}_ba_pmc_traffic.json
 python tools/sq_summary.py $O profiles/${R}_matcher_sq_counters.json
 python tools/frame_sq_summary.py $O profiles/${R}_frame_sq_counters.json
 python - $R <<'PY'

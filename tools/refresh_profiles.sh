@@ -7,7 +7,7 @@
 # roofline.traffic of the SAME build.
 set -e
 R=$PWD
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 O=$R/gpurun_out/refresh
 rm -rf $O && mkdir -p $O  # (clear the LOCAL gpurun_out/refresh too before a new run: gpurun merges, it does not delete)
 cd /tmp && export TMPDIR=/tmp
@@ -43,4 +43,6 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 # bundle adjustment: kernel durations of the local window and of the 1000-camera map
 echo ba; rocprofv3 --kernel-trace --stats --output-format csv -d $O/lba -- python3 $R/tools/local_ba_probe.py 7 > $O/lba.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gba -- python3 $R/tools/global_ba_bench.py --iters 8 --single-call > $O/gba.log 2>&1
+# bundle adjustment: HBM traffic of the fused local iteration and of the large-system kernels (separate --pmc passes)
+echo ba_pmc; (cd $R && bash tools/ba_pmc.sh $ROUND > $O/ba_pmc.log 2>&1; cp gpurun_out/${ROUND}_ba_pmc_traffic.json $O/ 2>/dev/null)
 echo refresh done
