@@ -42,6 +42,7 @@
 #include <cmath>
 
 #include "ba_device.h"
+#include "dpp_chol.h"
 #include "vsl_common.h"
 
 namespace {
@@ -632,62 +633,6 @@ __global__ __launch_bounds__(256) void baf_init_finish_kernel(int n, int nfree, 
 // flag = 0 if a pivot is not positive / finite.
 #define CS_LD 129   // row stride (doubles): one matrix row per lane is conflict-free (2 dwords per lane and bank)
 #define CS_ROWS 129 // 128 matrix rows + the right-hand-side row
-
-template <int J>
-__device__ __forceinline__ double cs_bcast(double v) {  // lane J of every 16-lane row -> all lanes of the row
-  double r;
-  // (two wait states between a VALU write and a DPP read of the same register: the compiler does not see into the asm)
-  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
-  return r;
-}
-template <int K, bool NOP>
-__device__ __forceinline__ void cs_fmac_bcast(double& acc, double bsrc, double own) {  // acc -= bsrc[lane K of the row] * own
-  if (NOP)
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
-  else
-    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
-}
-
-template <int J>
-struct CsCol {  // pivot step J of a panel: d = the diagonal block's row of this lane, p = its panel row
-  static __device__ __forceinline__ void run(double (&d)[16], double (&p)[16], double* inv_out, bool& good) {
-    const double dj = cs_bcast<J>(d[J]);
-    if (!(dj > 0.0) || !isfinite(dj)) good = false;
-    // 1 / sqrt by the hardware estimate and two Newton steps (an IEEE sqrt + divide is ~200 dependent instructions)
-    double iv = __builtin_amdgcn_rsq(dj);
-    iv = iv * (1.5 - 0.5 * dj * iv * iv);
-    iv = iv * (1.5 - 0.5 * dj * iv * iv);
-    if (inv_out) inv_out[J] = iv;  // (lane J of wavefront 0 only: the pointer is null elsewhere)
-    const double lj = d[J] * iv;  // lane J: sqrt(pivot); lanes below: l(i, J)
-    const double pj = p[J] * iv;
-    d[J] = lj;
-    p[J] = pj;
-    upd<J + 1>(d, p, lj, pj);
-    CsCol<J + 1>::run(d, p, inv_out, good);
-  }
-  template <int K>
-  static __device__ __forceinline__ void upd(double (&d)[16], double (&p)[16], double lj, double pj) {
-    if constexpr (K < 16) {
-      cs_fmac_bcast<K, K == J + 1>(d[K], lj, lj);  // d(i, K) -= l(K, J) l(i, J)
-      cs_fmac_bcast<K, false>(p[K], lj, pj);       // p(r, K) -= l(K, J) l(r, J)
-      upd<K + 1>(d, p, lj, pj);
-    }
-  }
-};
-template <>
-struct CsCol<16> {
-  static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double*, bool&) {}
-};
-
-template <int J>
-struct CsBack {  // step J (descending) of the transposed 16 x 16 solve: c[k] = l(k, lane) of the diagonal block
-  static __device__ __forceinline__ void run(double& tp, double& x, const double (&c)[16], double ivl, int dr) {
-    const double xj = tp * ivl;          // meaningful in lane J
-    if (dr == J) x = xj;
-    cs_fmac_bcast<J, true>(tp, xj, c[J]);  // t(lane) -= x_J l(J, lane)  (lanes >= J: c[J] = 0 or already solved)
-    if constexpr (J > 0) CsBack<J - 1>::run(tp, x, c, ivl, dr);
-  }
-};
 
 __global__ __launch_bounds__(BF_THREADS) void baf_chol_kernel(int n, const double* __restrict__ S,
                                                               const double* __restrict__ rhs, double* __restrict__ dc,

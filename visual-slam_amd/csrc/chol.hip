@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "vsl_common.h"
+#include "dpp_chol.h"
 
 #define CH_NB 32
 
@@ -872,6 +873,66 @@ __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, 
 // steps (the band kernel on such a block spent 88k of its 389k cycles staging panels and 102k in the window update's
 // load -> MFMA -> store chain); global traffic is one read of the block and one write of its factor.
 // y = L^-1 (b - pending updates) rides along as the window's last row; L (lower), 1 / pivots and y go to global memory.
+// The 32-column panel of bcr_chol_registers factored with the DPP scheme of dpp_chol.h (round 4) instead of
+// cbf_panel_factor's four 8-column sub-steps (factor8 by one wavefront with v_readlane broadcasts + a row solve through
+// LDS per sub-step): two 16-column halves, each ONE pass in which every wavefront that has panel rows factors the
+// diagonal block in its DPP rows and solves its rows beside it, and between them the rank-16 update of columns 16..31 as
+// 16 x 16 tiles on the matrix unit.  Same contract as cbf_panel_factor: W holds the panel of L and the solved right-hand
+// side row, sh.dinv_s the reciprocal pivots, sh.fail_s is set on a bad pivot, ends with a workgroup barrier.
+template <int NTHR>
+__device__ __forceinline__ void bcr_panel_factor_dpp(double (*W)[CH_NB + 1], int rows, CbfShared& sh) {
+  static_assert(CH_NB == 32, "two 16-column halves");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l16 = lane & 15;
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    const int c0 = 16 * half, r0 = c0 + 16, nrow = rows - r0;  // panel rows below the diagonal block, the right-hand side included
+    if (wave * 64 < nrow) {  // wave-uniform
+      const int prow = r0 + wave * 64 + lane;
+      const bool valid = prow < rows;
+      double d[16], p[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        d[k] = W[c0 + l16][c0 + k];
+        p[k] = valid ? W[prow][c0 + k] : 0.0;
+      }
+      bool good = true;
+      CsCol<0>::run(d, p, (wave == 0 && lane == 0) ? sh.dinv_s + c0 : (double*)nullptr, good);
+      if (wave == 0 && lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) W[c0 + lane][c0 + k] = k <= lane ? d[k] : 0.0;
+      }
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) W[prow][c0 + k] = p[k];
+      }
+      if (!good && lane == 0) sh.fail_s = 1;
+    }
+    __syncthreads();
+    if (half == 0) {
+      // columns 16..31 of the rows from 16 on lose their products with the first sixteen columns
+      const int nt = (rows - 16 + 15) >> 4;
+      for (int t = wave; t < nt; t += NTHR / 64) {
+        const int R0 = 16 + 16 * t;
+        const int ra = min(R0 + l16, rows - 1), rb = 16 + l16;
+        v4d_t acc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = W[min(R0 + kq + 4 * q, rows - 1)][16 + l16];
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-W[ra][4 * m + kq], W[rb][4 * m + kq], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int r = R0 + kq + 4 * q;
+          if (r < rows) W[r][16 + l16] = acc[q];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+#ifndef BCR_DPP_PANEL
+#define BCR_DPP_PANEL 1  // 0: the round-2 panel factorisation (four 8-column sub-steps), kept for A/B builds
+#endif
 #define BCR_REG_THREADS 512  // 8 wavefronts = 2 per SIMD: 256 VGPRs each, room for the tiles beside the panel factorisation
 template <int SLOTS>  // tiles per wavefront: 14 for B <= 224 (105 tiles), 17 for B <= 256 (136 tiles)
 __device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ Dg, const double* __restrict__ bg, const double* __restrict__ pend0,
@@ -917,7 +978,10 @@ __device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ D
     }
     if (tid < CH_NB) W[rows - 1][tid] = bvec[k + tid];
     __syncthreads();
-    cbf_panel_factor<BCR_REG_THREADS>(W, rows, sh);
+    if (BCR_DPP_PANEL)
+      bcr_panel_factor_dpp<BCR_REG_THREADS>(W, rows, sh);
+    else
+      cbf_panel_factor<BCR_REG_THREADS>(W, rows, sh);
     if (sh.fail_s) return false;  // workgroup-uniform (cbf_panel_factor ends with a barrier)
     // the factored panel, y and the reciprocal pivots to global memory; right-hand side of the rows below
     for (int idx = tid; idx < (CH_NB + m) * CH_NB; idx += BCR_REG_THREADS) {
