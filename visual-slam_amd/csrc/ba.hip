@@ -32,6 +32,7 @@
 
 #include "vsl_common.h"
 #include "ba_device.h"
+#include "ba_large.h"
 
 namespace {
 
@@ -1263,6 +1264,10 @@ struct BaState {
   // large systems, gather form of the Schur complement (ba_schur_gather_kernel): per-block pair lists, built on the
   // first use for the landmark range they cover, and the per-observation W / Y blocks of the current linearisation
   DevBuf pair_cnt, pair_start, pairs, Wg, Yg, cam_pos;
+  // recompute form of a session's iteration (ba_large.h): landmark runs of the workgroups, their partial sums
+  DevBuf wg_lm, lpart;
+  int n_wg = 0;
+  bool large_fused = false;
   int n_slots = 0, hbp1 = 0;
   size_t n_pairs_cap = 0;
   int pair_l0 = -1, pair_lc = -1;
@@ -1546,6 +1551,23 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   });
   tr.lap("sort + CSRs");
   st.small = D.n <= 128 && D.nfree <= SCH_CMAX && kmax_free <= SCH_KMAX;
+  // landmark runs of the recompute-form kernels: <= BL_THREADS observations and <= BL_LMW landmarks per workgroup
+  std::vector<int> wg_lm;
+  if (!st.small) {
+    wg_lm.push_back(0);
+    for (int l = 0, a = 0; l < D.L; l++) {
+      if (lm_start[l + 1] - lm_start[l] > BL_THREADS) {  // a landmark seen by more cameras than a workgroup has threads
+        wg_lm.clear();
+        break;
+      }
+      if (lm_start[l + 1] - lm_start[a] > BL_THREADS || l - a == BL_LMW) {
+        wg_lm.push_back(l);
+        a = l;
+      }
+      if (l == D.L - 1) wg_lm.push_back(D.L);
+    }
+  }
+  st.n_wg = wg_lm.empty() ? 0 : (int)wg_lm.size() - 1;
   st.nb_obs = (D.O + 255) / 256;
   st.nb_upd = (std::max(D.C, D.L) + 255) / 256;
   st.G = std::min(SCH_GMAX, (D.L + SCH_LB - 1) / SCH_LB);
@@ -1562,7 +1584,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       {&st.lm_start, 4 * (L + 1)}, {&st.cam_start, 4 * (C + 1)}, {&st.cam_obs, 4 * O},
       {&st.cand_poses, 8 * 7 * C}, {&st.cand_points, 8 * 3 * L}, {&st.r, 16 * O}, {&st.F, 96 * O}, {&st.E, 48 * O},
       {&st.scale_c, 8 * n}, {&st.scale_l, 24 * L}, {&st.n2l, 24 * L}, {&st.grad_l, 24 * L},
-      {&st.cam_part, 8 * 27 * (size_t)std::max(1, D.nfree) * st.cb_seg}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
+      {&st.cam_part, 8 * 33 * (size_t)std::max(1, D.nfree) * st.cb_seg}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
       {&st.diag_c, 8 * n}, {&st.diag_l, 24 * L}, {&st.gabs, 8 * (n + 3 * L)}, {&st.S, 8 * st.s_elems}, {&st.rhs, 8 * n},
       {&st.Pinv, 72 * L}, {&st.bl, 24 * L}, {&st.dc, 8 * n}, {&st.dl, 24 * L},
       {&st.partials, 8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)}, {&st.scalars, 8 * 16 + sizeof(int) * 4}};
@@ -1580,6 +1602,8 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     want.push_back({&st.cam_pos, 4 * O});
     want.push_back({&st.Wg, 8 * 18 * O});
     want.push_back({&st.Yg, 8 * 18 * O});
+    want.push_back({&st.wg_lm, 4 * ((size_t)st.n_wg + 1)});
+    want.push_back({&st.lpart, 8 * 4 * (size_t)std::max(1, st.n_wg)});
   }
   if (st.want_alt_set) {
     const Want alt[] = {{&st.r2, 16 * O}, {&st.F2, 96 * O}, {&st.E2, 48 * O}, {&st.n2l2, 24 * L}, {&st.grad_l2, 24 * L},
@@ -1632,6 +1656,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   BA_HIP(up(st.cam_start, cam_start.data(), 4 * (C + 1)));
   BA_HIP(up(st.cam_obs, cam_obs.data(), 4 * O));
   if (!st.small) BA_HIP(up(st.cam_pos, cam_pos.data(), 4 * O));
+  if (!st.small && st.n_wg > 0) BA_HIP(up(st.wg_lm, wg_lm.data(), 4 * wg_lm.size()));
   BA_HIP(hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors that die here
   tr.lap("uploads");
   return VSL_OK;
@@ -1668,6 +1693,27 @@ int ba_columns(vsl_ctx* ctx, BaState& st) {
                        st.cb_seg, st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>());
   }
   VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// block pair lists of the gather-form Schur complement for landmarks [l0, l0 + lc): built once per solve / session
+int ba_pair_lists(vsl_ctx* ctx, BaState& st, int l0, int lc) {
+  if (st.pair_l0 == l0 && st.pair_lc == lc) return VSL_OK;
+  VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
+  hipLaunchKernelGGL(ba_pair_list_kernel<false>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
+                     st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
+                     st.pair_cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(ba_pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, st.n_slots, st.pair_cnt.as<int>(),
+                     st.pair_start.as<int>());
+  VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
+  hipLaunchKernelGGL(ba_pair_list_kernel<true>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
+                     st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
+                     st.pair_cnt.as<int>(), st.pair_start.as<int>(), st.pairs.as<int>());
+  hipLaunchKernelGGL(ba_pair_sort_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.pair_start.as<int>(),
+                     st.pairs.as<int>());
+  VSL_CHECK_LAUNCH(ctx);
+  st.pair_l0 = l0;
+  st.pair_lc = lc;
   return VSL_OK;
 }
 
@@ -1712,22 +1758,8 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
                          st.E.as<double>(), dgl, inv_radius, l0, lc, st.S_eff(), st.rhs.as<double>(), Pinv, bl, lower_mode,
                          st.ldS);
     else if (lc > 0) {
-      if (st.pair_l0 != l0 || st.pair_lc != lc) {  // block pair lists of this landmark range: once per solve / session
-        VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
-        hipLaunchKernelGGL(ba_pair_list_kernel<false>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
-                           st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
-                           st.pair_cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
-        hipLaunchKernelGGL(ba_pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, st.n_slots, st.pair_cnt.as<int>(),
-                           st.pair_start.as<int>());
-        VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
-        hipLaunchKernelGGL(ba_pair_list_kernel<true>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
-                           st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
-                           st.pair_cnt.as<int>(), st.pair_start.as<int>(), st.pairs.as<int>());
-        hipLaunchKernelGGL(ba_pair_sort_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.pair_start.as<int>(),
-                           st.pairs.as<int>());
-        st.pair_l0 = l0;
-        st.pair_lc = lc;
-      }
+      int rc = ba_pair_lists(ctx, st, l0, lc);
+      if (rc) return rc;
       hipLaunchKernelGGL(ba_schur_prep_kernel, dim3((lc + 3) / 4), dim3(256), 0, ctx->stream, D, st.lm_start.as<int>(),
                          st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.r.as<double>(), st.F.as<double>(),
                          st.E.as<double>(), dgl, inv_radius, l0, lc, st.Wg.as<double>(), st.Yg.as<double>(), st.rhs.as<double>(),
@@ -1795,6 +1827,89 @@ int ba_solve(vsl_ctx* ctx, BaState& st, bool& ok) {
 int read_scalars(vsl_ctx* ctx, BaState& st, double* out, int n) {
   VSL_HIP(ctx, hipMemcpyAsync(out, st.scalars.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VSL_OK;
+}
+
+BlArgs bal_args(BaState& st) {
+  BlArgs a;
+  a.D = st.D;
+  a.poses = st.poses.as<double>();
+  a.points = st.points.as<double>();
+  a.intr = st.intr.as<double>();
+  a.cam_intr = st.cam_intr.as<int>();
+  a.cam_free = st.cam_free.as<int>();
+  a.obs_cam = st.obs_cam.as<int>();
+  a.obs_lm = st.obs_lm.as<int>();
+  a.obs_uv = st.obs_uv.as<double>();
+  a.lm_start = st.lm_start.as<int>();
+  a.wg_lm = st.wg_lm.as<int>();
+  a.scale_c = st.scale_c.as<double>();
+  a.scale_l = st.scale_l.as<double>();
+  return a;
+}
+
+// recompute form (ba_large.h), the Jacobi-scaling pass: unscaled column norms (st.n2l, diag of st.H) and the cost
+int bal_init_pass(vsl_ctx* ctx, BaState& st) {
+  const BaDims& D = st.D;
+  VslStage s(ctx, VSL_STAGE_BA_LIN);
+  const BlArgs a = bal_args(st);
+  hipLaunchKernelGGL(bal_prep_kernel<true>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, (const int*)nullptr, 0.0,
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, st.n2l.as<double>(),
+                     st.lpart.as<double>());
+  hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
+                     st.scalars.as<double>(), (double*)nullptr);
+  hipLaunchKernelGGL(bal_cam_kernel<true>, dim3(D.nfree, st.cb_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
+                     st.cam_start.as<int>(), st.cam_obs.as<int>(), (const double*)nullptr, (const double*)nullptr,
+                     st.cam_part.as<double>());
+  hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.cb_seg, 0,
+                     st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// recompute form: S (landmark damping only, no camera damping), rhs, H, g_c, P^-1, b at the current point;
+// scalars[0] = cost, gl_out[0] = max |gradient| over the landmark columns (unscaled problem).
+int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
+  const BaDims& D = st.D;
+  VslStage s(ctx, VSL_STAGE_BA_SCHUR);
+  const BlArgs a = bal_args(st);
+  VSL_HIP(ctx, hipMemsetAsync(st.S.p, 0, sizeof(double) * st.s_elems, ctx->stream));
+  int rc = ba_pair_lists(ctx, st, 0, D.L);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bal_prep_kernel<false>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, st.cam_pos.as<int>(),
+                     1.0 / radius, st.Wg.as<double>(), st.Yg.as<double>(), st.Pinv.as<double>(), st.bl.as<double>(),
+                     (double*)nullptr, st.lpart.as<double>());
+  hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
+                     st.scalars.as<double>(), gl_out);
+  hipLaunchKernelGGL(bal_cam_kernel<false>, dim3(D.nfree, st.cb_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
+                     st.cam_start.as<int>(), st.cam_obs.as<int>(), st.Yg.as<double>(), st.bl.as<double>(),
+                     st.cam_part.as<double>());
+  hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.cb_seg, 1,
+                     st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
+  hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
+                     st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(), st.ldS,
+                     st.banded ? 2 : (D.n > 128 ? 1 : 0));  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
+  hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
+                     st.H.as<double>(), st.g_c.as<double>(), (const double*)nullptr, 0.0, st.S_eff(), st.rhs.as<double>(),
+                     st.ldS, st.banded ? 1 : 0);
+  VSL_CHECK_LAUNCH(ctx);
+  return VSL_OK;
+}
+
+// recompute form: candidate (cand_poses, cand_points) from dc, scalars[2..7] as the operator-by-operator chain leaves them
+int bal_step(vsl_ctx* ctx, BaState& st) {
+  const BaDims& D = st.D;
+  VslStage s(ctx, VSL_STAGE_BA_STEP);
+  const BlArgs a = bal_args(st);
+  hipLaunchKernelGGL(bal_pose_kernel, dim3(1), dim3(256), 0, ctx->stream, D, st.cam_free.as<int>(), st.poses.as<double>(),
+                     st.dc.as<double>(), st.scale_c.as<double>(), st.cand_poses.as<double>(), st.scalars.as<double>(),
+                     st.flag.as<int>());
+  hipLaunchKernelGGL(bal_step_kernel, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, st.Pinv.as<double>(),
+                     st.bl.as<double>(), st.dc.as<double>(), st.cand_poses.as<double>(), st.cand_points.as<double>(),
+                     st.lpart.as<double>(), st.flag.as<int>());
+  hipLaunchKernelGGL(bal_step_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
+                     st.scalars.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
 
@@ -2063,6 +2178,7 @@ struct vsl_ba_session {
   vsl_ba_options opt;
   int lm_first = 0, lm_count = 0, n_lms_total = 0;
   DevBuf diagc_keep;  // clamp(diag H_full): reused across rejected steps
+  bool solo = false;  // vsl_ba_session_solve without a collective: S stays where it is (no copy into packB and back)
 };
 
 namespace {
@@ -2125,9 +2241,11 @@ __global__ void sess_damp_kernel(int n, size_t elems, const double* __restrict__
   }
 }
 
-__global__ void sess_pack_c_kernel(const double* __restrict__ scalars, const int* __restrict__ flag, double* __restrict__ out) {
+__global__ void sess_pack_c_kernel(const double* __restrict__ scalars, const int* __restrict__ flag, int both,
+                                   double* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    out[0] = flag[0] ? 0.0 : 1.0;  // number of ranks whose step is unusable
+    // number of ranks whose step is unusable (both: flag[0] = step finite, flag[1] = factorisation succeeded)
+    out[0] = (flag[0] && (!both || flag[1])) ? 0.0 : 1.0;
     out[1] = scalars[2];           // model cost change, own observations
     out[2] = scalars[3];           // squared step norm (own landmarks + cameras, see ba_dist.py)
     out[3] = scalars[4];           // squared x norm   (own landmarks + cameras)
@@ -2210,6 +2328,14 @@ extern "C" int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, c
     delete s;
     return rc;
   }
+  {
+    // the recompute-form iteration (ba_large.h) for large systems in gather form; "ba_no_fused" / VSL_BA_NO_FUSED keep
+    // the operator-by-operator chain over stored r / F / E blocks (A/B runs, tests)
+    static const bool env_no_fused = getenv("VSL_BA_NO_FUSED") != nullptr;
+    BaState& st = s->st;
+    st.large_fused = !st.small && st.n_wg > 0 && st.D.nfree > 0 && !ctx->ba_no_fused && !env_no_fused &&
+                     !ctx->ba_schur_atomics && st.n_pairs_cap < ((size_t)1 << 31);
+  }
   if (s->diagc_keep.alloc(8 * (size_t)(s->st.D.n > 0 ? s->st.D.n : 1)) != hipSuccess) {
     delete s;
     return vsl_fail(ctx, VSL_ERR_NOMEM, "device allocation failed");
@@ -2251,6 +2377,8 @@ extern "C" int vsl_ba_session_linearize(vsl_ba_session* s, int use_scale) {
   if (!s) return VSL_ERR_INVALID;
   vsl_ctx* ctx = s->ctx;
   VSL_HIP(ctx, hipSetDevice(ctx->device));
+  if (s->st.large_fused)  // nothing is stored per observation: vsl_ba_session_reduce_dev evaluates at the current point
+    return use_scale ? VSL_OK : bal_init_pass(ctx, s->st);
   int rc = ba_linearize(ctx, s->st, use_scale != 0);
   if (rc) return rc;
   return ba_columns(ctx, s->st);
@@ -2277,6 +2405,8 @@ extern "C" int vsl_ba_session_set_scale_dev(vsl_ba_session* s, const double* hdi
   const int nmax = std::max(D.n, 3 * D.L);
   hipLaunchKernelGGL(sess_scale_kernel, dim3((nmax + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, D.L, hdiag_full_dev,
                      st.n2l.as<double>(), st.scale_c.as<double>(), st.scale_l.as<double>());
+  VSL_CHECK_LAUNCH(ctx);
+  if (st.large_fused) return VSL_OK;
   hipLaunchKernelGGL(ba_apply_scale_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, D.O, st.cam_free.as<int>(),
                      st.obs_cam.as<int>(), st.obs_lm.as<int>(), st.scale_c.as<double>(), st.scale_l.as<double>(),
                      st.F.as<double>(), st.E.as<double>());
@@ -2293,18 +2423,22 @@ extern "C" int vsl_ba_session_reduce_dev(vsl_ba_session* s, double radius, doubl
   BaState& st = s->st;
   const BaDims& D = st.D;
   const int n = D.n;
-  hipLaunchKernelGGL(sess_diag_l_kernel, dim3((3 * D.L + 255) / 256), dim3(256), 0, ctx->stream, D.L, st.n2l.as<double>(),
-                     st.grad_l.as<double>(), st.scale_l.as<double>(), st.diag_l.as<double>(), st.gabs.as<double>());
-  if (gmax_l_dev) {
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), 3 * D.L, gmax_l_dev, 0, 1);
+  int rc;
+  if (st.large_fused) {
+    if ((rc = bal_reduce(ctx, st, radius, gmax_l_dev))) return rc;
+  } else {
+    hipLaunchKernelGGL(sess_diag_l_kernel, dim3((3 * D.L + 255) / 256), dim3(256), 0, ctx->stream, D.L, st.n2l.as<double>(),
+                       st.grad_l.as<double>(), st.scale_l.as<double>(), st.diag_l.as<double>(), st.gabs.as<double>());
+    if (gmax_l_dev) {
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.gabs.as<double>(), 3 * D.L, gmax_l_dev, 0, 1);
+    }
+    VSL_CHECK_LAUNCH(ctx);
+    // Schur with landmark damping only: reuse ba_schur with damping, but with a zero camera diagonal
+    VSL_HIP(ctx, hipMemsetAsync(st.diag_c.p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), ctx->stream));
+    if ((rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true))) return rc;
   }
-  VSL_CHECK_LAUNCH(ctx);
-  // Schur with landmark damping only: reuse ba_schur with damping, but with a zero camera diagonal
-  VSL_HIP(ctx, hipMemsetAsync(st.diag_c.p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), ctx->stream));
-  int rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true);
-  if (rc) return rc;
   if (n > 0) {
-    VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!s->solo) VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(sess_pack_b_kernel, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, D.nfree, st.rhs.as<double>(),
                        st.H.as<double>(), st.g_c.as<double>(), st.scalars.as<double>(), packB_dev + st.s_elems);
     VSL_CHECK_LAUNCH(ctx);
@@ -2323,14 +2457,23 @@ extern "C" int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_fu
   const BaDims& D = st.D;
   const int n = D.n, nl = 3 * D.L;
   if (n > 0) {
-    VSL_HIP(ctx, hipMemcpyAsync(st.S.p, packB_full_dev, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!s->solo) VSL_HIP(ctx, hipMemcpyAsync(st.S.p, packB_full_dev, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(sess_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.s_elems, packB_full_dev, 1.0 / radius,
                        refresh_diag, s->diagc_keep.as<double>(), st.S_eff(), st.ldS, st.rhs.as<double>());
     VSL_CHECK_LAUNCH(ctx);
   }
+  int rc;
+  if (st.large_fused) {
+    // everything is enqueued, nothing is read back here: a failed factorisation leaves flag[1] = 0 and numbers nobody
+    // uses (the caller's one read of packC per iteration sees the step as unusable)
+    if ((rc = ba_solve_enqueue(ctx, st))) return rc;
+    if ((rc = bal_step(ctx, st))) return rc;
+    hipLaunchKernelGGL(sess_pack_c_kernel, dim3(1), dim3(64), 0, ctx->stream, st.scalars.as<double>(), st.flag.as<int>(), 1, packC_dev);
+    VSL_CHECK_LAUNCH(ctx);
+    return VSL_OK;
+  }
   bool ok = true;
-  int rc = ba_solve(ctx, st, ok);
-  if (rc) return rc;
+  if ((rc = ba_solve(ctx, st, ok))) return rc;
   const int okflag = ok ? 1 : 0;
   VSL_HIP(ctx, hipMemcpyAsync(st.flag.p, &okflag, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2357,7 +2500,7 @@ extern "C" int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_fu
     hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream, st.partials.as<double>(), st.nb_obs, st.scalars.as<double>(), 5, 0);
     VSL_CHECK_LAUNCH(ctx);
   }
-  hipLaunchKernelGGL(sess_pack_c_kernel, dim3(1), dim3(64), 0, ctx->stream, st.scalars.as<double>(), st.flag.as<int>(), packC_dev);
+  hipLaunchKernelGGL(sess_pack_c_kernel, dim3(1), dim3(64), 0, ctx->stream, st.scalars.as<double>(), st.flag.as<int>(), 0, packC_dev);
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
@@ -2417,9 +2560,9 @@ extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduc
   const int n = st.D.n;
   const size_t elems = st.s_elems, nB = elems + 3 * (size_t)n + 2;
   const double t_start = now_ms();
-  DevBuf bufA, packB, packC, gl, hostpack, gather;
-  if (bufA.alloc(8 * ((size_t)n + 1)) != hipSuccess || packB.alloc(8 * nB) != hipSuccess || packC.alloc(64) != hipSuccess ||
-      gl.alloc(8) != hipSuccess || hostpack.alloc(16) != hipSuccess)
+  DevBuf bufA, packB, packC, gl, gather;
+  if (bufA.alloc(8 * ((size_t)n + 1)) != hipSuccess || packB.alloc(8 * nB) != hipSuccess || packC.alloc(80) != hipSuccess ||
+      gl.alloc(8) != hipSuccess)
     return vsl_fail(ctx, VSL_ERR_NOMEM, "vsl_ba_session_solve: device allocation failed");
   auto AR = [&](double* buf, size_t count, int op) -> int {
     if (!allreduce) return VSL_OK;  // a caller that passes a callback at world 1 gets its (trivial) collectives: tests
@@ -2432,6 +2575,7 @@ extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduc
     return VSL_OK;
   };
   int rc;
+  s->solo = !allreduce;
   vsl_ba_summary sum;
   memset(&sum, 0, sizeof(sum));
   VSL_HIP(ctx, hipMemsetAsync(gl.p, 0, 8, ctx->stream));
@@ -2445,6 +2589,8 @@ extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduc
   sum.initial_cost = h2[0];
   double radius = 1e4, decrease = 2.0, cost = sum.initial_cost, gmax = INFINITY;
   int it = 0, invalid = 0, refresh = 1;
+  bool have_h2 = false;
+  double* const hostpack = packC.as<double>() + 8;  // [cost | max |gradient|] behind the 8 doubles of packC: one copy brings both
   sum.termination = 0;
   if (verbosity >= 2) fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n%4d % .6e\n", 0, cost);
   while (true) {
@@ -2453,20 +2599,38 @@ extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduc
     if (refresh) {
       if ((rc = AR(gl.as<double>(), 1, 1))) return rc;
       hipLaunchKernelGGL(sess_gmax_c_kernel, dim3(1), dim3(256), 0, ctx->stream, n, packB.as<double>() + elems + 2 * (size_t)n,
-                         st.scale_c.as<double>(), packB.as<double>() + elems + 3 * (size_t)n, gl.as<double>(), hostpack.as<double>());
+                         st.scale_c.as<double>(), packB.as<double>() + elems + 3 * (size_t)n, gl.as<double>(), hostpack);
       VSL_CHECK_LAUNCH(ctx);
-      if ((rc = D2H(h2, hostpack.p, 16))) return rc;
-      cost = h2[0];
-      gmax = h2[1];
+      have_h2 = false;  // (cost, |gradient|) of this linearisation: read together with the step's verdict below --
+                        // ONE host round trip per iteration; a gradient below tolerance is found one step late, and
+                        // that step is dropped
     }
-    if (it >= max_iters) { sum.termination = 0; break; }
-    if (gmax <= 1e-10) { sum.termination = 2; break; }
+    if (it >= max_iters) {
+      if (!have_h2) {
+        if ((rc = D2H(h2, hostpack, 16))) return rc;
+        cost = h2[0];
+        gmax = h2[1];
+      }
+      sum.termination = 0;
+      break;
+    }
+    if (have_h2 && gmax <= 1e-10) { sum.termination = 2; break; }
     if (radius <= 1e-32) { sum.termination = 4; break; }
     it++;
     if ((rc = vsl_ba_session_step_dev(s, packB.as<double>(), radius, refresh, packC.as<double>()))) return rc;
     if ((rc = AR(packC.as<double>(), 8, 0))) return rc;
-    double c[8];
-    if ((rc = D2H(c, packC.p, 64))) return rc;
+    double c[10];
+    if ((rc = D2H(c, packC.p, 80))) return rc;
+    if (!have_h2) {
+      cost = c[8];
+      gmax = c[9];
+      have_h2 = true;
+      if (gmax <= 1e-10) {
+        it--;
+        sum.termination = 2;
+        break;
+      }
+    }
     const double cams_step2 = c[5] / world, cams_x2 = c[6] / world;
     const bool ok = c[0] == 0.0 && c[1] > 0.0;
     if (!ok) {

@@ -879,10 +879,23 @@ __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, 
 // diagonal block in its DPP rows and solves its rows beside it, and between them the rank-16 update of columns 16..31 as
 // 16 x 16 tiles on the matrix unit.  Same contract as cbf_panel_factor: W holds the panel of L and the solved right-hand
 // side row, sh.dinv_s the reciprocal pivots, sh.fail_s is set on a bad pivot, ends with a workgroup barrier.
+#ifdef BCR_TIMING
+#define BCP_TARG , long long* sh_tp
+#define BCP_TPASS , tq2
+#else
+#define BCP_TARG
+#define BCP_TPASS
+#endif
 template <int NTHR>
-__device__ __forceinline__ void bcr_panel_factor_dpp(double (*W)[CH_NB + 1], int rows, CbfShared& sh) {
+__device__ __forceinline__ void bcr_panel_factor_dpp(double (*W)[CH_NB + 1], int rows, CbfShared& sh BCP_TARG) {
   static_assert(CH_NB == 32, "two 16-column halves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, l16 = lane & 15;
+#ifdef BCR_TIMING
+  long long tt = __builtin_amdgcn_s_memtime();
+#define BCP_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); sh_tp[q] += t2 - tt; tt = t2; }
+#else
+#define BCP_STAMP(q)
+#endif
 #pragma unroll 1
   for (int half = 0; half < 2; half++) {
     const int c0 = 16 * half, r0 = c0 + 16, nrow = rows - r0;  // panel rows below the diagonal block, the right-hand side included
@@ -896,7 +909,9 @@ __device__ __forceinline__ void bcr_panel_factor_dpp(double (*W)[CH_NB + 1], int
         p[k] = valid ? W[prow][c0 + k] : 0.0;
       }
       bool good = true;
+      BCP_STAMP(0)
       CsCol<0>::run(d, p, (wave == 0 && lane == 0) ? sh.dinv_s + c0 : (double*)nullptr, good);
+      BCP_STAMP(1)
       if (wave == 0 && lane < 16) {
 #pragma unroll
         for (int k = 0; k < 16; k++) W[c0 + lane][c0 + k] = k <= lane ? d[k] : 0.0;
@@ -906,8 +921,10 @@ __device__ __forceinline__ void bcr_panel_factor_dpp(double (*W)[CH_NB + 1], int
         for (int k = 0; k < 16; k++) W[prow][c0 + k] = p[k];
       }
       if (!good && lane == 0) sh.fail_s = 1;
+      BCP_STAMP(2)
     }
     __syncthreads();
+    BCP_STAMP(3)
     if (half == 0) {
       // columns 16..31 of the rows from 16 on lose their products with the first sixteen columns
       const int nt = (rows - 16 + 15) >> 4;
@@ -925,7 +942,9 @@ __device__ __forceinline__ void bcr_panel_factor_dpp(double (*W)[CH_NB + 1], int
           if (r < rows) W[r][16 + l16] = acc[q];
         }
       }
+      BCP_STAMP(4)
       __syncthreads();
+      BCP_STAMP(5)
     }
   }
 }
@@ -954,21 +973,33 @@ __device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ D
     tile_of[id] = id < ntiles ? (unsigned short)(ti | ((id - ti * (ti + 1) / 2) << 8)) : (unsigned short)0xffff;
   }
   __syncthreads();
+#ifdef BCR_TIMING
+  long long tq[6] = {0, 0, 0, 0, 0, 0}, tq2[6] = {0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
+#define BCR_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); tq[q] += t2 - tt; tt = t2; }
+#else
+#define BCR_STAMP(q)
+#endif
   double acc[SLOTS][4];  // (plain doubles: an array of ext-vectors stayed in scratch memory)
+  // the wavefront's tile ids are wave-uniform: held in scalar registers (round 4; read from the LDS table in front of
+  // every slot of every panel step they were 14 dependent LDS round trips per step in both tile loops)
+  unsigned tsl[SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; sl++) tsl[sl] = (unsigned)__builtin_amdgcn_readfirstlane((int)tile_of[wave + (BCR_REG_THREADS / 64) * sl]);
 #pragma unroll
   for (int sl = 0; sl < SLOTS; sl++) {
-    const unsigned t = tile_of[wave + (BCR_REG_THREADS / 64) * sl];
+    const unsigned t = tsl[sl];
     const int ti = t & 255, tj = t >> 8;
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[sl][q] = t != 0xffffu ? Dg[(size_t)(16 * ti + kq + 4 * q) * B + 16 * tj + l16] : 0.0;
   }
   __syncthreads();
+  BCR_STAMP(0)
   for (int k = 0; k < B; k += CH_NB) {
     const int m = B - k - CH_NB, rows = CH_NB + m + 1, tk = k >> 4;  // tk: first tile column of the panel
     // the panel into the window: the owners of tile columns tk, tk + 1 write their tiles (rows from matrix row k)
 #pragma unroll
     for (int sl = 0; sl < SLOTS; sl++) {
-      const unsigned t = tile_of[wave + (BCR_REG_THREADS / 64) * sl];
+      const unsigned t = tsl[sl];
       const int ti = t & 255, tj = t >> 8;
       if (t != 0xffffu && (tj == tk || tj == tk + 1)) {
 #pragma unroll
@@ -978,10 +1009,12 @@ __device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ D
     }
     if (tid < CH_NB) W[rows - 1][tid] = bvec[k + tid];
     __syncthreads();
+    BCR_STAMP(1)
     if (BCR_DPP_PANEL)
-      bcr_panel_factor_dpp<BCR_REG_THREADS>(W, rows, sh);
+      bcr_panel_factor_dpp<BCR_REG_THREADS>(W, rows, sh BCP_TPASS);
     else
       cbf_panel_factor<BCR_REG_THREADS>(W, rows, sh);
+    BCR_STAMP(2)
     if (sh.fail_s) return false;  // workgroup-uniform (cbf_panel_factor ends with a barrier)
     // the factored panel, y and the reciprocal pivots to global memory; right-hand side of the rows below
     for (int idx = tid; idx < (CH_NB + m) * CH_NB; idx += BCR_REG_THREADS) {
@@ -998,10 +1031,11 @@ __device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ D
       for (int c = 0; c < CH_NB; c++) dot += W[CH_NB + tid][c] * W[rows - 1][c];
       bvec[k + CH_NB + tid] -= dot;
     }
+    BCR_STAMP(3)
     // trailing tiles: acc -= P_i P_j^T, P = the solved panel rows (W row of matrix row r is r - k)
 #pragma unroll
     for (int sl = 0; sl < SLOTS; sl++) {
-      const unsigned t = tile_of[wave + (BCR_REG_THREADS / 64) * sl];
+      const unsigned t = tsl[sl];
       const int ti = t & 255, tj = t >> 8;
       if (t != 0xffffu && tj >= tk + 2) {
         const int ra = 16 * ti - k + l16, rb = 16 * tj - k + l16;
@@ -1016,8 +1050,18 @@ __device__ __forceinline__ bool bcr_chol_registers(int B, double* __restrict__ D
       }
       __builtin_amdgcn_sched_barrier(0);  // one tile at a time: hoisting every slot's 16 operand loads costs 400 registers
     }
+    BCR_STAMP(4)
     __syncthreads();
+    BCR_STAMP(5)
   }
+#ifdef BCR_TIMING
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 3 || wave == 7))
+    printf("bcr_chol wave %d: load %lld | tiles->W %lld | panel %lld | store+dot %lld | trailing %lld | barrier %lld  (x10 ns)\n", wave,
+           tq[0], tq[1], tq[2], tq[3], tq[4], tq[5]);
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 3 || wave == 7))
+    printf("   panel wave %d: lds->regs %lld | columns %lld | regs->lds %lld | barrier %lld | rank-16 %lld | barrier %lld\n", wave, tq2[0],
+           tq2[1], tq2[2], tq2[3], tq2[4], tq2[5]);
+#endif
   return true;
 }
 
@@ -1131,20 +1175,33 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
     }
   }
   __syncthreads();
-  const int col = tid & 31, grp = tid >> 5;  // 8 groups x 4 rows of a panel
-  for (int p0 = 0; p0 < B; p0 += 32) {
-    for (int rr0 = 0; rr0 < 32; rr0 += 8) {  // the panel's rows of L left of its diagonal block: column k = tid (B <= 256)
-      double v[8];
+  const int col = tid & 31, grp = tid >> 5;  // 8 groups x 4 rows (the right-hand-side dot product below)
+  const int wv = tid >> 6, lane = tid & 63, ti = wv >> 1, tj = wv & 1, kq = lane >> 4, l16 = lane & 15;
+  // The panel's rows of L left of its diagonal block (column k = tid: B <= 256) and the inverse of that block are
+  // fetched into registers TWO PANELS AHEAD (round 4): as loads at the top of a panel step they were two exposed global
+  // round trips on a chain of seven dependent steps, and one step of two small matrix products is shorter than a round
+  // trip.  Three barriers per step, both products on the matrix unit.
+  auto fetch = [&](int pn, double (&lv)[32], double (&li)[4]) {
+    if (pn >= B) return;
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = tid < p0 ? L[(size_t)(p0 + rr0 + u) * B + tid] : 0.0;
+    for (int u = 0; u < 32; u++) lv[u] = tid < pn ? L[(size_t)(pn + u) * B + tid] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (tid < p0) Lp[(rr0 + u) * (B + 1) + tid] = v[u];
+    for (int u = 0; u < 4; u++) li[u] = Li[(size_t)(pn >> 5) * 1024 + tid + 256 * u];
+  };
+  auto step = [&](int p0, double (&lv)[32], double (&li)[4]) {
+    if (tid < p0) {
+#pragma unroll
+      for (int u = 0; u < 32; u++) Lp[u * (B + 1) + tid] = lv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = tid + 256 * u;
+      Ls[(idx >> 5) * 33 + (idx & 31)] = li[u];
     }
     __syncthreads();
+    fetch(p0 + 64, lv, li);
     {  // T_p = R_p - L[p, 0:p0] U[0:p0]: one 16 x 16 tile per wavefront on the matrix unit (two chains); as four rows
        // per thread on the vector ALU this product was LDS-bound (five LDS reads per four multiply-adds)
-      const int wv = tid >> 6, lane = tid & 63, ti = wv >> 1, tj = wv & 1, kq = lane >> 4, l16 = lane & 15;
       v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
       const double* lrow = Lp + (16 * ti + l16) * (B + 1) + kq;
       const double* ucol = Us + kq * 33 + 16 * tj + l16;
@@ -1158,23 +1215,31 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
       for (int qq = 0; qq < 4; qq++) Us[(p0 + 16 * ti + kq + 4 * qq) * 33 + 16 * tj + l16] -= acc[qq] + acc2[qq];
     }
     __syncthreads();
-    // the 32 x 32 diagonal part: U_p = Linv_pp T_p, a dense product (all threads)
-    for (int idx = tid; idx < 1024; idx += 256) Ls[(idx >> 5) * 33 + (idx & 31)] = Li[(size_t)(p0 >> 5) * 1024 + idx];
-    __syncthreads();
-    {
-      double o[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-      for (int k = 0; k < 32; k++) {
-        const double t = Us[(p0 + k) * 33 + col];
+    {  // the 32 x 32 diagonal part: U_p = Linv_pp T_p, the same tile of the same wavefront
+      v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+      const double* arow = Ls + (16 * ti + l16) * 33 + kq;
+      const double* tcol = Us + (p0 + kq) * 33 + 16 * tj + l16;
 #pragma unroll
-        for (int a = 0; a < 4; a++) o[a] += Ls[(4 * grp + a) * 33 + k] * t;
+      for (int k0 = 0; k0 < 32; k0 += 8) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k0], tcol[k0 * 33], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k0 + 4], tcol[(k0 + 4) * 33], acc2, 0, 0, 0);
       }
       __syncthreads();
 #pragma unroll
-      for (int a = 0; a < 4; a++) Us[(p0 + 4 * grp + a) * 33 + col] = o[a];
+      for (int qq = 0; qq < 4; qq++) Us[(p0 + 16 * ti + kq + 4 * qq) * 33 + 16 * tj + l16] = acc[qq] + acc2[qq];
     }
-    __syncthreads();
+  };
+  double lvA[32], liA[4], lvB[32], liB[4];
+#pragma unroll
+  for (int u = 0; u < 32; u++) lvA[u] = 0.0;  // (panel 0 has no rows to its left)
+#pragma unroll
+  for (int u = 0; u < 4; u++) liA[u] = Li[tid + 256 * u];
+  fetch(32, lvB, liB);
+  for (int p0 = 0; p0 < B; p0 += 64) {
+    step(p0, lvA, liA);
+    if (p0 + 32 < B) step(p0 + 32, lvB, liB);
   }
+  __syncthreads();
   for (int r = tid >> 5; r < B; r += 8) Uo[(size_t)r * B + c0 + (tid & 31)] = Us[r * 33 + (tid & 31)];
   // right-hand side of the neighbour: (U^T z_e) for these 32 columns, accumulated in the neighbour's pending slot
   // (slot 1 of p: written by the eliminated block below it; slot 0 of q: by the one above; one writer per level)
@@ -1257,16 +1322,97 @@ __global__ __launch_bounds__(256) void bcr_gemm_kernel(const BcrJob* __restrict_
   }
 }
 
-// solution of an eliminated block: t = z_e - U1 x_p - U2 x_q, then L_e^T x_e = t panel by panel from the bottom:
-// x_p = Linv_pp^T (t_p - sum over the rows below of L[r][p]^T x_r) -- the 32 x 32 triangular part through the
-// precomputed inverse of the diagonal block (no serial 32-step chain), the rest a column-sliced dot product.
-__global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ D,
-                                                               const double* __restrict__ U, const double* __restrict__ Linv,
-                                                               double* __restrict__ bb, const double* __restrict__ yy,
-                                                               const int* __restrict__ ok) {
-  __shared__ double ts[BCR_MAXB];              // t, then x
-  __shared__ double part[CBF_THREADS / 32][33];
-  __shared__ double wv[32];
+// All products of one level in ONE launch, target by target (round 4; the two launches of bcr_gemm_kernel above -- the
+// D_p updates and new couplings, then the D_q updates, because D_p of one job is D_q of the job above it -- kept for A/B
+// builds under BCR_GEMM_TARGETS 0).  A target is a remaining diagonal block with its one or two updates
+// D_x -= U1(b)^T U1(b) + U2(a)^T U2(a) (lower 32 x 32 tiles only) or a new coupling K(q, p) = -U2^T U1 (all tiles); the sum
+// over the two contributions runs in a fixed order.  One wavefront per 16 x 16 tile of the target on
+// v_mfma_f64_16x16x4_f64, operands straight from the row-major U blocks (a k-row of 16 consecutive doubles per
+// 16 lanes), two batches of sixteen loads in flight per wavefront and no LDS: the 32 x 32-per-workgroup form staged two 224 x 32 slabs
+// (114 KB: one workgroup per compute unit) and spent five LDS reads per four multiply-adds of a 2 x 2 register patch.
+struct BcrTarget {
+  int c_is_k, c_idx;  // destination: Knext[c_idx] (assigned) or D[c_idx] (updated, lower tiles)
+  int m1, n1;         // first product  M^T N: U block slots (2 u + 0 / 1)
+  int m2, n2;         // second product (-1: none)
+  int pad0, pad1;
+};
+
+#ifndef BCR_GEMM_TARGETS
+#define BCR_GEMM_TARGETS 1
+#endif
+#define BCR_GT_KU 8  // k-steps (of 4) per load batch: 16 loads in flight per lane, two batches deep
+
+// one batch of operands: k-rows k0 + 4 u + kq of the two slabs (16 consecutive doubles per 16 lanes)
+__device__ __forceinline__ void bcr_gt_load(const double* __restrict__ Mp, const double* __restrict__ Np, int B, int k0,
+                                            double (&av)[BCR_GT_KU], double (&bv)[BCR_GT_KU]) {
+#pragma unroll
+  for (int u = 0; u < BCR_GT_KU; u++) {
+    const size_t off = (size_t)(k0 + 4 * u) * B;
+    av[u] = Mp[off];
+    bv[u] = Np[off];
+  }
+}
+
+__global__ __launch_bounds__(256) void bcr_gemm_targets_kernel(const BcrTarget* __restrict__ targets, int B,
+                                                               const double* __restrict__ U, double* __restrict__ D,
+                                                               double* __restrict__ Knext, const int* __restrict__ ok) {
+  if (!*ok) return;
+  const BcrTarget tg = targets[blockIdx.x];
+  const int tiles = B / 16, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // one wavefront per 16 x 16 tile (a wavefront's chain is B / 4 or B / 2 dependent matrix instructions: with 32 x 32
+  // per wavefront the deepest levels -- one to three jobs -- ran as long as level 0); workgroup = 2 x 2 tiles, so the two
+  // waves of a tile row share the M rows in the L1, of a tile column the N rows
+  const int wt = (tiles + 1) / 2;
+  const int ti = 2 * (blockIdx.y / wt) + (wave >> 1), tj = 2 * (blockIdx.y % wt) + (wave & 1);
+  if (ti >= tiles || tj >= tiles) return;
+  if (!tg.c_is_k && tj > ti) return;
+  const size_t BB = (size_t)B * B;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int i0 = 16 * ti, j0 = 16 * tj;
+  v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  for (int pass = 0; pass < 2; pass++) {
+    const int ms = pass ? tg.m2 : tg.m1, ns = pass ? tg.n2 : tg.n1;
+    if (ms < 0) break;
+    const double* Mp = U + (size_t)ms * BB + (size_t)kq * B + i0 + l16;
+    const double* Np = U + (size_t)ns * BB + (size_t)kq * B + j0 + l16;
+    // B is a multiple of 32 = one batch; the next batch's loads are issued before this batch's products
+    double a0[BCR_GT_KU], b0[BCR_GT_KU], a1[BCR_GT_KU], b1[BCR_GT_KU];
+    bcr_gt_load(Mp, Np, B, 0, a0, b0);
+    for (int k0 = 0; k0 < B; k0 += 8 * BCR_GT_KU) {
+      const bool more1 = k0 + 4 * BCR_GT_KU < B, more2 = k0 + 8 * BCR_GT_KU < B;
+      if (more1) bcr_gt_load(Mp, Np, B, k0 + 4 * BCR_GT_KU, a1, b1);
+#pragma unroll
+      for (int u = 0; u < BCR_GT_KU; u += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u + 1], b0[u + 1], acc2, 0, 0, 0);
+      }
+      if (!more1) break;
+      if (more2) bcr_gt_load(Mp, Np, B, k0 + 8 * BCR_GT_KU, a0, b0);
+#pragma unroll
+      for (int u = 0; u < BCR_GT_KU; u += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u + 1], b1[u + 1], acc2, 0, 0, 0);
+      }
+    }
+  }
+  double* C = tg.c_is_k ? Knext + (size_t)tg.c_idx * BB : D + (size_t)tg.c_idx * BB;
+#pragma unroll
+  for (int qq = 0; qq < 4; qq++) {
+    double* c = C + (size_t)(i0 + kq + 4 * qq) * B + j0 + l16;
+    if (tg.c_is_k)
+      *c = -(acc[qq] + acc2[qq]);
+    else
+      *c -= acc[qq] + acc2[qq];  // (entries above the diagonal of a diagonal tile are never read)
+  }
+}
+
+// t = z_e - U1 x_p - U2 x_q of the eliminated blocks of one level, rows spread over BCR_GV_CHUNKS workgroups per block
+// (round 4: inside bcr_back_kernel this product -- 2 B^2 doubles read by ONE workgroup per block -- was ~15 us of its
+// ~34 us in front of the seven dependent panel steps); t is left in the block's solution slot bb[e].
+#define BCR_GV_CHUNKS 8
+__global__ __launch_bounds__(256) void bcr_back_gemv_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ U,
+                                                            double* __restrict__ bb, const double* __restrict__ yy,
+                                                            const int* __restrict__ ok) {
   if (!*ok) return;
   const BcrJob jb = jobs[blockIdx.x];
   const size_t BB = (size_t)B * B;
@@ -1275,74 +1421,92 @@ __global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __r
   const double* xp = bb + (size_t)jb.p * B;
   const double* xq = jb.q >= 0 ? bb + (size_t)jb.q * B : nullptr;
   const double* z = yy + (size_t)jb.e * B;
-  const double* L = D + (size_t)jb.e * BB;
-  const double* Li = Linv + (size_t)jb.u * (B / 32) * 1024;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum; four rows at a time so that
-  // their loads are in flight together (B <= 256: four 64-column chunks per row)
-  {
-    double xpv[4], xqv[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (B + BCR_GV_CHUNKS - 1) / BCR_GV_CHUNKS, r_lo = per * blockIdx.y, r_hi = min(B, r_lo + per);
+  double xpv[4], xqv[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int c = lane + 64 * j;
-      xpv[j] = c < B ? xp[c] : 0.0;
-      xqv[j] = (xq && c < B) ? xq[c] : 0.0;
-    }
-    for (int r0 = 4 * wave; r0 < B; r0 += 4 * (CBF_THREADS / 64)) {
-      double a1[4][4], a2[4][4];
+  for (int j = 0; j < 4; j++) {
+    const int c = lane + 64 * j;
+    xpv[j] = c < B ? xp[c] : 0.0;
+    xqv[j] = (xq && c < B) ? xq[c] : 0.0;
+  }
+  // one wavefront per row, lanes along the (contiguous) columns, fixed-order lane sum; four rows at a time so that their
+  // loads are in flight together (B <= 256: four 64-column chunks per row)
+  for (int r0 = r_lo + 4 * wave; r0 < r_hi; r0 += 16) {
+    double a1[4][4], a2[4][4];
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int r = r0 + u, c = lane + 64 * j;
-          const bool in = r < B && c < B;
-          a1[u][j] = in ? U1[(size_t)r * B + c] : 0.0;
-          a2[u][j] = (in && xq) ? U2[(size_t)r * B + c] : 0.0;
-        }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) sacc += a1[u][j] * xpv[j] + a2[u][j] * xqv[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-        if (lane == 0 && r0 + u < B) ts[r0 + u] = z[r0 + u] - sacc;
+      for (int j = 0; j < 4; j++) {
+        const int r = r0 + u, c = lane + 64 * j;
+        const bool in = r < r_hi && c < B;
+        a1[u][j] = in ? U1[(size_t)r * B + c] : 0.0;
+        a2[u][j] = (in && xq) ? U2[(size_t)r * B + c] : 0.0;
       }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) sacc += a1[u][j] * xpv[j] + a2[u][j] * xqv[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+      if (lane == 0 && r0 + u < r_hi) bb[(size_t)jb.e * B + r0 + u] = z[r0 + u] - sacc;
     }
   }
-  __syncthreads();
+}
+
+// solution of an eliminated block: t = z_e - U1 x_p - U2 x_q, then L_e^T x_e = t panel by panel from the bottom:
+// x_p = Linv_pp^T (t_p - sum over the rows below of L[r][p]^T x_r) -- the 32 x 32 triangular part through the
+// precomputed inverse of the diagonal block (no serial 32-step chain), the rest a column-sliced dot product.
+__global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __restrict__ jobs, int B, const double* __restrict__ D,
+                                                               const double* __restrict__ Linv, double* __restrict__ bb,
+                                                               const int* __restrict__ ok) {
+  __shared__ double ts[BCR_MAXB];              // t, then x
+  __shared__ double part[CBF_THREADS / 32][33];
+  __shared__ double Lis[(BCR_MAXB / 32) * 1024];  // the inverses of the factor's diagonal blocks
+  if (!*ok) return;
+  const BcrJob jb = jobs[blockIdx.x];
+  const size_t BB = (size_t)B * B;
+  const double* L = D + (size_t)jb.e * BB;
+  const double* Li = Linv + (size_t)jb.u * (B / 32) * 1024;
+  const int tid = threadIdx.x;
+  for (int r = tid; r < B; r += CBF_THREADS) ts[r] = bb[(size_t)jb.e * B + r];  // t (bcr_back_gemv_kernel)
   const int col = tid & 31, sl = tid >> 5;  // CBF_THREADS / 32 row slices x 32 columns
   constexpr int NS = CBF_THREADS / 32;
+  // (round 4) nothing of the chain below waits for global memory: the diagonal-block inverses are staged once, the rows
+  // of L below a panel are fetched one panel ahead, and the panel's solution comes from one wavefront without a barrier
+  // between the partial sums and the product with the inverse (it was 7 steps x (2 exposed round trips + 3 barriers))
+  auto fetch = [&](int p0, double* lv) {
+#pragma unroll
+    for (int u = 0; u < 11; u++) {  // the rows below the panel, NS apart per slice: at most ceil(224 / 24) = 10 per thread
+      const int r = p0 + 32 + sl + NS * u;
+      lv[u] = (p0 >= 0 && r < B) ? L[(size_t)r * B + p0 + col] : 0.0;
+    }
+  };
+  double lv[11];
+  fetch(B - 32, lv);
+  for (int idx = tid; idx < (B / 32) * 1024; idx += CBF_THREADS) Lis[idx] = Li[idx];
+  __syncthreads();
   for (int p0 = B - 32; p0 >= 0; p0 -= 32) {
     double sacc = 0.0;
-    {  // the rows below the panel, NS apart per slice: at most ceil(224 / 24) = 10 per thread, all loaded before use
-      double lv[11];
 #pragma unroll
-      for (int u = 0; u < 11; u++) {
-        const int r = p0 + 32 + sl + NS * u;
-        lv[u] = r < B ? L[(size_t)r * B + p0 + col] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 11; u++) {
-        const int r = p0 + 32 + sl + NS * u;
-        if (r < B) sacc += lv[u] * ts[r];
-      }
+    for (int u = 0; u < 11; u++) {
+      const int r = p0 + 32 + sl + NS * u;
+      if (r < B) sacc += lv[u] * ts[r];
     }
     part[sl][col] = sacc;
+    fetch(p0 - 32, lv);
     __syncthreads();
-    if (tid < 32) {
+    if (tid < 64) {  // lanes 32..63 mirror 0..31 (the broadcasts read lanes 0..31 only)
       double t = 0.0;
 #pragma unroll
-      for (int g = 0; g < NS; g++) t += part[g][tid];
-      wv[tid] = ts[p0 + tid] - t;
-    }
-    __syncthreads();
-    if (tid < 32) {  // x_c = sum_k Linv[k][c] w_k  (k >= c: the inverse is lower triangular)
-      double x = 0.0;
-      const double* Lb = Li + (size_t)(p0 >> 5) * 1024;
-#pragma unroll 8
-      for (int k = 0; k < 32; k++) x += Lb[k * 32 + tid] * wv[k];
-      ts[p0 + tid] = x;
+      for (int g = 0; g < NS; g++) t += part[g][tid & 31];
+      const double w = ts[p0 + (tid & 31)] - t;
+      double x = 0.0;  // x_c = sum_k Linv[k][c] w_k  (k >= c: the inverse is lower triangular)
+      const double* Lb = Lis + (size_t)(p0 >> 5) * 1024;
+#pragma unroll
+      for (int k = 0; k < 32; k++) x += Lb[k * 32 + (tid & 31)] * lane_bcast(w, k);
+      if (tid < 32) ts[p0 + tid] = x;
     }
     __syncthreads();
   }
@@ -1388,6 +1552,25 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     active = next;
   }
   const int last = active[0];
+  // product targets per level (bcr_gemm_targets_kernel): the remaining blocks with their one or two updates, the new couplings
+  std::vector<std::vector<BcrTarget>> targets(levels.size());
+  for (size_t l = 0; l < levels.size(); l++) {
+    std::vector<BcrTarget>& tl = targets[l];
+    std::vector<int> slot_of(nblk, -1);
+    for (const BcrJob& jb : levels[l]) {   // jobs in block order: the update from the block above (as its q) comes first
+      for (int side = 0; side < 2; side++) {
+        const int x = side ? jb.q : jb.p, us = 2 * jb.u + side;
+        if (x < 0) continue;
+        if (slot_of[x] < 0) {
+          slot_of[x] = (int)tl.size();
+          tl.push_back(BcrTarget{0, x, us, us, -1, -1, 0, 0});
+        } else {
+          tl[slot_of[x]].m2 = tl[slot_of[x]].n2 = us;
+        }
+      }
+      if (jb.knew >= 0 && l + 1 < levels.size()) tl.push_back(BcrTarget{1, jb.knew, 2 * jb.u + 1, 2 * jb.u, -1, -1, 0, 0});
+    }
+  }
   size_t n_k = 0, n_jobs = 0;
   for (size_t l = 0; l < levels.size(); l++) {
     n_k += (size_t)ncoup[l];
@@ -1398,7 +1581,10 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
   for (auto& lv : levels) max_nj = std::max(max_nj, lv.size());
   const size_t linv_doubles = ((size_t)n_u + 1) * (size_t)(B / 32) * 1024;  // per eliminated block (+ the last one), kept for the back-substitution
   const size_t doubles = (size_t)nblk * BB + n_k * BB + (size_t)2 * n_u * BB + 5 * (size_t)nblk * B + linv_doubles + 16;
-  const size_t job_bytes = (n_jobs + 1) * sizeof(BcrJob);
+  size_t n_targets = 0;
+  for (auto& tl : targets) n_targets += tl.size();
+  const size_t job_only_bytes = ((n_jobs + 1) * sizeof(BcrJob) + 63) / 64 * 64;
+  const size_t job_bytes = job_only_bytes + (n_targets + 1) * sizeof(BcrTarget);
   void* ws = nullptr;
   int rc = vsl_ctx_dscratch(ctx, sizeof(double) * doubles + 256, &ws);
   if (rc) return rc;
@@ -1433,11 +1619,20 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
       ko += (size_t)ncoup[l];
     }
   }
+  BcrTarget* targets_dev = (BcrTarget*)((char*)ctx->bcr_jobs + job_only_bytes);
+  std::vector<BcrTarget> tflat;
+  std::vector<size_t> tgt_off;
+  for (auto& tl : targets) {
+    tgt_off.push_back(tflat.size());
+    tflat.insert(tflat.end(), tl.begin(), tl.end());
+  }
   static const int one = 1;
   VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (ctx->bcr_key_n != n || ctx->bcr_key_bw != bw) {
     VSL_HIP(ctx, hipMemcpyAsync(jobs_dev, flat.data(), flat.size() * sizeof(BcrJob), hipMemcpyHostToDevice, ctx->stream));
-    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is on this stack frame
+    if (!tflat.empty())
+      VSL_HIP(ctx, hipMemcpyAsync(targets_dev, tflat.data(), tflat.size() * sizeof(BcrTarget), hipMemcpyHostToDevice, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` / `tflat` are on this stack frame
     ctx->bcr_key_n = n;
     ctx->bcr_key_bw = bw;
   }
@@ -1455,8 +1650,16 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
       hipLaunchKernelGGL(bcr_chol_kernel<17>, dim3(nj), dim3(BCR_REG_THREADS), 0, q, jl, B, D, bb, yy, dinv, pend, ok_dev);
     hipLaunchKernelGGL(bcr_dinv_kernel, dim3(nj, tiles), dim3(64), 0, q, jl, B, D, dinv, Linv, ok_dev);
     hipLaunchKernelGGL(bcr_trsm_kernel, dim3(nj, 2 * tiles), dim3(256), 0, q, jl, B, D, Linv, Kl, U, yy, pend, ok_dev);
+#if BCR_GEMM_TARGETS
+    {
+      const int wt = (B / 16 + 1) / 2;
+      hipLaunchKernelGGL(bcr_gemm_targets_kernel, dim3((unsigned)targets[l].size(), wt * wt), dim3(256), 0, q,
+                         targets_dev + tgt_off[l], B, U, D, Kn, ok_dev);
+    }
+#else
     hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles, Kn ? 2 : 1), dim3(256), 0, q, jl, B, 0, U, D, Kn, ok_dev);
     hipLaunchKernelGGL(bcr_gemm_kernel, dim3(nj, tiles * tiles, 1), dim3(256), 0, q, jl, B, 1, U, D, Kn, ok_dev);
+#endif
   }
   if (B <= 224)
     hipLaunchKernelGGL(bcr_last_kernel<14>, dim3(1), dim3(BCR_REG_THREADS), 0, q, last, B, D, bb, yy, dinv, pend, ok_dev);
@@ -1465,7 +1668,8 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
   hipLaunchKernelGGL(bcr_last_back_kernel, dim3(1), dim3(CBF_THREADS), 0, q, last, B, D, bb, yy, dinv, ok_dev);
   for (size_t l = levels.size(); l-- > 0;) {
     const int nj = (int)levels[l].size();
-    hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, U, Linv, bb, yy, ok_dev);
+    hipLaunchKernelGGL(bcr_back_gemv_kernel, dim3(nj, BCR_GV_CHUNKS), dim3(256), 0, q, jobs_dev + job_off[l], B, U, bb, yy, ok_dev);
+    hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, Linv, bb, ok_dev);
   }
   hipLaunchKernelGGL(bcr_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, q, bb, n, b, ok_dev);
   VSL_CHECK_LAUNCH(ctx);

@@ -25,13 +25,23 @@ __device__ __forceinline__ void cs_fmac_bcast(double& acc, double bsrc, double o
     asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
 }
 
+// Pivot step J of a panel: d = the diagonal block's row of this lane, p = its panel row.  The updates of a column are
+// split (round 4): only column J + 1 -- the next pivot's column -- is updated at once; the others are DEFERRED into the
+// next step, where they are issued between the pivot's broadcast and the use of its reciprocal square root, i.e. under the
+// latency of rsq and its two Newton steps instead of in front of it (a wavefront issues in order, and one wavefront per
+// SIMD runs the panel: 16 columns x (chain ~150 cycles + 2 (15 - J) multiply-adds) became ~max of the two).  Every entry
+// still receives its updates in column order: results are bit-identical to the undeferred form.
 template <int J>
-struct CsCol {  // pivot step J of a panel: d = the diagonal block's row of this lane, p = its panel row
-  static __device__ __forceinline__ void run(double (&d)[16], double (&p)[16], double* inv_out, bool& good) {
+struct CsCol {
+  // (ljp, pjp): column J - 1 of the factor (this lane's rows of the diagonal block / of the panel), not yet applied to
+  // columns J + 1 .. 15
+  static __device__ __forceinline__ void run(double (&d)[16], double (&p)[16], double* inv_out, bool& good, double ljp = 0.0,
+                                             double pjp = 0.0) {
     const double dj = cs_bcast<J>(d[J]);
     if (!(dj > 0.0) || !isfinite(dj)) good = false;
     // 1 / sqrt by the hardware estimate and two Newton steps (an IEEE sqrt + divide is ~200 dependent instructions)
     double iv = __builtin_amdgcn_rsq(dj);
+    if constexpr (J > 0) upd<J - 1, J + 1>(d, p, ljp, pjp);
     iv = iv * (1.5 - 0.5 * dj * iv * iv);
     iv = iv * (1.5 - 0.5 * dj * iv * iv);
     if (inv_out) inv_out[J] = iv;  // (lane J of wavefront 0 only: the pointer is null elsewhere)
@@ -39,21 +49,24 @@ struct CsCol {  // pivot step J of a panel: d = the diagonal block's row of this
     const double pj = p[J] * iv;
     d[J] = lj;
     p[J] = pj;
-    upd<J + 1>(d, p, lj, pj);
-    CsCol<J + 1>::run(d, p, inv_out, good);
+    if constexpr (J < 15) {
+      cs_fmac_bcast<J + 1, true>(d[J + 1], lj, lj);   // d(i, J + 1) -= l(J + 1, J) l(i, J)
+      cs_fmac_bcast<J + 1, false>(p[J + 1], lj, pj);  // p(r, J + 1) -= l(J + 1, J) l(r, J)
+    }
+    CsCol<J + 1>::run(d, p, inv_out, good, lj, pj);
   }
-  template <int K>
+  template <int C, int K>  // column C of the factor into columns K .. 15
   static __device__ __forceinline__ void upd(double (&d)[16], double (&p)[16], double lj, double pj) {
     if constexpr (K < 16) {
-      cs_fmac_bcast<K, K == J + 1>(d[K], lj, lj);  // d(i, K) -= l(K, J) l(i, J)
-      cs_fmac_bcast<K, false>(p[K], lj, pj);       // p(r, K) -= l(K, J) l(r, J)
-      upd<K + 1>(d, p, lj, pj);
+      cs_fmac_bcast<K, false>(d[K], lj, lj);  // (lj was written a whole step ago: no wait states needed)
+      cs_fmac_bcast<K, false>(p[K], lj, pj);
+      upd<C, K + 1>(d, p, lj, pj);
     }
   }
 };
 template <>
 struct CsCol<16> {
-  static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double*, bool&) {}
+  static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double*, bool&, double = 0.0, double = 0.0) {}
 };
 
 template <int J>
