@@ -801,38 +801,71 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDims D, const int*
 // 64th pair of the list -- both 144-byte blocks with 16-byte loads, all 36 products -- so 64 pairs' loads are in flight
 // at once (one pair per iteration with the 36 entries over the lanes was bound by the latency of the dependent loads
 // pair -> W / Y: 0.85 ms per iteration at 4.4 M pairs); the 36 x 64 partial sums are folded through LDS in lane order.
+// The blocks of a round's 64 pairs are FETCHED COOPERATIVELY (round 4): the 128 blocks are 1152 pieces of 16 bytes,
+// piece m = 64 t + lane belongs to block m / 9, so nine consecutive lanes read one contiguous 144-byte block and an
+// instruction touches ~10 cache lines; they land in LDS at double2[m] (linear, conflict-free) and every lane reads its
+// own two blocks from there.  With a lane loading its own blocks every 16-byte load instruction touched 64 different
+// lines, and the L1's one-line-per-cycle tag rate -- 18 instructions x 64 lines per round -- bounded the kernel.
 // Band form keeps only x >= y of a diagonal block (lower_mode 2); lower_mode 1 = dense lower triangle (diagonal blocks
 // complete), 0 = full matrix (the mirror block is written as well).
 __global__ __launch_bounds__(64) void ba_schur_gather_kernel(int n_slots, int hbp1, const int* __restrict__ start,
                                                              const int* __restrict__ pairs, const double* __restrict__ Wg,
                                                              const double* __restrict__ Yg, double* __restrict__ S, int ldS,
                                                              int lower_mode) {
-  __shared__ double red[36][65];
-  const int slot = blockIdx.x;
+  __shared__ double red[36][65];  // (halved with a shuffle step first -- 12 instead of 8 wavefronts per compute unit -- the kernel was 9% SLOWER: more rows in flight than the L2 holds)
+  int slot = blockIdx.x;
+  if (hbp1 > 0) {
+    // Band form, XCD-aware order (round 4): workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD gets a
+    // CONTIGUOUS range of camera rows, walked in order.  The hbp1 slots of a row read the same Y blocks (the row camera's
+    // observations) and the rows c .. c + hbp1 - 1 the same W blocks (camera c's): with slot = blockIdx.x those readers
+    // sat on all eight XCDs, each L2 (4 MB) fetched every block for itself and the kernel ran at the fabric's ~5 TB/s
+    // (1.3 GB per launch for 254 MB of distinct blocks).
+    const int nrows = n_slots / hbp1, rpx = (nrows + 7) >> 3;
+    const int k = (int)(blockIdx.x >> 3), row = (int)(blockIdx.x & 7) * rpx + k / hbp1;
+    if (row >= nrows) return;
+    slot = row * hbp1 + k % hbp1;
+  }
   const int p0 = start[slot], p1 = start[slot + 1];
   if (p0 == p1) return;
   const int lane = threadIdx.x;
   double acc[36];
 #pragma unroll
   for (int e = 0; e < 36; e++) acc[e] = 0.0;
-  for (int p = p0 + lane; p < p1; p += 64) {
-    const int2 ij = *(const int2*)(pairs + 2 * (size_t)p);
-    const double2* yp = (const double2*)(Yg + 18 * (size_t)ij.x);
-    const double2* wp = (const double2*)(Wg + 18 * (size_t)ij.y);
-    double yv[18], wv[18];
+  double2* stage = (double2*)&red[0][0];  // 1152 pieces of a round; the same LDS folds the partial sums afterwards
+  static_assert(sizeof(red) >= 1152 * sizeof(double2), "the staging area must fit");
+  for (int base = p0; base < p1; base += 64) {
+    const int p = base + lane;
+    const bool have = p < p1;
+    int2 ij = make_int2(0, 0);  // (idle lanes fetch block 0: valid memory, never accumulated)
+    if (have) ij = *(const int2*)(pairs + 2 * (size_t)p);
+    double2 piece[18];
 #pragma unroll
-    for (int q = 0; q < 9; q++) {
-      const double2 a2 = yp[q], b2 = wp[q];
-      yv[2 * q] = a2.x;
-      yv[2 * q + 1] = a2.y;
-      wv[2 * q] = b2.x;
-      wv[2 * q + 1] = b2.y;
+    for (int t = 0; t < 18; t++) {
+      const int m = 64 * t + lane, b = m / 9, part = m - 9 * b;
+      const int iy = __shfl(ij.x, b & 63), iw = __shfl(ij.y, b & 63);
+      const double* src = b < 64 ? Yg + 18 * (size_t)iy : Wg + 18 * (size_t)iw;
+      piece[t] = *(const double2*)(src + 2 * part);
     }
 #pragma unroll
-    for (int x = 0; x < 6; x++)
+    for (int t = 0; t < 18; t++) stage[64 * t + lane] = piece[t];
+    __syncthreads();
+    if (have) {
+      double yv[18], wv[18];
 #pragma unroll
-      for (int y = 0; y < 6; y++)
-        acc[6 * x + y] += yv[3 * x] * wv[3 * y] + yv[3 * x + 1] * wv[3 * y + 1] + yv[3 * x + 2] * wv[3 * y + 2];
+      for (int q = 0; q < 9; q++) {
+        const double2 a2 = stage[9 * lane + q], b2 = stage[9 * (64 + lane) + q];
+        yv[2 * q] = a2.x;
+        yv[2 * q + 1] = a2.y;
+        wv[2 * q] = b2.x;
+        wv[2 * q + 1] = b2.y;
+      }
+#pragma unroll
+      for (int x = 0; x < 6; x++)
+#pragma unroll
+        for (int y = 0; y < 6; y++)
+          acc[6 * x + y] += yv[3 * x] * wv[3 * y] + yv[3 * x + 1] * wv[3 * y + 1] + yv[3 * x + 2] * wv[3 * y + 2];
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int e = 0; e < 36; e++) red[e][lane] = acc[e];
@@ -1696,6 +1729,13 @@ int ba_columns(vsl_ctx* ctx, BaState& st) {
   return VSL_OK;
 }
 
+// workgroups of ba_schur_gather_kernel: one per slot; in band form eight equal row ranges (see the kernel)
+unsigned gather_grid(const BaState& st) {
+  if (st.hbp1 <= 0) return (unsigned)st.n_slots;
+  const int nrows = st.n_slots / st.hbp1;
+  return 8u * (unsigned)((nrows + 7) / 8) * (unsigned)st.hbp1;
+}
+
 // block pair lists of the gather-form Schur complement for landmarks [l0, l0 + lc): built once per solve / session
 int ba_pair_lists(vsl_ctx* ctx, BaState& st, int l0, int lc) {
   if (st.pair_l0 == l0 && st.pair_lc == lc) return VSL_OK;
@@ -1768,7 +1808,7 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
         hipLaunchKernelGGL(ba_schur_rhs_kernel, dim3(D.nfree), dim3(64), 0, ctx->stream, D.nfree, st.free_cams.as<int>(),
                            st.cam_start.as<int>(), st.cam_obs.as<int>(), st.obs_lm.as<int>(), st.Yg.as<double>(),
                            st.bl.as<double>(), l0, lc, st.rhs.as<double>());
-      hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
+      hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(gather_grid(st)), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
                          st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(),
                          st.ldS, lower_mode);
     }
@@ -1886,7 +1926,7 @@ int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
                      st.cam_part.as<double>());
   hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.cb_seg, 1,
                      st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
-  hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
+  hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(gather_grid(st)), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
                      st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(), st.ldS,
                      st.banded ? 2 : (D.n > 128 ? 1 : 0));  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
   hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,

@@ -1181,40 +1181,71 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
   // fetched into registers TWO PANELS AHEAD (round 4): as loads at the top of a panel step they were two exposed global
   // round trips on a chain of seven dependent steps, and one step of two small matrix products is shorter than a round
   // trip.  Three barriers per step, both products on the matrix unit.
+  // (thread = column pair c2 = tid & 127 of the rows 2 u + (tid >> 7): sixteen 16-byte loads, not thirty-two of 8)
+  const int c2 = tid & 127, rh = tid >> 7;
   auto fetch = [&](int pn, double (&lv)[32], double (&li)[4]) {
     if (pn >= B) return;
+    const double* src = L + (size_t)(pn + rh) * B + 2 * c2;
 #pragma unroll
-    for (int u = 0; u < 32; u++) lv[u] = tid < pn ? L[(size_t)(pn + u) * B + tid] : 0.0;
+    for (int u = 0; u < 16; u++) {
+      const double2 v = 2 * c2 < pn ? *(const double2*)(src + (size_t)(2 * u) * B) : make_double2(0.0, 0.0);
+      lv[2 * u] = v.x;
+      lv[2 * u + 1] = v.y;
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) li[u] = Li[(size_t)(pn >> 5) * 1024 + tid + 256 * u];
   };
+#ifdef BCR_TIMING
+  long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt = __builtin_amdgcn_s_memtime();
+#define TRS_STAMP(q) { const long long t2 = __builtin_amdgcn_s_memtime(); tq[q] += t2 - tt; tt = t2; }
+#else
+#define TRS_STAMP(q)
+#endif
   auto step = [&](int p0, double (&lv)[32], double (&li)[4]) {
-    if (tid < p0) {
+    TRS_STAMP(0)
+    if (2 * c2 < p0) {
 #pragma unroll
-      for (int u = 0; u < 32; u++) Lp[u * (B + 1) + tid] = lv[u];
+      for (int u = 0; u < 16; u++) {
+        Lp[(2 * u + rh) * (B + 1) + 2 * c2] = lv[2 * u];
+        Lp[(2 * u + rh) * (B + 1) + 2 * c2 + 1] = lv[2 * u + 1];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int idx = tid + 256 * u;
       Ls[(idx >> 5) * 33 + (idx & 31)] = li[u];
     }
+    TRS_STAMP(1)
     __syncthreads();
+    TRS_STAMP(2)
     fetch(p0 + 64, lv, li);
+    TRS_STAMP(3)
     {  // T_p = R_p - L[p, 0:p0] U[0:p0]: one 16 x 16 tile per wavefront on the matrix unit (two chains); as four rows
        // per thread on the vector ALU this product was LDS-bound (five LDS reads per four multiply-adds)
       v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
       const double* lrow = Lp + (16 * ti + l16) * (B + 1) + kq;
       const double* ucol = Us + kq * 33 + 16 * tj + l16;
-      int k0 = 0;
-      for (; k0 + 8 <= p0; k0 += 8) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[k0], ucol[k0 * 33], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[k0 + 4], ucol[(k0 + 4) * 33], acc2, 0, 0, 0);
+      // (p0 is a multiple of 32: eight k-steps per round, their sixteen LDS operand reads issued together -- read
+      // one step at a time, every matrix instruction waited for an LDS round trip: 28k of the kernel's 60k cycles)
+      for (int k0 = 0; k0 < p0; k0 += 32) {
+        double la[8], ub[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          la[u] = lrow[k0 + 4 * u];
+          ub[u] = ucol[(k0 + 4 * u) * 33];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[u], ub[u], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[u + 1], ub[u + 1], acc2, 0, 0, 0);
+        }
       }
-      for (; k0 < p0; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lrow[k0], ucol[k0 * 33], acc, 0, 0, 0);
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) Us[(p0 + 16 * ti + kq + 4 * qq) * 33 + 16 * tj + l16] -= acc[qq] + acc2[qq];
     }
+    TRS_STAMP(4)
     __syncthreads();
+    TRS_STAMP(5)
     {  // the 32 x 32 diagonal part: U_p = Linv_pp T_p, the same tile of the same wavefront
       v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
       const double* arow = Ls + (16 * ti + l16) * 33 + kq;
@@ -1228,6 +1259,7 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) Us[(p0 + 16 * ti + kq + 4 * qq) * 33 + 16 * tj + l16] = acc[qq] + acc2[qq];
     }
+    TRS_STAMP(6)
   };
   double lvA[32], liA[4], lvB[32], liB[4];
 #pragma unroll
@@ -1240,6 +1272,12 @@ __global__ __launch_bounds__(256) void bcr_trsm_kernel(const BcrJob* __restrict_
     if (p0 + 32 < B) step(p0 + 32, lvB, liB);
   }
   __syncthreads();
+  TRS_STAMP(7)
+#ifdef BCR_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    printf("bcr_trsm: stage R + prefetch %lld | lds stores %lld | barrier %lld | fetch issue %lld | product %lld | barrier %lld | diag %lld | tail %lld\n",
+           tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[7]);
+#endif
   for (int r = tid >> 5; r < B; r += 8) Uo[(size_t)r * B + c0 + (tid & 31)] = Us[r * 33 + (tid & 31)];
   // right-hand side of the neighbour: (U^T z_e) for these 32 columns, accumulated in the neighbour's pending slot
   // (slot 1 of p: written by the eliminated block below it; slot 0 of q: by the one above; one writer per level)
@@ -1326,9 +1364,8 @@ __global__ __launch_bounds__(256) void bcr_gemm_kernel(const BcrJob* __restrict_
 // D_p updates and new couplings, then the D_q updates, because D_p of one job is D_q of the job above it -- kept for A/B
 // builds under BCR_GEMM_TARGETS 0).  A target is a remaining diagonal block with its one or two updates
 // D_x -= U1(b)^T U1(b) + U2(a)^T U2(a) (lower 32 x 32 tiles only) or a new coupling K(q, p) = -U2^T U1 (all tiles); the sum
-// over the two contributions runs in a fixed order.  One wavefront per 16 x 16 tile of the target on
-// v_mfma_f64_16x16x4_f64, operands straight from the row-major U blocks (a k-row of 16 consecutive doubles per
-// 16 lanes), two batches of sixteen loads in flight per wavefront and no LDS: the 32 x 32-per-workgroup form staged two 224 x 32 slabs
+// over the two contributions runs in a fixed order.  16 x 16 tiles of the target on v_mfma_f64_16x16x4_f64, operands
+// straight from the row-major U blocks (a k-row of 16 consecutive doubles per 16 lanes), no operand staging in LDS: the 32 x 32-per-workgroup form staged two 224 x 32 slabs
 // (114 KB: one workgroup per compute unit) and spent five LDS reads per four multiply-adds of a 2 x 2 register patch.
 struct BcrTarget {
   int c_is_k, c_idx;  // destination: Knext[c_idx] (assigned) or D[c_idx] (updated, lower tiles)
@@ -1340,69 +1377,63 @@ struct BcrTarget {
 #ifndef BCR_GEMM_TARGETS
 #define BCR_GEMM_TARGETS 1
 #endif
-#define BCR_GT_KU 8  // k-steps (of 4) per load batch: 16 loads in flight per lane, two batches deep
-
-// one batch of operands: k-rows k0 + 4 u + kq of the two slabs (16 consecutive doubles per 16 lanes)
-__device__ __forceinline__ void bcr_gt_load(const double* __restrict__ Mp, const double* __restrict__ Np, int B, int k0,
-                                            double (&av)[BCR_GT_KU], double (&bv)[BCR_GT_KU]) {
-#pragma unroll
-  for (int u = 0; u < BCR_GT_KU; u++) {
-    const size_t off = (size_t)(k0 + 4 * u) * B;
-    av[u] = Mp[off];
-    bv[u] = Np[off];
-  }
-}
-
+// workgroup = one 16 x 16 tile, the inner dimension split over its four wavefronts (a wavefront's share of one product
+// is B / 16 <= 16 matrix instructions, all of its operand loads -- both products -- issued before the first of them: ONE
+// exposed round trip; with the whole inner dimension per wavefront the loads of a batch took longer than its eight
+// matrix instructions however far ahead they were issued, and the deepest levels -- one to three jobs -- ran as long as
+// level 0); the four partial tiles are summed in wavefront order through LDS.
 __global__ __launch_bounds__(256) void bcr_gemm_targets_kernel(const BcrTarget* __restrict__ targets, int B,
                                                                const double* __restrict__ U, double* __restrict__ D,
                                                                double* __restrict__ Knext, const int* __restrict__ ok) {
   if (!*ok) return;
+  __shared__ double red[4][256];
   const BcrTarget tg = targets[blockIdx.x];
   const int tiles = B / 16, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // one wavefront per 16 x 16 tile (a wavefront's chain is B / 4 or B / 2 dependent matrix instructions: with 32 x 32
-  // per wavefront the deepest levels -- one to three jobs -- ran as long as level 0); workgroup = 2 x 2 tiles, so the two
-  // waves of a tile row share the M rows in the L1, of a tile column the N rows
-  const int wt = (tiles + 1) / 2;
-  const int ti = 2 * (blockIdx.y / wt) + (wave >> 1), tj = 2 * (blockIdx.y % wt) + (wave & 1);
-  if (ti >= tiles || tj >= tiles) return;
+  const int ti = blockIdx.y / tiles, tj = blockIdx.y - ti * tiles;
   if (!tg.c_is_k && tj > ti) return;
   const size_t BB = (size_t)B * B;
   const int kq = lane >> 4, l16 = lane & 15;
   const int i0 = 16 * ti, j0 = 16 * tj;
-  v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  const int ks = B / 16;  // k-steps (of 4) per wavefront: 14 at B = 224, 16 at B = 256
+  constexpr int KS_MAX = BCR_MAXB / 16;
+  const size_t krow = (size_t)(wave * (B / 4) + kq) * B;
+  double av[2][KS_MAX], bv[2][KS_MAX];
+#pragma unroll
   for (int pass = 0; pass < 2; pass++) {
     const int ms = pass ? tg.m2 : tg.m1, ns = pass ? tg.n2 : tg.n1;
-    if (ms < 0) break;
-    const double* Mp = U + (size_t)ms * BB + (size_t)kq * B + i0 + l16;
-    const double* Np = U + (size_t)ns * BB + (size_t)kq * B + j0 + l16;
-    // B is a multiple of 32 = one batch; the next batch's loads are issued before this batch's products
-    double a0[BCR_GT_KU], b0[BCR_GT_KU], a1[BCR_GT_KU], b1[BCR_GT_KU];
-    bcr_gt_load(Mp, Np, B, 0, a0, b0);
-    for (int k0 = 0; k0 < B; k0 += 8 * BCR_GT_KU) {
-      const bool more1 = k0 + 4 * BCR_GT_KU < B, more2 = k0 + 8 * BCR_GT_KU < B;
-      if (more1) bcr_gt_load(Mp, Np, B, k0 + 4 * BCR_GT_KU, a1, b1);
+    const double* Mp = U + (size_t)(ms < 0 ? 0 : ms) * BB + krow + i0 + l16;
+    const double* Np = U + (size_t)(ns < 0 ? 0 : ns) * BB + krow + j0 + l16;
 #pragma unroll
-      for (int u = 0; u < BCR_GT_KU; u += 2) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u + 1], b0[u + 1], acc2, 0, 0, 0);
-      }
-      if (!more1) break;
-      if (more2) bcr_gt_load(Mp, Np, B, k0 + 8 * BCR_GT_KU, a0, b0);
+    for (int u = 0; u < KS_MAX; u++) {
+      const bool in = ms >= 0 && u < ks;
+      av[pass][u] = in ? Mp[(size_t)(4 * u) * B] : 0.0;
+      bv[pass][u] = in ? Np[(size_t)(4 * u) * B] : 0.0;
+    }
+  }
+  v4d_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int u = 0; u < BCR_GT_KU; u += 2) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u + 1], b1[u + 1], acc2, 0, 0, 0);
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass && tg.m2 < 0) break;
+#pragma unroll
+    for (int u = 0; u < KS_MAX; u += 2) {
+      if (u < ks) {  // (ks is even)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pass][u], bv[pass][u], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[pass][u + 1], bv[pass][u + 1], acc2, 0, 0, 0);
       }
     }
   }
-  double* C = tg.c_is_k ? Knext + (size_t)tg.c_idx * BB : D + (size_t)tg.c_idx * BB;
 #pragma unroll
-  for (int qq = 0; qq < 4; qq++) {
-    double* c = C + (size_t)(i0 + kq + 4 * qq) * B + j0 + l16;
+  for (int qq = 0; qq < 4; qq++) red[wave][64 * qq + lane] = acc[qq] + acc2[qq];
+  __syncthreads();
+  {
+    const int t = threadIdx.x, qq = t >> 6, l = t & 63;
+    const double v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    double* C = tg.c_is_k ? Knext + (size_t)tg.c_idx * BB : D + (size_t)tg.c_idx * BB;
+    double* c = C + (size_t)(i0 + (l >> 4) + 4 * qq) * B + j0 + (l & 15);
     if (tg.c_is_k)
-      *c = -(acc[qq] + acc2[qq]);
+      *c = -v;
     else
-      *c -= acc[qq] + acc2[qq];  // (entries above the diagonal of a diagonal tile are never read)
+      *c -= v;  // (entries above the diagonal of a diagonal tile are never read)
   }
 }
 
@@ -1652,8 +1683,8 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     hipLaunchKernelGGL(bcr_trsm_kernel, dim3(nj, 2 * tiles), dim3(256), 0, q, jl, B, D, Linv, Kl, U, yy, pend, ok_dev);
 #if BCR_GEMM_TARGETS
     {
-      const int wt = (B / 16 + 1) / 2;
-      hipLaunchKernelGGL(bcr_gemm_targets_kernel, dim3((unsigned)targets[l].size(), wt * wt), dim3(256), 0, q,
+      const int t16 = B / 16;
+      hipLaunchKernelGGL(bcr_gemm_targets_kernel, dim3((unsigned)targets[l].size(), t16 * t16), dim3(256), 0, q,
                          targets_dev + tgt_off[l], B, U, D, Kn, ok_dev);
     }
 #else
