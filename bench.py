@@ -851,7 +851,8 @@ def main():
             stg_g = ctx.stage_ms()
             ctx.set_profiling(0)
             g_iters = max(sgp.iterations, 1)
-            g_dev = {k: round(stg_g[k][0] / g_iters, 4) for k in ("ba_linearize", "ba_schur", "ba_solve") if stg_g.get(k, (0, 0))[1] > 0}
+            g_dev = {k: round(stg_g[k][0] / g_iters, 4) for k in ("ba_linearize", "ba_schur", "ba_solve", "ba_step")
+                     if stg_g.get(k, (0, 0))[1] > 0}
             out["global_ba"] = {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d; "
                                             "session API, 1 rank" % (len(dg["poses"]), int(dg["cam_fixed"].sum()), len(dg["points"]),
                                                                      len(dg["obs_cam"]), 6 * int((dg["cam_fixed"] == 0).sum()),
@@ -871,14 +872,15 @@ def main():
                 tr_iter_g, _, tr_src_g = ba_traffic("global", set())
                 ach_g = alg_g / (it_ms_g * 1e-3) / 1e9
                 out["global_ba"]["roofline"] = {
-                    "bound": "hbm", "kernel": {"ba_linearize": "ba_linearize_kernel + per-camera blocks",
-                                               "ba_schur": "ba_schur_prep / gather / rhs kernels",
-                                               "ba_solve": "block-cyclic-reduction band Cholesky (bcr_* kernels) + back-substitution"}[dom_g],
+                    "bound": "hbm", "kernel": {"ba_linearize": "bal_prep / bal_cam kernels, Jacobi-scaling pass (once per solve)",
+                                               "ba_schur": "bal_prep / bal_cam / ba_schur_gather kernels (recompute form, ba_large.h)",
+                                               "ba_solve": "block-cyclic-reduction band Cholesky (bcr_* kernels) + back-substitution",
+                                               "ba_step": "bal_pose / bal_step kernels"}[dom_g],
                     "achieved": round(ach_g, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_g / HBM_PEAK_GBS, 5),
                     "traffic": tr_iter_g, "traffic_source": tr_src_g, "algorithmic_bytes_per_launch": int(alg_g),
                     "avg_launch_ms": round(it_ms_g, 4),
-                    "launch_is": "one LM iteration (a chain of ~40 kernels; the dominant stage is named in `kernel`, its device "
-                                 "time in device_ms_per_iteration)",
+                    "launch_is": "one LM iteration (a chain of ~55 kernels, ONE host round trip; the dominant stage is named in "
+                                 "`kernel`, its device time in device_ms_per_iteration)",
                     "algorithmic_bytes_are": "SURVEY 8(d) with S in band storage: 24 B per observation + 24 B per landmark + "
                                              "56 B per camera + 128 in; %d doubles of S + rhs + 96 B per landmark out" % s_doubles,
                     "note": "latency- and fp64-compute-bound, not bandwidth-bound: the solve is log2(n / B) dependent levels of "

@@ -1285,6 +1285,7 @@ struct BaState {
   BaDims D;
   int G = 1, lm_per_wg = 1, nb_obs = 1, nb_upd = 1;
   int cb_seg = 1;  // workgroups per free camera in ba_cam_block_kernel
+  int bl_seg = 1;  // ... in bal_cam_kernel (recompute form: an observation is a chain of dependent gathers, one per thread)
   bool small = true;
   std::vector<int> perm;  // sorted position -> caller observation index
   DevBuf poses, cand_poses, points, cand_points, intr, cam_intr, cam_free, free_cams, obs_cam, obs_lm, obs_uv, lm_start,
@@ -1298,7 +1299,7 @@ struct BaState {
   // first use for the landmark range they cover, and the per-observation W / Y blocks of the current linearisation
   DevBuf pair_cnt, pair_start, pairs, Wg, Yg, cam_pos;
   // recompute form of a session's iteration (ba_large.h): landmark runs of the workgroups, their partial sums
-  DevBuf wg_lm, lpart;
+  DevBuf wg_lm, lpart, pbs;  // pbs[3 l + x] = scale_l (P^-1 b)_l: what the reduced right-hand side needs of a landmark
   int n_wg = 0;
   bool large_fused = false;
   int n_slots = 0, hbp1 = 0;
@@ -1610,6 +1611,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   const size_t n = (size_t)D.n, L = (size_t)D.L, O = (size_t)D.O, C = (size_t)D.C;
   // enough workgroups per camera that a camera's observations are ~2 slices of 256 per workgroup (1 when cameras are many)
   st.cb_seg = D.nfree > 0 ? std::max(1, std::min(32, (int)(D.O / std::max(1, D.nfree) / 512))) : 1;
+  st.bl_seg = st.cb_seg;  // (one workgroup per 256 observations of a camera measured 121 us against 80: more gathers in flight than the L2 holds)
   struct Want { DevBuf* b; size_t bytes; };
   std::vector<Want> want = {
       {&st.poses, 8 * 7 * C}, {&st.points, 8 * 3 * L}, {&st.intr, 8 * 16}, {&st.cam_intr, 4 * C}, {&st.cam_free, 4 * C},
@@ -1617,7 +1619,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       {&st.lm_start, 4 * (L + 1)}, {&st.cam_start, 4 * (C + 1)}, {&st.cam_obs, 4 * O},
       {&st.cand_poses, 8 * 7 * C}, {&st.cand_points, 8 * 3 * L}, {&st.r, 16 * O}, {&st.F, 96 * O}, {&st.E, 48 * O},
       {&st.scale_c, 8 * n}, {&st.scale_l, 24 * L}, {&st.n2l, 24 * L}, {&st.grad_l, 24 * L},
-      {&st.cam_part, 8 * 33 * (size_t)std::max(1, D.nfree) * st.cb_seg}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
+      {&st.cam_part, 8 * 33 * (size_t)std::max(1, D.nfree) * std::max(st.cb_seg, st.bl_seg)}, {&st.H, 8 * 36 * (size_t)D.nfree}, {&st.g_c, 8 * n},
       {&st.diag_c, 8 * n}, {&st.diag_l, 24 * L}, {&st.gabs, 8 * (n + 3 * L)}, {&st.S, 8 * st.s_elems}, {&st.rhs, 8 * n},
       {&st.Pinv, 72 * L}, {&st.bl, 24 * L}, {&st.dc, 8 * n}, {&st.dl, 24 * L},
       {&st.partials, 8 * (size_t)(2 * std::max(st.nb_obs, st.nb_upd) + 16)}, {&st.scalars, 8 * 16 + sizeof(int) * 4}};
@@ -1637,6 +1639,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     want.push_back({&st.Yg, 8 * 18 * O});
     want.push_back({&st.wg_lm, 4 * ((size_t)st.n_wg + 1)});
     want.push_back({&st.lpart, 8 * 4 * (size_t)std::max(1, st.n_wg)});
+    want.push_back({&st.pbs, 24 * L});
   }
   if (st.want_alt_set) {
     const Want alt[] = {{&st.r2, 16 * O}, {&st.F2, 96 * O}, {&st.E2, 48 * O}, {&st.n2l2, 24 * L}, {&st.grad_l2, 24 * L},
@@ -1894,14 +1897,13 @@ int bal_init_pass(vsl_ctx* ctx, BaState& st) {
   VslStage s(ctx, VSL_STAGE_BA_LIN);
   const BlArgs a = bal_args(st);
   hipLaunchKernelGGL(bal_prep_kernel<true>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, (const int*)nullptr, 0.0,
-                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, st.n2l.as<double>(),
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, st.n2l.as<double>(),
                      st.lpart.as<double>());
   hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
                      st.scalars.as<double>(), (double*)nullptr);
-  hipLaunchKernelGGL(bal_cam_kernel<true>, dim3(D.nfree, st.cb_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
-                     st.cam_start.as<int>(), st.cam_obs.as<int>(), (const double*)nullptr, (const double*)nullptr,
-                     st.cam_part.as<double>());
-  hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.cb_seg, 0,
+  hipLaunchKernelGGL(bal_cam_kernel<true>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
+                     st.cam_start.as<int>(), st.cam_obs.as<int>(), (const double*)nullptr, st.cam_part.as<double>());
+  hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 0,
                      st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
@@ -1918,13 +1920,12 @@ int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
   if (rc) return rc;
   hipLaunchKernelGGL(bal_prep_kernel<false>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, st.cam_pos.as<int>(),
                      1.0 / radius, st.Wg.as<double>(), st.Yg.as<double>(), st.Pinv.as<double>(), st.bl.as<double>(),
-                     (double*)nullptr, st.lpart.as<double>());
+                     st.pbs.as<double>(), (double*)nullptr, st.lpart.as<double>());
   hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
                      st.scalars.as<double>(), gl_out);
-  hipLaunchKernelGGL(bal_cam_kernel<false>, dim3(D.nfree, st.cb_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
-                     st.cam_start.as<int>(), st.cam_obs.as<int>(), st.Yg.as<double>(), st.bl.as<double>(),
-                     st.cam_part.as<double>());
-  hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.cb_seg, 1,
+  hipLaunchKernelGGL(bal_cam_kernel<false>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
+                     st.cam_start.as<int>(), st.cam_obs.as<int>(), st.pbs.as<double>(), st.cam_part.as<double>());
+  hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 1,
                      st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
   hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(gather_grid(st)), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
                      st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(), st.ldS,

@@ -98,7 +98,8 @@ template <bool INIT>
 __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const int* __restrict__ cam_pos, double inv_radius,
                                                               double* __restrict__ Wg, double* __restrict__ Yg,
                                                               double* __restrict__ Pinv, double* __restrict__ bl,
-                                                              double* __restrict__ n2l_out, double* __restrict__ part) {
+                                                              double* __restrict__ pbs, double* __restrict__ n2l_out,
+                                                              double* __restrict__ part) {
   __shared__ double stage_s[BL_THREADS * 9];  // E^T E (6) | E^T r (3) per observation
   __shared__ double pi_s[BL_LMW * 9];
   __shared__ double pts_s[BL_LMW * 3];
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const in
 #pragma unroll
       for (int x = 0; x < 3; x++) {
         bl[3 * l + x] = ok ? bb[x] : 0.0;
+        // (P^-1 b) in the scale of the UNSCALED landmark block: the camera kernel multiplies it with E sqrt(rho')
+        pbs[3 * l + x] = (Pi[3 * x] * bb[0] + Pi[3 * x + 1] * bb[1] + Pi[3 * x + 2] * bb[2]) * scl_s[3 * tid + x];
         gl = fmax(gl, fabs(bb[x] / scl_s[3 * tid + x]));
       }
     }
@@ -191,23 +194,43 @@ __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const in
     if (lane == 0) red_s[1][wave] = gm;
   }
   __syncthreads();
-  if (!INIT && have && o.fc >= 0) {
-    const double* Pi = pi_s + 9 * lml;
-    const size_t at = 18 * (size_t)cam_pos[q];
-    double2* wq = (double2*)(Wg + at);
-    double2* yq = (double2*)(Yg + at);
+  if (!INIT) {
+    // W = F^T E and Y = W P^-1 of the free observations, stored COOPERATIVELY: a lane's own 144-byte block as nine 16-byte
+    // stores is 64 different cache lines per store instruction (the same one-line-per-cycle limit that bounded the
+    // gather's loads); instead the blocks of 32 lanes go through the wavefront's 4.6 KB of the (now dead) staging
+    // area as 288 pieces of 16 bytes, piece m of block m / 9, and nine consecutive lanes store one contiguous block.
+    const bool is_free = have && o.fc >= 0;
     double w[18], y[18];
+    if (is_free) {
+      const double* Pi = pi_s + 9 * lml;
 #pragma unroll
-    for (int x = 0; x < 6; x++) {
+      for (int x = 0; x < 6; x++) {
 #pragma unroll
-      for (int z = 0; z < 3; z++) w[3 * x + z] = o.F[x] * o.E[z] + o.F[6 + x] * o.E[3 + z];
+        for (int z = 0; z < 3; z++) w[3 * x + z] = o.F[x] * o.E[z] + o.F[6 + x] * o.E[3 + z];
 #pragma unroll
-      for (int z = 0; z < 3; z++) y[3 * x + z] = w[3 * x] * Pi[z] + w[3 * x + 1] * Pi[3 + z] + w[3 * x + 2] * Pi[6 + z];
+        for (int z = 0; z < 3; z++) y[3 * x + z] = w[3 * x] * Pi[z] + w[3 * x + 1] * Pi[3 + z] + w[3 * x + 2] * Pi[6 + z];
+      }
     }
+    const int pos = is_free ? cam_pos[q] : -1;
+    double2* region = (double2*)stage_s + (size_t)wave * (BL_THREADS * 9 / 2 / BL_WAVES);  // 288 double2 per wavefront
+    static_assert(BL_THREADS * 9 / 2 / BL_WAVES == 288, "32 blocks of 9 pieces per wavefront and round");
 #pragma unroll
-    for (int x = 0; x < 9; x++) {
-      wq[x] = make_double2(w[2 * x], w[2 * x + 1]);
-      yq[x] = make_double2(y[2 * x], y[2 * x + 1]);
+    for (int round = 0; round < 4; round++) {
+      const int half = round & 1;
+      const double* v = round < 2 ? w : y;
+      double* dst = round < 2 ? Wg : Yg;
+      __syncthreads();  // (the staging area: dead since the landmark sums / the previous round's pieces are out)
+      if (is_free && (lane >> 5) == half) {
+#pragma unroll
+        for (int x = 0; x < 9; x++) region[9 * (lane & 31) + x] = make_double2(v[2 * x], v[2 * x + 1]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 5; t++) {
+        const int m = 64 * t + lane, b = m < 288 ? m / 9 : 0, part = m - 9 * b;
+        const int bpos = __shfl(pos, 32 * half + b);
+        if (m < 288 && bpos >= 0) *(double2*)(dst + 18 * (size_t)bpos + 2 * part) = region[m];
+      }
     }
   }
   if (tid == 0) {
@@ -247,13 +270,14 @@ __global__ __launch_bounds__(256) void bal_prep_finish_kernel(int G, const doubl
 }
 
 // per free camera (grid = (free cameras, segments), like ba_cam_block_kernel): 21 entries of the upper triangle of
-// H = sum F^T F, g = sum F^T r and -- when Yg / bl are given -- sum over the camera's observations of Y b, evaluated
-// from the observations of the camera's list; part[(fc * nseg + seg) * 33 + e].
+// H = sum F^T F, g = sum F^T r and the landmark part of the reduced right-hand side, sum over the camera's observations
+// of Y b = F^T (E (P^-1 b)) -- from the landmark's 24 bytes pbs, not from the observation's 144-byte Y block (whose 16-byte
+// loads touch 64 cache lines per instruction: 80 -> 57 us) --, evaluated from the observations of the camera's list;
+// part[(fc * nseg + seg) * 33 + e].
 template <bool INIT>
 __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __restrict__ free_cams,
                                                       const int* __restrict__ cam_start, const int* __restrict__ cam_obs,
-                                                      const double* __restrict__ Yg, const double* __restrict__ bl,
-                                                      double* __restrict__ part) {
+                                                      const double* __restrict__ pbs, double* __restrict__ part) {
   constexpr int NE = INIT ? 27 : 33;
   __shared__ double sh[4][NE];
   const int fc = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __res
     const double pw[3] = {a.points[3 * (size_t)lm], a.points[3 * (size_t)lm + 1], a.points[3 * (size_t)lm + 2]};
     const double one[3] = {1.0, 1.0, 1.0};
     BlObs o;
-    bl_eval<!INIT, true>(a, cam, pw, one, uv, o);  // (E is not used here: its scaling is dead code)
+    bl_eval<!INIT, true>(a, cam, pw, one, uv, o);  // (E robustified, NOT Jacobi-scaled: pbs carries the landmark's scale)
     const double* f = o.F;
     int e = 0;
 #pragma unroll
@@ -278,17 +302,10 @@ __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __res
 #pragma unroll
     for (int x = 0; x < 6; x++) acc[21 + x] += f[x] * o.r[0] + f[6 + x] * o.r[1];
     if (!INIT) {
-      const double2* yq = (const double2*)(Yg + 18 * (size_t)k);
-      double y[18];
+      const double b0 = pbs[3 * (size_t)lm], b1 = pbs[3 * (size_t)lm + 1], b2 = pbs[3 * (size_t)lm + 2];
+      const double u0 = o.E[0] * b0 + o.E[1] * b1 + o.E[2] * b2, u1 = o.E[3] * b0 + o.E[4] * b1 + o.E[5] * b2;
 #pragma unroll
-      for (int x = 0; x < 9; x++) {
-        const double2 v = yq[x];
-        y[2 * x] = v.x;
-        y[2 * x + 1] = v.y;
-      }
-      const double b0 = bl[3 * (size_t)lm], b1 = bl[3 * (size_t)lm + 1], b2 = bl[3 * (size_t)lm + 2];
-#pragma unroll
-      for (int x = 0; x < 6; x++) acc[27 + x] += y[3 * x] * b0 + y[3 * x + 1] * b1 + y[3 * x + 2] * b2;
+      for (int x = 0; x < 6; x++) acc[27 + x] += f[x] * u0 + f[6 + x] * u1;
     }
   }
 #pragma unroll
