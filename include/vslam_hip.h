@@ -381,6 +381,10 @@ int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba
 int vsl_ba_session_destroy(vsl_ba_session* s);
 /* n = 6 * free cameras; owned landmarks / observations; cameras. */
 int vsl_ba_session_dims(const vsl_ba_session* s, int* n, int* n_lms_own, int* n_obs_own, int* n_cams);
+/* use_scale = 0: the Jacobi-scaling pass (column norms, cost); 1: after an accepted step.  Large systems run in the
+ * recompute form (visual-slam_amd/csrc/ba_large.h: nothing is stored per observation) -- there the call with
+ * use_scale = 1 has nothing to do, vsl_ba_session_reduce_dev evaluates the observations at the current point itself.
+ * Diagnostic "ba_no_fused" / VSL_BA_NO_FUSED: the chain over stored residual / Jacobian blocks instead. */
 int vsl_ba_session_linearize(vsl_ba_session* s, int use_scale);
 /* out_dev[n + 1] = [diag(H_part) | cost_part] */
 int vsl_ba_session_hdiag_cost_dev(vsl_ba_session* s, double* out_dev);
