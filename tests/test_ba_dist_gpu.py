@@ -238,3 +238,55 @@ def test_bench_gpus_2_runs_the_global_ba_all_reduce_leg():
     assert g["final_cost_rel_diff_vs_world1"] <= 1e-9
     assert g["max_pose_diff_vs_world1"] <= 1e-7
     assert g["ms_per_lm_iteration_marginal"] > 0
+
+
+def _session_solve(vsl, synth, d, no_fused, max_iters=8):
+    import torch
+    ba_dist = importlib.import_module("visual_slam_amd.ba_dist")
+    ctx = vsl.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    if no_fused:
+        ctx.set_diagnostic("ba_no_fused", 1)
+    a = vsl.BaArrays.from_dict(d)
+    s = ba_dist.bundle_adjust_distributed(vsl, ctx, a, max_iters=max_iters)
+    ctx.close()
+    return s, a
+
+
+def test_recompute_form_matches_the_stored_blocks_form(vsl, synth):
+    """The session iteration that evaluates observations on the fly (ba_large.h) against the chain over stored
+    r / F / E blocks ("ba_no_fused"): the same LM trajectory, the same optimum; and a solve is reproducible bit for bit."""
+    d = _problem(synth)
+    s_new, a_new = _session_solve(vsl, synth, d, False)
+    s_old, a_old = _session_solve(vsl, synth, d, True)
+    assert (s_new.iterations, s_new.termination, s_new.successful_steps) == (s_old.iterations, s_old.termination, s_old.successful_steps)
+    assert s_new.initial_cost == pytest.approx(s_old.initial_cost, rel=1e-12)
+    assert s_new.final_cost == pytest.approx(s_old.final_cost, rel=1e-9)
+    assert np.allclose(a_new.poses, a_old.poses, rtol=0, atol=1e-7)
+    dp = np.abs(a_new.points - a_old.points).max(1)
+    assert (dp < 1e-6).mean() > 0.97 and dp.max() < 0.05
+    s_again, a_again = _session_solve(vsl, synth, d, False)
+    assert s_again.final_cost == s_new.final_cost
+    assert np.array_equal(a_again.poses, a_new.poses) and np.array_equal(a_again.points, a_new.points)
+
+
+def test_a_landmark_with_more_observations_than_a_workgroup_takes_the_stored_blocks_form(vsl, orc, synth):
+    """The recompute-form kernels give a landmark's observations one thread each of a 512-thread workgroup; a landmark
+    observed more often than that (here: its observations repeated) must fall back to the stored-blocks chain, not fail."""
+    d = dict(_problem(synth))
+    lm = int(np.bincount(d["obs_lm"]).argmax())
+    idx = np.nonzero(d["obs_lm"] == lm)[0]
+    reps = 520 // len(idx) + 1
+    extra = np.tile(idx, reps)
+    for k in ("obs_cam", "obs_lm", "obs_uv"):
+        d[k] = np.ascontiguousarray(np.concatenate([d[k], d[k][extra]]))
+    assert (d["obs_lm"] == lm).sum() > 512
+    s_def, a_def = _session_solve(vsl, synth, d, False, max_iters=5)
+    s_old, a_old = _session_solve(vsl, synth, d, True, max_iters=5)
+    # the same kernels ran both times (equal up to the summation order of pair lists longer than PAIR_SORT_MAX, which
+    # the repeated observations produce here: those keep their fill order, ba.hip ba_pair_sort_kernel)
+    assert s_def.final_cost == pytest.approx(s_old.final_cost, rel=1e-12)
+    assert np.allclose(a_def.poses, a_old.poses, rtol=0, atol=1e-11)
+    a_cpu = _arr(orc, d)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=5)
+    assert (s_def.iterations, s_def.termination) == (s_cpu.iterations, s_cpu.termination)
+    assert s_def.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)

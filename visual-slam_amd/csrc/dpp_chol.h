@@ -39,11 +39,13 @@ struct CsCol {
                                              double pjp = 0.0) {
     const double dj = cs_bcast<J>(d[J]);
     if (!(dj > 0.0) || !isfinite(dj)) good = false;
-    // 1 / sqrt by the hardware estimate and two Newton steps (an IEEE sqrt + divide is ~200 dependent instructions)
+    // 1 / sqrt by the hardware estimate (2^-23 relative) and two Newton steps (an IEEE sqrt + divide is ~200 dependent
+    // instructions); a step is three dependent operations -- iv^2, fma(-dj / 2, iv^2, 3/2), product -- not four
     double iv = __builtin_amdgcn_rsq(dj);
+    const double hj = 0.5 * dj;
     if constexpr (J > 0) upd<J - 1, J + 1>(d, p, ljp, pjp);
-    iv = iv * (1.5 - 0.5 * dj * iv * iv);
-    iv = iv * (1.5 - 0.5 * dj * iv * iv);
+    iv = iv * fma(-hj, iv * iv, 1.5);
+    iv = iv * fma(-hj, iv * iv, 1.5);
     if (inv_out) inv_out[J] = iv;  // (lane J of wavefront 0 only: the pointer is null elsewhere)
     const double lj = d[J] * iv;  // lane J: sqrt(pivot); lanes below: l(i, J)
     const double pj = p[J] * iv;
