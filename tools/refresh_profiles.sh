@@ -42,7 +42,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS --output-format csv -d $O/mm3 -- python3 $R/tools/match_probe.py match_use_i8=1 > $O/mm3.log 2>&1
 # bundle adjustment: kernel durations of the local window and of the 1000-camera map
 echo ba; rocprofv3 --kernel-trace --stats --output-format csv -d $O/lba -- python3 $R/tools/local_ba_probe.py 7 > $O/lba.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/gba -- python3 $R/tools/global_ba_bench.py --iters 8 --single-call > $O/gba.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gba -- python3 $R/tools/global_ba_bench.py --iters 8 > $O/gba.log 2>&1
 # bundle adjustment: HBM traffic of the fused local iteration and of the large-system kernels (separate --pmc passes)
 echo ba_pmc; (cd $R && bash tools/ba_pmc.sh $ROUND > $O/ba_pmc.log 2>&1; cp gpurun_out/${ROUND}_ba_pmc_traffic.json $O/ 2>/dev/null)
 echo refresh done

@@ -1942,7 +1942,7 @@ int bal_step(vsl_ctx* ctx, BaState& st) {
   const BaDims& D = st.D;
   VslStage s(ctx, VSL_STAGE_BA_STEP);
   const BlArgs a = bal_args(st);
-  hipLaunchKernelGGL(bal_pose_kernel, dim3(1), dim3(256), 0, ctx->stream, D, st.cam_free.as<int>(), st.poses.as<double>(),
+  hipLaunchKernelGGL(bal_pose_kernel, dim3(1), dim3(1024), 0, ctx->stream, D, st.cam_free.as<int>(), st.poses.as<double>(),
                      st.dc.as<double>(), st.scale_c.as<double>(), st.cand_poses.as<double>(), st.scalars.as<double>(),
                      st.flag.as<int>());
   hipLaunchKernelGGL(bal_step_kernel, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, st.Pinv.as<double>(),
@@ -2572,16 +2572,16 @@ extern "C" int vsl_ba_session_download(vsl_ba_session* s, double* poses, double*
 // Per iteration: SUM of packB (the packed partial reduced camera system, band form when the cameras order into a band:
 // ~20 MB instead of 287 MB at 1000 cameras), MAX of one scalar after an accepted step, SUM of the 8 doubles of packC.
 namespace {
-__global__ __launch_bounds__(256) void sess_gmax_c_kernel(int n, const double* __restrict__ g_c, const double* __restrict__ scale_c,
-                                                          const double* __restrict__ cost_in, const double* __restrict__ gl,
-                                                          double* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sess_gmax_c_kernel(int n, const double* __restrict__ g_c, const double* __restrict__ scale_c,
+                                                           const double* __restrict__ cost_in, const double* __restrict__ gl,
+                                                           double* __restrict__ out) {
   // out[0] = cost (copied), out[1] = max(max_i |g_c[i] / scale_c[i]|, gl[0])
-  __shared__ double sh[256];
+  __shared__ double sh[1024];
   double m = 0;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(g_c[i] / scale_c[i]));
+  for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, fabs(g_c[i] / scale_c[i]));
   sh[threadIdx.x] = m;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
     __syncthreads();
   }
@@ -2639,7 +2639,7 @@ extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduc
     if ((rc = AR(packB.as<double>(), nB, 0))) return rc;
     if (refresh) {
       if ((rc = AR(gl.as<double>(), 1, 1))) return rc;
-      hipLaunchKernelGGL(sess_gmax_c_kernel, dim3(1), dim3(256), 0, ctx->stream, n, packB.as<double>() + elems + 2 * (size_t)n,
+      hipLaunchKernelGGL(sess_gmax_c_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, packB.as<double>() + elems + 2 * (size_t)n,
                          st.scale_c.as<double>(), packB.as<double>() + elems + 3 * (size_t)n, gl.as<double>(), hostpack);
       VSL_CHECK_LAUNCH(ctx);
       have_h2 = false;  // (cost, |gradient|) of this linearisation: read together with the step's verdict below --

@@ -344,15 +344,15 @@ __global__ void bal_cam_finish_kernel(int nfree, int nseg, int with_rhs, const d
 }
 
 // candidate poses = T exp(dc .* scale_c) (fixed cameras copied); scalars[6] / [7] = squared step / x norm of the free
-// cameras; flag[0] cleared when the camera step is not finite.  One workgroup.
-__global__ __launch_bounds__(256) void bal_pose_kernel(BaDims D, const int* __restrict__ cam_free,
-                                                       const double* __restrict__ poses, const double* __restrict__ dc,
-                                                       const double* __restrict__ scale_c, double* __restrict__ cand_poses,
-                                                       double* __restrict__ scalars, int* __restrict__ flag) {
-  __shared__ double sh[256];
+// cameras; flag[0] cleared when the camera step is not finite.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void bal_pose_kernel(BaDims D, const int* __restrict__ cam_free,
+                                                        const double* __restrict__ poses, const double* __restrict__ dc,
+                                                        const double* __restrict__ scale_c, double* __restrict__ cand_poses,
+                                                        double* __restrict__ scalars, int* __restrict__ flag) {
+  __shared__ double sh[2][16];
   double step2 = 0, x2 = 0;
   bool bad = false;
-  for (int c = threadIdx.x; c < D.C; c += 256) {
+  for (int c = threadIdx.x; c < D.C; c += 1024) {
     const int fc = cam_free[c];
     const double* T = poses + 7 * (size_t)c;
     double* o = cand_poses + 7 * (size_t)c;
@@ -371,12 +371,20 @@ __global__ __launch_bounds__(256) void bal_pose_kernel(BaDims D, const int* __re
     se3_plus(T, d, o);
   }
   if (bad) flag[0] = 0;
-  const double s2 = block_sum_256(step2, sh);
+  const double s2 = bl_wave_sum(step2), xx = bl_wave_sum(x2);  // xor tree, then the 16 wavefronts in order
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = s2;
+    sh[1][threadIdx.x >> 6] = xx;
+  }
   __syncthreads();
-  const double xx = block_sum_256(x2, sh);
   if (threadIdx.x == 0) {
-    scalars[6] = s2;
-    scalars[7] = xx;
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 16; w++) {
+      a += sh[0][w];
+      b += sh[1][w];
+    }
+    scalars[6] = a;
+    scalars[7] = b;
   }
 }
 

@@ -1668,7 +1668,7 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     ctx->bcr_key_bw = bw;
   }
   hipStream_t q = ctx->stream;
-  hipLaunchKernelGGL(bcr_extract_kernel, dim3(16, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, D, K0, bb, pend);
+  hipLaunchKernelGGL(bcr_extract_kernel, dim3(64, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, D, K0, bb, pend);
   const int tiles = B / 32;
   for (size_t l = 0; l < levels.size(); l++) {
     const int nj = (int)levels[l].size();
