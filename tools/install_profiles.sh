@@ -6,11 +6,11 @@ cd "$(dirname "$0")/.."
 R=${1:-r04}
 O=gpurun_out/refresh
 cp $O/bench_line.json profiles/${R}_bench_line.json
-cp $(ls $O/kt1/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_1stream.csv
-cp $(ls $O/kt2/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_2streams.csv
-cp $(ls $O/lba/*/*_kernel_stats.csv | head -1) profiles/${R}_local_ba_kernel_stats.csv
-cp $(ls $O/gba/*/*_kernel_stats.csv | head -1) profiles/${R}_global_ba_kernel_stats.csv
-cp $(ls $O/bow/*/*_kernel_stats.csv | head -1) profiles/${R}_bow_orb_kernel_stats.csv
+cp $(ls -t $O/kt1/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_1stream.csv
+cp $(ls -t $O/kt2/*/*_kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats_2streams.csv
+cp $(ls -t $O/lba/*/*_kernel_stats.csv | head -1) profiles/${R}_local_ba_kernel_stats.csv
+cp $(ls -t $O/gba/*/*_kernel_stats.csv | head -1) profiles/${R}_global_ba_kernel_stats.csv
+cp $(ls -t $O/bow/*/*_kernel_stats.csv | head -1) profiles/${R}_bow_orb_kernel_stats.csv
 cp $O/${R}_e2e_kernel_stats.json $O/${R}_e2e_kernel_stats.csv profiles/
 cp $O/${R}_stages_e2e_kernel_stats.json profiles/${R}_e2e_loop_closing_stages_kernel_stats.json
 cp $O/${R}_stages_e2e_kernel_stats.csv profiles/${R}_e2e_loop_closing_stages_kernel_stats.csv
@@ -19,9 +19,9 @@ python tools/pmc_summary.py $O profiles/${R}_pmc_traffic.json 512
 python tools/sq_summary.py $O profiles/${R}_matcher_sq_counters.json
 python tools/frame_sq_summary.py $O profiles/${R}_frame_sq_counters.json
 python - $R <<'PY'
-import csv, glob, statistics, re, sys
+import csv, glob, os, statistics, re, sys
 R = sys.argv[1]
-f = glob.glob('gpurun_out/refresh/kt1/*/*_kernel_trace.csv')[0]
+f = max(glob.glob('gpurun_out/refresh/kt1/*/*_kernel_trace.csv'), key=os.path.getmtime)
 lines = ["rocprofv3 --kernel-trace of `python3 bench.py --streams 1 --batch 512 --passes 18 --steps 20 --warmup 5 --cpu-frames 0 --no-ba --no-gba --no-e2e --no-bow --stream-seconds 0` (tools/refresh_profiles.sh):",
          "per-launch kernel durations in microseconds, 512 stereo frames = 1024 images per launch; the HIP events of bench.py cover the LAST 5 passes."]
 d = {}

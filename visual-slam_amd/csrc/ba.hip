@@ -1897,7 +1897,7 @@ int bal_init_pass(vsl_ctx* ctx, BaState& st) {
   VslStage s(ctx, VSL_STAGE_BA_LIN);
   const BlArgs a = bal_args(st);
   hipLaunchKernelGGL(bal_prep_kernel<true>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, (const int*)nullptr, 0.0,
-                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, st.n2l.as<double>(),
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, st.n2l.as<double>(),
                      st.lpart.as<double>());
   hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
                      st.scalars.as<double>(), (double*)nullptr);
@@ -1919,8 +1919,8 @@ int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
   int rc = ba_pair_lists(ctx, st, 0, D.L);
   if (rc) return rc;
   hipLaunchKernelGGL(bal_prep_kernel<false>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, st.cam_pos.as<int>(),
-                     1.0 / radius, st.Wg.as<double>(), st.Yg.as<double>(), st.Pinv.as<double>(), st.bl.as<double>(),
-                     st.pbs.as<double>(), (double*)nullptr, st.lpart.as<double>());
+                     1.0 / radius, st.Yg.as<double>(), st.Pinv.as<double>(), st.bl.as<double>(), st.pbs.as<double>(),
+                     (double*)nullptr, st.lpart.as<double>());
   hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
                      st.scalars.as<double>(), gl_out);
   hipLaunchKernelGGL(bal_cam_kernel<false>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
@@ -1928,7 +1928,7 @@ int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
   hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 1,
                      st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
   hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(gather_grid(st)), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
-                     st.pair_start.as<int>(), st.pairs.as<int>(), st.Wg.as<double>(), st.Yg.as<double>(), st.S_eff(), st.ldS,
+                     st.pair_start.as<int>(), st.pairs.as<int>(), st.Yg.as<double>(), st.Yg.as<double>(), st.S_eff(), st.ldS,
                      st.banded ? 2 : (D.n > 128 ? 1 : 0));  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
   hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
                      st.H.as<double>(), st.g_c.as<double>(), (const double*)nullptr, 0.0, st.S_eff(), st.rhs.as<double>(),

@@ -8,10 +8,11 @@
 // needed -- the residual and its two Jacobian blocks cost ~200 fp64 operations, the arrays they replace cost 160 B of
 // HBM traffic per observation and pass:
 //   bal_prep_kernel    workgroup = a run of landmarks (<= BL_THREADS observations), thread = observation:
-//                      P = sum E^T E, b = sum E^T r per landmark, damped P^-1, and per free observation W = F^T E,
-//                      Y = W P^-1 in camera-major order (what ba_schur_gather_kernel reads); cost and max |gradient|.
+//                      P = sum E^T E, b = sum E^T r per landmark, damped P^-1 = L L^T, and per free observation
+//                      Z = F^T E L in camera-major order (ba_schur_gather_kernel reads it on both sides of a pair:
+//                      Y_i W_j^T = Z_i Z_j^T); cost and max |gradient|.
 //   bal_cam_kernel     workgroup = (free camera, segment) over the camera's observation list: H = sum F^T F,
-//                      g = sum F^T r and the landmark part of the reduced right-hand side, -sum Y b.
+//                      g = sum F^T r and the landmark part of the reduced right-hand side, -sum F^T E (P^-1 b).
 //   bal_pose_kernel    candidate poses T exp(d), camera parts of the step / x norms.
 //   bal_step_kernel    same partition as bal_prep: back-substitution dl = -P^-1 (b + sum W^T dc), model cost change,
 //                      candidate points, cost at the candidate.
@@ -92,12 +93,13 @@ __device__ __forceinline__ void bl_eval(const BlArgs& a, int cam, const double* 
 }
 
 // INIT: n2l_out[3 l + x] = squared norm of landmark column x (unscaled), cost partial.  Otherwise: the damped inverse
-// P^-1 and b per landmark (kept for the back-substitution), W / Y per free observation, cost and gradient partials.
+// P^-1 and b per landmark (kept for the back-substitution), Z = F^T E chol(P^-1) per free observation (the gather's
+// block: Y_i W_j^T = Z_i Z_j^T), cost and gradient partials.
 // part[0 * G + g] = cost, part[1 * G + g] = max |gradient| over the workgroup's landmark columns (unscaled problem).
 template <bool INIT>
 __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const int* __restrict__ cam_pos, double inv_radius,
-                                                              double* __restrict__ Wg, double* __restrict__ Yg,
-                                                              double* __restrict__ Pinv, double* __restrict__ bl,
+                                                              double* __restrict__ Zg, double* __restrict__ Pinv,
+                                                              double* __restrict__ bl,
                                                               double* __restrict__ pbs, double* __restrict__ n2l_out,
                                                               double* __restrict__ part) {
   __shared__ double stage_s[BL_THREADS * 9];  // E^T E (6) | E^T r (3) per observation
@@ -173,13 +175,27 @@ __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const in
       P[4] += fmin(fmax(P6[3], 1e-6), 1e32) * inv_radius;
       P[8] += fmin(fmax(P6[5], 1e-6), 1e32) * inv_radius;
       double Pi[9];
-      const bool ok = i1 > i0 && inv3(P, Pi);
+      bool ok = i1 > i0 && inv3(P, Pi);
+      // P^-1 = L L^T (lower Cholesky factor, 3 x 3): the gather forms Y_i W_j^T = (W_i P^-1) W_j^T as Z_i Z_j^T with
+      // Z = W L -- ONE 144-byte block per observation instead of two
+      double L6[6] = {0, 0, 0, 0, 0, 0};  // l00 l10 l11 l20 l21 l22
+      if (ok) {
+        const double l00 = sqrt(Pi[0]), l10 = Pi[3] / l00, l20 = Pi[6] / l00;
+        const double l11 = sqrt(Pi[4] - l10 * l10), l21 = (Pi[7] - l20 * l10) / l11;
+        const double l22 = sqrt(Pi[8] - l20 * l20 - l21 * l21);
+        ok = l00 > 0.0 && l11 > 0.0 && l22 > 0.0 && isfinite(l00) && isfinite(l11) && isfinite(l22) && isfinite(l10) &&
+             isfinite(l20) && isfinite(l21);  // (a P^-1 that is not positive definite in fp64: treated like a singular P)
+        if (ok) {
+          L6[0] = l00; L6[1] = l10; L6[2] = l11; L6[3] = l20; L6[4] = l21; L6[5] = l22;
+        }
+      }
 #pragma unroll
       for (int x = 0; x < 9; x++) {
-        Pi[x] = ok ? Pi[x] : 0.0;  // a singular block contributes nothing (Y = 0) and its landmark does not move
-        pi_s[9 * tid + x] = Pi[x];
+        Pi[x] = ok ? Pi[x] : 0.0;  // a singular block contributes nothing (Z = 0) and its landmark does not move
         Pinv[9 * l + x] = Pi[x];
       }
+#pragma unroll
+      for (int x = 0; x < 6; x++) pi_s[9 * tid + x] = L6[x];
 #pragma unroll
       for (int x = 0; x < 3; x++) {
         bl[3 * l + x] = ok ? bb[x] : 0.0;
@@ -195,41 +211,40 @@ __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const in
   }
   __syncthreads();
   if (!INIT) {
-    // W = F^T E and Y = W P^-1 of the free observations, stored COOPERATIVELY: a lane's own 144-byte block as nine 16-byte
-    // stores is 64 different cache lines per store instruction (the same one-line-per-cycle limit that bounded the
-    // gather's loads); instead the blocks of 32 lanes go through the wavefront's 4.6 KB of the (now dead) staging
-    // area as 288 pieces of 16 bytes, piece m of block m / 9, and nine consecutive lanes store one contiguous block.
+    // Z = F^T E L of the free observations, stored COOPERATIVELY: a lane's own 144-byte block as nine 16-byte stores is
+    // 64 different cache lines per store instruction (the same lines-not-bytes limit that bounded the gather's loads);
+    // instead the blocks of 32 lanes go through the wavefront's 4.6 KB of the (now dead) staging area as 288 pieces of
+    // 16 bytes, piece m of block m / 9, and nine consecutive lanes store one contiguous block.
     const bool is_free = have && o.fc >= 0;
-    double w[18], y[18];
+    double z[18];
     if (is_free) {
-      const double* Pi = pi_s + 9 * lml;
+      const double* Lm = pi_s + 9 * lml;  // l00 l10 l11 l20 l21 l22
 #pragma unroll
       for (int x = 0; x < 6; x++) {
+        double w[3];
 #pragma unroll
-        for (int z = 0; z < 3; z++) w[3 * x + z] = o.F[x] * o.E[z] + o.F[6 + x] * o.E[3 + z];
-#pragma unroll
-        for (int z = 0; z < 3; z++) y[3 * x + z] = w[3 * x] * Pi[z] + w[3 * x + 1] * Pi[3 + z] + w[3 * x + 2] * Pi[6 + z];
+        for (int k = 0; k < 3; k++) w[k] = o.F[x] * o.E[k] + o.F[6 + x] * o.E[3 + k];
+        z[3 * x] = w[0] * Lm[0] + w[1] * Lm[1] + w[2] * Lm[3];
+        z[3 * x + 1] = w[1] * Lm[2] + w[2] * Lm[4];
+        z[3 * x + 2] = w[2] * Lm[5];
       }
     }
     const int pos = is_free ? cam_pos[q] : -1;
     double2* region = (double2*)stage_s + (size_t)wave * (BL_THREADS * 9 / 2 / BL_WAVES);  // 288 double2 per wavefront
     static_assert(BL_THREADS * 9 / 2 / BL_WAVES == 288, "32 blocks of 9 pieces per wavefront and round");
 #pragma unroll
-    for (int round = 0; round < 4; round++) {
-      const int half = round & 1;
-      const double* v = round < 2 ? w : y;
-      double* dst = round < 2 ? Wg : Yg;
+    for (int half = 0; half < 2; half++) {
       __syncthreads();  // (the staging area: dead since the landmark sums / the previous round's pieces are out)
       if (is_free && (lane >> 5) == half) {
 #pragma unroll
-        for (int x = 0; x < 9; x++) region[9 * (lane & 31) + x] = make_double2(v[2 * x], v[2 * x + 1]);
+        for (int x = 0; x < 9; x++) region[9 * (lane & 31) + x] = make_double2(z[2 * x], z[2 * x + 1]);
       }
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < 5; t++) {
         const int m = 64 * t + lane, b = m < 288 ? m / 9 : 0, part = m - 9 * b;
         const int bpos = __shfl(pos, 32 * half + b);
-        if (m < 288 && bpos >= 0) *(double2*)(dst + 18 * (size_t)bpos + 2 * part) = region[m];
+        if (m < 288 && bpos >= 0) *(double2*)(Zg + 18 * (size_t)bpos + 2 * part) = region[m];
       }
     }
   }
