@@ -1299,7 +1299,7 @@ struct BaState {
   // first use for the landmark range they cover, and the per-observation W / Y blocks of the current linearisation
   DevBuf pair_cnt, pair_start, pairs, Wg, Yg, cam_pos;
   // recompute form of a session's iteration (ba_large.h): landmark runs of the workgroups, their partial sums
-  DevBuf wg_lm, lpart, pbs;  // pbs[3 l + x] = scale_l (P^-1 b)_l: what the reduced right-hand side needs of a landmark
+  DevBuf wg_lm, lpart, pbs, cam_lm, cam_uv;  // pbs[3 l + x] = scale_l (P^-1 b)_l: what the reduced right-hand side needs of a landmark
   int n_wg = 0;
   bool large_fused = false;
   int n_slots = 0, hbp1 = 0;
@@ -1640,6 +1640,8 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
     want.push_back({&st.wg_lm, 4 * ((size_t)st.n_wg + 1)});
     want.push_back({&st.lpart, 8 * 4 * (size_t)std::max(1, st.n_wg)});
     want.push_back({&st.pbs, 24 * L});
+    want.push_back({&st.cam_lm, 4 * O});
+    want.push_back({&st.cam_uv, 16 * O});
   }
   if (st.want_alt_set) {
     const Want alt[] = {{&st.r2, 16 * O}, {&st.F2, 96 * O}, {&st.E2, 48 * O}, {&st.n2l2, 24 * L}, {&st.grad_l2, 24 * L},
@@ -1902,7 +1904,7 @@ int bal_init_pass(vsl_ctx* ctx, BaState& st) {
   hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
                      st.scalars.as<double>(), (double*)nullptr);
   hipLaunchKernelGGL(bal_cam_kernel<true>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
-                     st.cam_start.as<int>(), st.cam_obs.as<int>(), (const double*)nullptr, st.cam_part.as<double>());
+                     st.cam_start.as<int>(), st.cam_lm.as<int>(), st.cam_uv.as<double>(), (const double*)nullptr, st.cam_part.as<double>());
   hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 0,
                      st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
   VSL_CHECK_LAUNCH(ctx);
@@ -1924,7 +1926,7 @@ int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
   hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
                      st.scalars.as<double>(), gl_out);
   hipLaunchKernelGGL(bal_cam_kernel<false>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
-                     st.cam_start.as<int>(), st.cam_obs.as<int>(), st.pbs.as<double>(), st.cam_part.as<double>());
+                     st.cam_start.as<int>(), st.cam_lm.as<int>(), st.cam_uv.as<double>(), st.pbs.as<double>(), st.cam_part.as<double>());
   hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 1,
                      st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
   hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(gather_grid(st)), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
@@ -2376,6 +2378,10 @@ extern "C" int vsl_ba_session_create(vsl_ctx* ctx, const vsl_ba_problem* prob, c
     BaState& st = s->st;
     st.large_fused = !st.small && st.n_wg > 0 && st.D.nfree > 0 && !ctx->ba_no_fused && !env_no_fused &&
                      !ctx->ba_schur_atomics && st.n_pairs_cap < ((size_t)1 << 31);
+    if (st.large_fused) {
+      hipLaunchKernelGGL(bal_cam_major_kernel, dim3(st.nb_obs), dim3(256), 0, ctx->stream, st.D.O, st.cam_obs.as<int>(),
+                         st.obs_lm.as<int>(), st.obs_uv.as<double>(), st.cam_lm.as<int>(), st.cam_uv.as<double>());
+    }
   }
   if (s->diagc_keep.alloc(8 * (size_t)(s->st.D.n > 0 ? s->st.D.n : 1)) != hipSuccess) {
     delete s;

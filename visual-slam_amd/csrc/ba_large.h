@@ -284,6 +284,17 @@ __global__ __launch_bounds__(256) void bal_prep_finish_kernel(int G, const doubl
   }
 }
 
+// camera-major copies of (landmark, pixel) for bal_cam_kernel: once per session
+__global__ void bal_cam_major_kernel(int O, const int* __restrict__ cam_obs, const int* __restrict__ obs_lm,
+                                     const double* __restrict__ obs_uv, int* __restrict__ cam_lm, double* __restrict__ cam_uv) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= O) return;
+  const size_t q = (size_t)cam_obs[k];
+  cam_lm[k] = obs_lm[q];
+  cam_uv[2 * (size_t)k] = obs_uv[2 * q];
+  cam_uv[2 * (size_t)k + 1] = obs_uv[2 * q + 1];
+}
+
 // per free camera (grid = (free cameras, segments), like ba_cam_block_kernel): 21 entries of the upper triangle of
 // H = sum F^T F, g = sum F^T r and the landmark part of the reduced right-hand side, sum over the camera's observations
 // of Y b = F^T (E (P^-1 b)) -- from the landmark's 24 bytes pbs, not from the observation's 144-byte Y block (whose 16-byte
@@ -291,8 +302,9 @@ __global__ __launch_bounds__(256) void bal_prep_finish_kernel(int G, const doubl
 // part[(fc * nseg + seg) * 33 + e].
 template <bool INIT>
 __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __restrict__ free_cams,
-                                                      const int* __restrict__ cam_start, const int* __restrict__ cam_obs,
-                                                      const double* __restrict__ pbs, double* __restrict__ part) {
+                                                      const int* __restrict__ cam_start, const int* __restrict__ cam_lm,
+                                                      const double* __restrict__ cam_uv, const double* __restrict__ pbs,
+                                                      double* __restrict__ part) {
   constexpr int NE = INIT ? 27 : 33;
   __shared__ double sh[4][NE];
   const int fc = blockIdx.x, seg = blockIdx.y, nseg = gridDim.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -301,9 +313,11 @@ __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __res
 #pragma unroll
   for (int k = 0; k < NE; k++) acc[k] = 0.0;
   for (int k = cam_start[cam] + seg * 256 + threadIdx.x; k < cam_start[cam + 1]; k += 256 * nseg) {
-    const size_t q = (size_t)cam_obs[k];
-    const int lm = a.obs_lm[q];
-    const double uv[2] = {a.obs_uv[2 * q], a.obs_uv[2 * q + 1]};
+    // (landmark and pixel of the camera's k-th observation from camera-major copies: through cam_obs -> obs_lm / obs_uv
+    // they were two more dependent, scattered loads per observation)
+    const int lm = cam_lm[k];
+    const double2 uv2 = *(const double2*)(cam_uv + 2 * (size_t)k);
+    const double uv[2] = {uv2.x, uv2.y};
     const double pw[3] = {a.points[3 * (size_t)lm], a.points[3 * (size_t)lm + 1], a.points[3 * (size_t)lm + 2]};
     const double one[3] = {1.0, 1.0, 1.0};
     BlObs o;
