@@ -26,6 +26,9 @@ python3 $R/tools/pmc_summary.py $O $R/profiles/${ROUND}_pmc_traffic.json 512 > $
 # into the box's profiles/ as well, so that the bench line's device_accounting block is this build's
 echo e2e; (cd $R && LOOK=90 bash tools/e2e_profile.sh $ROUND > $O/e2e_profile.log 2>&1; cp gpurun_out/${ROUND}_e2e_kernel_stats.json gpurun_out/${ROUND}_e2e_kernel_stats.csv profiles/ 2>/dev/null; cp gpurun_out/${ROUND}_e2e_kernel_stats.json gpurun_out/${ROUND}_e2e_kernel_stats.csv $O/)
 (cd $R && LOOK=90 LEG=stages bash tools/e2e_profile.sh $ROUND > $O/e2e_stages_profile.log 2>&1; cp gpurun_out/${ROUND}_stages_e2e_kernel_stats.json gpurun_out/${ROUND}_stages_e2e_kernel_stats.csv $O/ 2>/dev/null)
+# bundle adjustment: HBM traffic of the fused local iteration and of the session kernels of the 1000-camera map (separate
+# --pmc passes); into the box's profiles/ as well, so that the bench line's local_ba / global_ba rooflines carry THIS build's
+echo ba_pmc; (cd $R && bash tools/ba_pmc.sh $ROUND > $O/ba_pmc.log 2>&1; cp gpurun_out/${ROUND}_ba_pmc_traffic.json $O/ 2>/dev/null; cp gpurun_out/${ROUND}_ba_pmc_traffic.json profiles/ 2>/dev/null)
 cd /tmp
 echo bench; (cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench.err)
 # BoW (K8 / K9) and the ORB front end: kernel durations on the k = 10 / L = 6 vocabulary
@@ -43,6 +46,4 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 # bundle adjustment: kernel durations of the local window and of the 1000-camera map
 echo ba; rocprofv3 --kernel-trace --stats --output-format csv -d $O/lba -- python3 $R/tools/local_ba_probe.py 7 > $O/lba.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gba -- python3 $R/tools/global_ba_bench.py --iters 8 > $O/gba.log 2>&1
-# bundle adjustment: HBM traffic of the fused local iteration and of the large-system kernels (separate --pmc passes)
-echo ba_pmc; (cd $R && bash tools/ba_pmc.sh $ROUND > $O/ba_pmc.log 2>&1; cp gpurun_out/${ROUND}_ba_pmc_traffic.json $O/ 2>/dev/null)
 echo refresh done
