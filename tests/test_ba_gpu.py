@@ -154,6 +154,37 @@ def test_fused_iteration_at_window_sizes(ctx, orc, synth, n_kf, n_fixed_cams, n,
     assert np.array_equal(a_f.poses[fixed], d["poses"][fixed])
 
 
+@pytest.mark.parametrize("seed,n_kf,n_lms,max_iters,noise", [(411, 7, 3000, 20, 0.5), (412, 5, 1200, 40, 0.0), (413, 10, 2500, 3, 0.5),
+                                                             (414, 3, 300, 25, 2.0)])
+def test_device_decided_loop_equals_the_host_decided_one(ctx, orc, synth, seed, n_kf, n_lms, max_iters, noise):
+    # ba_fused.hip round 4: the Levenberg-Marquardt decision (gradient / parameter / function tolerance, step validity,
+    # the trust-region update, accept / reject) taken by baf_decide_kernel on the device, iterations enqueued one ahead
+    # of the decision the host has seen -- against the same kernels with the decision on the host ("ba_host_lm") and
+    # against the oracle: the same trajectory, to convergence (function tolerance), at the iteration limit, noise-free
+    d = synth.ba_problem(seed, n_kf=n_kf, n_lms=n_lms, pix_noise=noise, outlier_frac=0.05 if noise > 0 else 0.0)
+    a_dev, a_host, a_cpu = _arr(orc, d), _arr(orc, d), _arr(orc, d)
+    s_dev = ctx.bundle_adjust(a_dev, max_iters=max_iters)
+    ctx.set_diagnostic("ba_host_lm", 1)
+    try:
+        s_host = ctx.bundle_adjust(a_host, max_iters=max_iters)
+    finally:
+        ctx.set_diagnostic("ba_host_lm", 0)
+    s_cpu = orc.bundle_adjust(a_cpu, max_iters=max_iters)
+    assert (s_dev.iterations, s_dev.termination, s_dev.successful_steps) == (s_host.iterations, s_host.termination, s_host.successful_steps)
+    assert (s_dev.iterations, s_dev.termination, s_dev.successful_steps) == (s_cpu.iterations, s_cpu.termination, s_cpu.successful_steps)
+    assert s_dev.initial_cost == s_host.initial_cost
+    assert s_dev.final_cost == pytest.approx(s_host.final_cost, rel=1e-13)
+    assert s_dev.final_cost == pytest.approx(s_cpu.final_cost, rel=1e-7)
+    # (the radius update's cube is rounded once on both sides; a last-bit difference there would show up here)
+    assert np.allclose(a_dev.poses, a_host.poses, rtol=0, atol=1e-12)
+    assert np.allclose(a_dev.points, a_host.points, rtol=0, atol=1e-9)
+    # a second solve on the same context: the records of the first one must not be mistaken for this one's
+    a_again = _arr(orc, d)
+    s_again = ctx.bundle_adjust(a_again, max_iters=max_iters)
+    assert (s_again.iterations, s_again.final_cost) == (s_dev.iterations, s_dev.final_cost)
+    assert np.array_equal(a_again.poses, a_dev.poses)
+
+
 def test_fused_iteration_edge_cases(ctx, orc, synth):
     # (a) landmarks without any observation and landmarks seen by fixed cameras only ride along untouched / move by
     # their own 3 x 3 block; (b) a solved problem: the same (early) termination as the oracle;

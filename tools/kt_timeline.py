@@ -4,7 +4,8 @@ prints the kernels between the `which`-th last (default 3rd last) and the follow
 import csv, glob, sys
 d, key = sys.argv[1], sys.argv[2]
 which = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-f = glob.glob(d + '/*/*kernel_trace.csv')[0]
+import os
+f = max(glob.glob(d + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if key in r['Kernel_Name']]
 a, b = idx[-which], idx[-which + 1]

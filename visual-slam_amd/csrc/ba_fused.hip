@@ -67,8 +67,23 @@ __host__ __device__ inline unsigned bf_pack(unsigned rank, unsigned li, unsigned
   return rank | (li << 10) | (chunk << 15) | (lml << 19) | (cam << 26);
 }
 
+// Levenberg-Marquardt state of a solve ON THE DEVICE (round 4, "device-decided" loop): baf_decide_kernel applies the
+// [upstream] Ceres policy after every iteration and the kernels of the next one read radius / current buffer / done from
+// here, so the host enqueues iterations without waiting for the previous one's verdict.
+struct BfLm {
+  double cost, radius, decrease;
+  int iteration, invalid, successful, termination;
+  int cur;    // which (poses, points) buffer pair holds the current estimate: 0 = (poses, points), 1 = the _alt pair
+  int done;   // set with the termination reason: every later kernel of the stream returns at once
+  int bodies; // loop bodies decided so far
+  int pad;
+};
+
 struct BfArgs {
   BaDims D;
+  const BfLm* lm;          // null: the host decides (radius as a kernel argument, buffers swapped by the host)
+  double* poses_alt;       // device-decided loop: the second buffer pair (candidate of cur = 0, current of cur = 1)
+  double* points_alt;
   int NP;     // unknowns + the right-hand-side row, padded to whole tiles: 16 * ((n + 16) / 16)
   int NPs;    // row stride of the K-major operands (doubles): = 16 mod 32, so the four k-groups of an operand read spread over the banks
   int NT;     // NP / 16
@@ -91,6 +106,27 @@ struct BfArgs {
   double* hc_part;   // [G][nfree][27]: upper triangle of F^T F (21) | F^T r (6)
   double* sc_part;   // [G][2]: cost | max |landmark gradient|
 };
+
+// device-decided loop: the kernel's view of the argument block -- current buffers by the state's `cur`, the radius
+// from the state; returns false when the solve is over (the kernel leaves)
+__device__ __forceinline__ bool bf_resolve(BfArgs& a, double& inv_radius, double*& cand_poses, double*& cand_points) {
+  if (!a.lm) return true;
+  const BfLm st = *a.lm;
+  if (st.done) return false;
+  inv_radius = 1.0 / st.radius;
+  double* pA = const_cast<double*>(a.poses);
+  double* qA = const_cast<double*>(a.points);
+  if (st.cur) {
+    a.poses = a.poses_alt;
+    a.points = a.points_alt;
+    cand_poses = pA;
+    cand_points = qA;
+  } else {
+    cand_poses = a.poses_alt;
+    cand_points = a.points_alt;
+  }
+  return true;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -236,6 +272,10 @@ __global__ __launch_bounds__(BF_THREADS) void baf_schur_kernel(BfArgs a, double 
   __shared__ unsigned pres_s[BF_LMW];
   __shared__ double red_s[2][BF_WAVES];
   static_assert(BF_OBS_CAP * 14 <= BF_R, "the camera-major view must fit the work region");
+  {
+    double *cp_unused, *cq_unused;
+    if (!INIT && !bf_resolve(a, inv_radius, cp_unused, cq_unused)) return;
+  }
   const BaDims& D = a.D;
   const int tid = threadIdx.x, bid = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = D.n;
@@ -501,7 +541,12 @@ __global__ __launch_bounds__(256) void baf_finish_kernel(int n, int nfree, int G
                                                          const double* __restrict__ sc_part,
                                                          const double* __restrict__ scale_c, double inv_radius,
                                                          double* __restrict__ S, double* __restrict__ rhs,
-                                                         double* __restrict__ host_out, double* __restrict__ host_gabs) {
+                                                         double* __restrict__ host_out, double* __restrict__ host_gabs,
+                                                         const BfLm* __restrict__ lm) {
+  if (lm) {  // device-decided loop: radius from the state; nothing to do once the solve is over
+    if (lm->done) return;
+    inv_radius = 1.0 / lm->radius;
+  }
   // A workgroup sums 16 CONSECUTIVE doubles of the tile partials (128 contiguous bytes per partial: the first version
   // walked the partials entry by entry of S, 8 bytes out of every 32 -- FETCH_SIZE 45 MB for 8 MB of partials) and
   // scatters the sums to the entries of S they are: element q of lane l of tile (ti, tj) is
@@ -636,7 +681,8 @@ __global__ __launch_bounds__(256) void baf_init_finish_kernel(int n, int nfree, 
 
 __global__ __launch_bounds__(BF_THREADS) void baf_chol_kernel(int n, const double* __restrict__ S,
                                                               const double* __restrict__ rhs, double* __restrict__ dc,
-                                                              int* __restrict__ ok_flag) {
+                                                              int* __restrict__ ok_flag, const BfLm* __restrict__ lm) {
+  if (lm && lm->done) return;
   __shared__ double A[CS_ROWS * CS_LD];  // 133 KB
   __shared__ double inv_s[128];
   __shared__ double t_s[128];
@@ -763,8 +809,7 @@ __global__ __launch_bounds__(BF_THREADS) void baf_chol_kernel(int n, const doubl
 // = Plus(x, step .* scale); cost at the candidate.  step_part[5 * workgroup ..] = [model, candidate cost, |step|^2,
 // |x|^2, non-finite count] in pinned host memory.
 __global__ __launch_bounds__(BF_THREADS) void baf_step_kernel(BfArgs a, const double* __restrict__ dc,
-                                                              double* __restrict__ cand_poses,
-                                                              double* __restrict__ cand_points,
+                                                              double* cand_poses, double* cand_points,
                                                               double* __restrict__ step_part) {
   __shared__ double stage_v[BF_OBS_CAP * 3];
   __shared__ double cam_s[BF_CAMS * 12];
@@ -780,6 +825,10 @@ __global__ __launch_bounds__(BF_THREADS) void baf_step_kernel(BfArgs a, const do
   __shared__ int camk_s[BF_CAMS];
   __shared__ int camf_s[BF_CAMS];
   __shared__ double red_s[BF_WAVES][5];
+  {
+    double ir_unused = 0.0;
+    if (!bf_resolve(a, ir_unused, cand_poses, cand_points)) return;
+  }
   const BaDims& D = a.D;
   const int tid = threadIdx.x, bid = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = D.n;
@@ -899,6 +948,147 @@ __global__ __launch_bounds__(BF_THREADS) void baf_step_kernel(BfArgs a, const do
     for (int w = 0; w < BF_WAVES; w++) t += red_s[w][tid];
     step_part[5 * (size_t)bid + tid] = t;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The Levenberg-Marquardt decision on the device (one wavefront): what the host loop of vsl_ba_fused_solve does with
+// the mailbox after an iteration -- gradient tolerance, step validity, parameter / function tolerance, the
+// [upstream] Ceres trust-region update, accept / reject -- on the same numbers in the same order (IEEE double
+// throughout; the cube of the radius update is formed in double-double and rounded once, as the host's pow is), so the
+// trajectory is the host-decided one.  box = [cost | max landmark gradient | (int) Cholesky ok | . | gabs[128] |
+// 5 step partials per workgroup], the kernels' outputs in DEVICE memory; rec = one record per loop body in pinned host
+// memory: [seq, done, termination, iteration, successful, cost, radius, gmax, step norm, rel, candidate cost, cost change,
+// cur], seq written last behind a system-scope fence -- the host polls it.
+#define BF_REC 16
+__global__ __launch_bounds__(64) void baf_decide_kernel(BfLm* __restrict__ lm, const double* __restrict__ box, int n, int G,
+                                                        int max_iters, double* __restrict__ rec_base) {
+  const int lane = threadIdx.x;
+  BfLm st = *lm;
+  if (st.done) return;
+  // step partials in workgroup order (one quantity per lane), camera gradient maximum over the lanes.  The 5 G partials
+  // come in with all loads in flight (as a loop of load-and-add they were 256 dependent round trips: 35 us)
+  __shared__ double part_s[5 * 1024];
+  {
+    const int total = 5 * G;
+    for (int i0 = 0; i0 < total; i0 += 64 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + 64 * u + lane;
+        v[u] = i < total ? box[132 + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + 64 * u + lane;
+        if (i < total) part_s[i] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  double sum5 = 0.0;
+  if (lane < 5) {
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = part_s[5 * (g + u) + lane];
+#pragma unroll
+      for (int u = 0; u < 8; u++) sum5 += v[u];
+    }
+    for (; g < G; g++) sum5 += part_s[5 * g + lane];
+  }
+  double gm = 0.0;
+  for (int x = lane; x < n; x += 64) gm = fmax(gm, box[4 + x]);
+  gm = wave_max(gm);
+  const double model_change = __shfl(sum5, 0), cand_cost = __shfl(sum5, 1), step2 = __shfl(sum5, 2), x2 = __shfl(sum5, 3),
+               bad = __shfl(sum5, 4);
+  if (lane != 0) return;
+  const double gmax = fmax(box[1], gm);
+  const int chol_ok = *(const int*)(box + 2);
+  double step_norm = 0.0, rel = 0.0, cost_change = 0.0;
+  const double radius_used = st.radius;
+  int term = -1;
+  if (gmax <= 1e-10) {
+    term = 2;
+  } else if (st.radius <= 1e-32) {
+    term = 4;
+  } else {
+    st.iteration++;
+    step_norm = sqrt(step2);
+    const double x_norm = sqrt(x2);
+    const bool ok = chol_ok != 0 && bad == 0.0 && model_change > 0.0;
+    if (!ok) {
+      if (++st.invalid >= 5)
+        term = 4;
+      else
+        st.radius *= 0.5;
+    } else {
+      st.invalid = 0;
+      cost_change = st.cost - cand_cost;
+      if (step_norm <= 1e-8 * (x_norm + 1e-8)) {
+        term = 3;
+      } else if (fabs(cost_change) <= 1e-6 * st.cost) {
+        term = 1;
+      } else {
+        rel = cost_change / model_change;
+        if (rel > 1e-3) {
+          st.cost = cand_cost;
+          st.cur ^= 1;
+          st.successful++;
+          const double y = 2.0 * rel - 1.0;
+          const double p = y * y, pe = fma(y, y, -p);   // y^2 = p + pe
+          const double q = p * y, qe = fma(p, y, -q);   // p y = q + qe
+          const double y3 = q + (qe + pe * y);          // y^3 rounded once
+          st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - y3);
+          st.radius = fmin(1e16, st.radius);
+          st.decrease = 2.0;
+        } else {
+          st.radius = st.radius / st.decrease;
+          st.decrease *= 2.0;
+        }
+      }
+    }
+  }
+  if (term < 0 && st.iteration >= max_iters) term = 0;
+  if (term >= 0) {
+    st.termination = term;
+    st.done = 1;
+  }
+  const int body = st.bodies;
+  st.bodies = body + 1;
+  *lm = st;
+  double* rec = rec_base + (size_t)BF_REC * (body + 1);
+  rec[1] = (double)st.done;
+  rec[2] = (double)st.termination;
+  rec[3] = (double)st.iteration;
+  rec[4] = (double)st.successful;
+  rec[5] = st.cost;
+  rec[6] = radius_used;
+  rec[7] = gmax;
+  rec[8] = step_norm;
+  rec[9] = rel;
+  rec[10] = cand_cost;
+  rec[11] = cost_change;
+  rec[12] = (double)st.cur;
+  rec[13] = (double)(chol_ok != 0 && bad == 0.0 && model_change > 0.0);
+  __threadfence_system();
+  *(volatile double*)rec = (double)(body + 1);
+}
+
+// state of a fresh solve: the scaling pass left the initial cost in box[0]; record 0 carries it to the host
+__global__ void baf_lm_init_kernel(BfLm* __restrict__ lm, const double* __restrict__ box, double* __restrict__ rec_base) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  BfLm st;
+  st.cost = box[0];
+  st.radius = 1e4;
+  st.decrease = 2.0;
+  st.iteration = st.invalid = st.successful = 0;
+  st.termination = -1;
+  st.cur = st.done = st.bodies = st.pad = 0;
+  *lm = st;
+  rec_base[5] = st.cost;
+  __threadfence_system();
+  *(volatile double*)rec_base = -1.0;  // (sequence numbers of the loop bodies start at 1; -1 marks record 0 as written)
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1092,7 +1282,10 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   // the pinned block: the plan first, the kernels' mailbox behind it (one allocation, device-mapped)
   //   mailbox: [0] cost, [1] max |landmark gradient|, [2] (int) Cholesky ok, [4 .. 132) |camera gradient| per unknown,
   //            [132 .. 132 + 5 G) step partials
-  const size_t mail_doubles = 132 + 5 * (size_t)y.g_cap;
+  static const bool env_host_lm = getenv("VSL_BA_HOST_LM") != nullptr;
+  bool device_lm = !ctx->ba_host_lm && !env_host_lm;
+  // (device-decided loop: the pinned area holds one BF_REC-double record per loop body instead of the kernels' outputs)
+  const size_t mail_doubles = std::max<size_t>(132 + 5 * (size_t)y.g_cap, (size_t)BF_REC * ((size_t)std::max(opt->max_num_iterations, 0) + 4));
   const size_t pin_bytes = y.bytes + 8 * mail_doubles;
   if (ctx->ba_pin_cap < pin_bytes) {
     BF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1108,6 +1301,7 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   BfPlan pl;
   if (!bf_plan(prob, y, blk, pl)) return VSL_OK;
   *handled = 1;
+  if (pl.G > 1024) device_lm = false;  // (baf_decide_kernel stages 5 partials of <= 1024 workgroups)
   lap("plan");
   BaDims D;
   D.C = prob->n_cams;
@@ -1126,8 +1320,10 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
     size_t bytes;
   };
   char* dblk;
-  double *cand_poses, *cand_points, *scale_c, *scale_l, *Pinv, *bl, *S_part, *hc_part, *sc_part, *S, *rhs, *dc;
+  double *cand_poses, *cand_points, *scale_c, *scale_l, *Pinv, *bl, *S_part, *hc_part, *sc_part, *S, *rhs, *dc, *box;
+  BfLm* lm_dev;
   std::vector<Want> want = {{(void**)&dblk, y.bytes}, {(void**)&cand_poses, 56 * C}, {(void**)&cand_points, 24 * L},
+                            {(void**)&box, 8 * (132 + 5 * (size_t)y.g_cap)}, {(void**)&lm_dev, sizeof(BfLm)},
                             {(void**)&scale_c, 8 * 128}, {(void**)&scale_l, 24 * L}, {(void**)&Pinv, 72 * L},
                             {(void**)&bl, 24 * L}, {(void**)&S_part, 2048 * (size_t)T * G},
                             {(void**)&hc_part, 216 * (size_t)pl.nfree * G}, {(void**)&sc_part, 16 * (size_t)G},
@@ -1177,6 +1373,9 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   a.T = T;
   a.poses = poses;
   a.points = points;
+  a.lm = device_lm ? lm_dev : nullptr;
+  a.poses_alt = cand_poses;
+  a.points_alt = cand_points;
   a.intr = (const double*)(dblk + y.intr);
   a.cam_intr = (const int*)(dblk + y.cam_intr);
   a.cam_free = (const int*)(dblk + y.cam_free);
@@ -1201,14 +1400,105 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   double base_ms[5];
   for (int k = 0; k < 5; k++) base_ms[k] = ctx->stage_ms[st_of[k]];
 
+  if (device_lm)  // (sequence numbers of an earlier solve must not be mistaken for this one's)
+    for (int k = 0; k < std::max(opt->max_num_iterations, 0) + 3; k++) mailbox[(size_t)BF_REC * k] = 0.0;
   // Jacobi scaling from the unscaled Jacobian + the initial cost
   {
     VslStage s(ctx, VSL_STAGE_BA_LIN);
     hipLaunchKernelGGL((baf_schur_kernel<true, 1>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, 0.0);
     hipLaunchKernelGGL(baf_init_finish_kernel, dim3((n + 15) / 16 + 1), dim3(256), 0, ctx->stream, n, pl.nfree, G, hc_part,
-                       sc_part, scale_c, mailbox);
+                       sc_part, scale_c, device_lm ? box : mailbox);
+    if (device_lm) hipLaunchKernelGGL(baf_lm_init_kernel, dim3(1), dim3(64), 0, ctx->stream, lm_dev, box, mailbox);
     VSL_CHECK_LAUNCH(ctx);
   }
+  if (device_lm) {
+    // ---- the device-decided loop: iterations are enqueued ONE AHEAD of the decision the host has seen; a body that
+    // runs after the termination returns at its first instruction.  No synchronisation inside the loop: the host polls
+    // the pinned records.
+    volatile double* recs = mailbox;
+    auto enqueue_body = [&]() -> int {
+      {
+        VslStage s(ctx, VSL_STAGE_BA_SCHUR);
+        if (T <= BF_WAVES)
+          hipLaunchKernelGGL((baf_schur_kernel<false, 1>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, 0.0);
+        else if (T <= 2 * BF_WAVES)
+          hipLaunchKernelGGL((baf_schur_kernel<false, 2>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, 0.0);
+        else
+          hipLaunchKernelGGL((baf_schur_kernel<false, 3>), dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, 0.0);
+      }
+      {
+        VslStage s(ctx, VSL_STAGE_BA_FINISH);
+        hipLaunchKernelGGL(baf_finish_kernel, dim3(16 * T + 1), dim3(256), 0, ctx->stream, n, pl.nfree, G, T, S_part, hc_part,
+                           sc_part, scale_c, 0.0, S, rhs, box, box + 4, (const BfLm*)lm_dev);
+      }
+      {
+        VslStage s(ctx, VSL_STAGE_BA_SOLVE);
+        hipLaunchKernelGGL(baf_chol_kernel, dim3(1), dim3(BF_THREADS), 0, ctx->stream, n, S, rhs, dc, (int*)(box + 2),
+                           (const BfLm*)lm_dev);
+      }
+      {
+        VslStage s(ctx, VSL_STAGE_BA_STEP);
+        hipLaunchKernelGGL(baf_step_kernel, dim3(G), dim3(BF_THREADS), 0, ctx->stream, a, dc, cand_poses, cand_points, box + 132);
+        hipLaunchKernelGGL(baf_decide_kernel, dim3(1), dim3(64), 0, ctx->stream, lm_dev, box, n, G, opt->max_num_iterations,
+                           mailbox);
+      }
+      VSL_CHECK_LAUNCH(ctx);
+      return VSL_OK;
+    };
+    const int max_bodies = std::max(opt->max_num_iterations, 0);
+    int enq = 0, rc2;
+    for (; enq < std::min(2, max_bodies); enq++)
+      if ((rc2 = enqueue_body())) return rc2;
+    double last[BF_REC];
+    memset(last, 0, sizeof(last));
+    int seen = 0;
+    bool over = max_bodies == 0;
+    if (opt->verbosity >= 2) fprintf(stderr, "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n");
+    while (!over) {
+      volatile double* r = recs + (size_t)BF_REC * (seen + 1);
+      // wait for the decision of body `seen` (spin on pinned memory; a device error ends the wait through the query)
+      for (long spins = 0; r[0] != (double)(seen + 1); spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff) {
+          const hipError_t qe = hipStreamQuery(ctx->stream);
+          if (qe != hipSuccess && qe != hipErrorNotReady)
+            return vsl_fail(ctx, VSL_ERR_HIP, "fused bundle adjustment: %s while waiting for the device's decision", hipGetErrorString(qe));
+          if (qe == hipSuccess && r[0] != (double)(seen + 1))
+            return vsl_fail(ctx, VSL_ERR_HIP, "fused bundle adjustment: the stream drained without the decision of body %d", seen);
+        }
+      }
+      for (int k = 0; k < BF_REC; k++) last[k] = r[k];
+      seen++;
+      if (opt->verbosity >= 2) {
+        if (last[13] != 0.0)
+          fprintf(stderr, "%4d % .6e % .3e % .3e % .3e % .3e % .3e\n", (int)last[3], last[10], last[11], last[7], last[8], last[9], last[6]);
+        else
+          fprintf(stderr, "%4d  invalid step or termination before a step, radius %.3e\n", (int)last[3], last[6]);
+      }
+      if (last[1] != 0.0) break;  // done
+      if (enq < max_bodies) {
+        if ((rc2 = enqueue_body())) return rc2;
+        enq++;
+      } else if (seen == enq) {
+        over = true;  // (cannot happen: the last allowed body sets done)
+      }
+    }
+    BF_HIP(hipStreamSynchronize(ctx->stream));
+    lap("scaling pass + LM loop (device-decided)");
+    sum.initial_cost = recs[5];
+    if (seen > 0) {
+      sum.iterations = (int)last[3];
+      sum.successful_steps = (int)last[4];
+      sum.final_cost = last[5];
+      sum.termination = (int)last[2] < 0 ? 0 : (int)last[2];
+      if ((int)last[12]) {
+        std::swap(poses, cand_poses);
+        std::swap(points, cand_points);
+      }
+    } else {
+      sum.final_cost = sum.initial_cost;
+    }
+  } else {
   BF_HIP(hipStreamSynchronize(ctx->stream));
   lap("arena + upload + scaling pass");
   double cost = mail[0];
@@ -1237,12 +1527,13 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
     {
       VslStage s(ctx, VSL_STAGE_BA_FINISH);
       hipLaunchKernelGGL(baf_finish_kernel, dim3(16 * T + 1), dim3(256), 0, ctx->stream, n, pl.nfree,
-                         G, T, S_part, hc_part, sc_part, scale_c, inv_radius, S, rhs, mailbox, mailbox + 4);
+                         G, T, S_part, hc_part, sc_part, scale_c, inv_radius, S, rhs, mailbox, mailbox + 4, (const BfLm*)nullptr);
       VSL_CHECK_LAUNCH(ctx);
     }
     {
       VslStage s(ctx, VSL_STAGE_BA_SOLVE);
-      hipLaunchKernelGGL(baf_chol_kernel, dim3(1), dim3(BF_THREADS), 0, ctx->stream, n, S, rhs, dc, (int*)(mailbox + 2));
+      hipLaunchKernelGGL(baf_chol_kernel, dim3(1), dim3(BF_THREADS), 0, ctx->stream, n, S, rhs, dc, (int*)(mailbox + 2),
+                         (const BfLm*)nullptr);
       VSL_CHECK_LAUNCH(ctx);
     }
     {
@@ -1298,6 +1589,7 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
   sum.iterations = iteration;
   sum.final_cost = cost;
   lap("LM loop");
+  }  // host-decided loop
   BF_HIP(hipMemcpyAsync(prob->poses, poses, 56 * C, hipMemcpyDeviceToHost, ctx->stream));
   BF_HIP(hipMemcpyAsync(prob->points, points, 24 * L, hipMemcpyDeviceToHost, ctx->stream));
   BF_HIP(hipStreamSynchronize(ctx->stream));

@@ -84,6 +84,7 @@ struct vsl_ctx {
   bool ba_no_fused = false;             // diagnostic: local windows by the operator-by-operator kernels of ba.hip instead of the fused iteration (ba_fused.hip)
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int describe_tile_min_images = 96;   // describe launches of at least this many images use the shared-tile kernel (measured break-even ~64 images; diagnostic: 1 forces it, 0 disables it)
+  bool ba_host_lm = false;              // diagnostic: the fused local iteration with the Levenberg-Marquardt decision on the HOST (one synchronisation per iteration) instead of on the device (ba_fused.hip baf_decide_kernel)
   bool bow_no_wg_score = false;         // diagnostic: wave-per-candidate scoring kernel also for few candidates
   bool bow_keys64 = false;              // diagnostic: 64-bit sort keys in the BowVector assembly even where (id, feature) fits 32 bits
   int vo_chain_ticket = 0;              // diagnostic: vsl_map_track draws chain positions from the atomic ticket at every map size
