@@ -26,7 +26,9 @@
 #ifndef K1_ROWS
 #define K1_ROWS 60
 #endif
+#ifndef K1_ROWS_SMALL
 #define K1_ROWS_SMALL 29  // strips of launches of fewer than 8 images (17 strips of a 480-row image instead of 8)
+#endif
 // goodFeaturesToTrack's qualityLevel as the reference passes it (keypoints.h:138): threshold = max response * 0.01
 #define VSL_QUALITY_LEVEL 0.01
 #define K1_WLIST 384  // LDS candidate slots per wave strip (60 x 60 pixels); overflow goes straight to global memory
