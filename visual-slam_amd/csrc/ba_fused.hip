@@ -1161,7 +1161,7 @@ bool bf_plan(const vsl_ba_problem* p, const BfLayout& y, char* blk, BfPlan& pl) 
   for (int l = 0; l < L; l++) lm_start[l + 1] += lm_start[l];
   if (sorted) {
     memcpy(s_uv, p->obs_uv, 16 * (size_t)O);
-    for (int i = 0; i < O; i++) meta[i] = (unsigned)p->obs_cam[i] << 26;
+    // (the camera field is written together with the rest of the word in the landmark loop below: one pass less)
   } else {
     unsigned* fill = (unsigned*)(blk + y.lm_pres);  // borrowed as the scatter cursor; rewritten below
     for (int l = 0; l < L; l++) fill[l] = (unsigned)lm_start[l];
@@ -1187,6 +1187,7 @@ bool bf_plan(const vsl_ba_problem* p, const BfLayout& y, char* blk, BfPlan& pl) 
     const long long target = (long long)O * (g + 1) / G0;  // cumulative observations this workgroup should reach
     int* rec = wg_info + (size_t)BF_INFO * g;
     memset(rec, 0, 4 * BF_INFO);
+    for (int c = 0; c <= nfree; c++) cnt[c] = 0;
     const int lm0 = l, obs0 = lm_start[l];
     int n_ch = 0, ch_lm = 0;
     while (l < L) {
@@ -1205,12 +1206,14 @@ bool bf_plan(const vsl_ba_problem* p, const BfLayout& y, char* blk, BfPlan& pl) 
       unsigned m = 0;
       const unsigned word = bf_pack(0, (unsigned)ch_lm, (unsigned)n_ch, (unsigned)(l - lm0), 0);
       for (int q = a; q < b; q++) {
-        const int fc = cam_free[meta[q] >> 26];
+        const unsigned cam = sorted ? (unsigned)p->obs_cam[q] : meta[q] >> 26;
+        const int fc = cam_free[cam];
         if (fc >= 0) {
           if (m & (1u << fc)) return false;
           m |= 1u << fc;
+          cnt[fc + 1]++;  // (camera-major counts of the workgroup: gathered here, not in a pass of their own)
         }
-        meta[q] |= word;
+        meta[q] = (cam << 26) | word;
       }
       pres[l] = m;
       ch_lm++;
@@ -1226,11 +1229,6 @@ bool bf_plan(const vsl_ba_problem* p, const BfLayout& y, char* blk, BfPlan& pl) 
     for (int c = n_ch; c <= BF_MAXCH; c++) rec[BF_INFO_CB + c] = l - lm0;
     if (rec[3] > BF_OBS_CAP) return false;  // (a single landmark has <= 64 observations: a logic guard)
     // camera-major ranks of the free-camera observations of this workgroup
-    for (int c = 0; c <= nfree; c++) cnt[c] = 0;
-    for (int q = obs0; q < obs1; q++) {
-      const int fc = cam_free[meta[q] >> 26];
-      if (fc >= 0) cnt[fc + 1]++;
-    }
     for (int c = 0; c < nfree; c++) cnt[c + 1] += cnt[c];
     for (int c = 0; c <= nfree; c++) rec[BF_INFO_CAM + c] = cnt[c];
     for (int q = obs0; q < obs1; q++) {
