@@ -61,7 +61,7 @@ def main():
     doc = {"note": __doc__.replace("\n", " "), "workloads": {}}
     # kernels of one LM iteration (one dispatch each per iteration unless a count is given)
     local_iter = {"baf_schur_kernel<false,1>": 1, "baf_schur_kernel<false,2>": 1, "baf_schur_kernel<false,3>": 1,
-                  "baf_finish_kernel": 1, "baf_chol_kernel": 1, "baf_step_kernel": 1}
+                  "baf_finish_kernel": 1, "baf_chol_kernel": 1, "baf_step_kernel": 1, "baf_decide_kernel": 1}
     for name, n_kf in (("local7", 7), ("local10", 10)):
         d = synth.ba_problem(4, n_kf=n_kf, n_lms=20000)
         n = 6 * int((d["cam_fixed"] == 0).sum())
