@@ -1392,10 +1392,20 @@ int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free
   std::vector<uint64_t> adj((size_t)nfree * words, 0);
   {
     std::vector<int> start(gp->n_lms + 1, 0);
-    for (int i = 0; i < gp->n_obs; i++) start[gp->obs_lm[i] + 1]++;
+    bool sorted_in = true;
+    for (int i = 0; i < gp->n_obs; i++) {
+      start[gp->obs_lm[i] + 1]++;
+      if (i > 0 && gp->obs_lm[i] < gp->obs_lm[i - 1]) sorted_in = false;
+    }
     for (int l = 0; l < gp->n_lms; l++) start[l + 1] += start[l];
-    std::vector<int> fill(start.begin(), start.end() - 1), cams(gp->n_obs);
-    for (int i = 0; i < gp->n_obs; i++) cams[fill[gp->obs_lm[i]]++] = cam_free0[gp->obs_cam[i]];
+    // free-camera index of every observation in landmark order (the reference's own order is landmark order already)
+    std::vector<int> cams(gp->n_obs);
+    if (sorted_in) {
+      for (int i = 0; i < gp->n_obs; i++) cams[i] = cam_free0[gp->obs_cam[i]];
+    } else {
+      std::vector<int> fill(start.begin(), start.end() - 1);
+      for (int i = 0; i < gp->n_obs; i++) cams[fill[gp->obs_lm[i]]++] = cam_free0[gp->obs_cam[i]];
+    }
     // a private bit matrix per thread, OR-ed together afterwards (shared atomics made the threads fight over its lines)
     std::vector<std::vector<uint64_t>> priv(8);
     host_parallel(gp->n_lms, [&](int l0, int l1, int t) {
@@ -1527,27 +1537,47 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   ctx->last_ba_banded = st.banded ? 1 : 0;
   ctx->last_ba_bw = st.bw;
   tr.lap("free cameras + band order");
-  // sort observations by landmark (stable: keeps the caller's order inside a landmark)
-  std::vector<int> lm_start(D.L + 1, 0);
-  for (int i = 0; i < D.O; i++) lm_start[p->obs_lm[i] + 1]++;
-  for (int l = 0; l < D.L; l++) lm_start[l + 1] += lm_start[l];
-  st.perm.resize(D.O);
-  {
-    std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
-    for (int i = 0; i < D.O; i++) st.perm[fill[p->obs_lm[i]]++] = i;
+  // sort observations by landmark (stable: keeps the caller's order inside a landmark).  The reference's own order
+  // (map_utils.h:373 / loop_closure_utils.h:700: landmarks, then their observations) -- what
+  // include/visnav_amd/bundle_adjustment.h hands over -- is sorted already: then the caller's arrays ARE the sorted ones
+  // (no permutation, no 24 MB of gathered copies at 881 k observations; st.perm stays empty = identity)
+  std::vector<int> lm_start(D.L + 1, 0), cam_start(D.C + 1, 0);
+  bool sorted_in = true;
+  for (int i = 0; i < D.O; i++) {
+    lm_start[p->obs_lm[i] + 1]++;
+    cam_start[p->obs_cam[i] + 1]++;
+    if (i > 0 && p->obs_lm[i] < p->obs_lm[i - 1]) sorted_in = false;
   }
-  std::vector<int> s_cam(D.O), s_lm(D.O);
-  std::vector<double> s_uv(2 * (size_t)D.O);
-  int kmax_free = 0;
-  host_parallel(D.O, [&](int q0, int q1, int) {
-    for (int q = q0; q < q1; q++) {
-      const int i = st.perm[q];
-      s_cam[q] = p->obs_cam[i];
-      s_lm[q] = p->obs_lm[i];
-      s_uv[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
-      s_uv[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
+  for (int l = 0; l < D.L; l++) lm_start[l + 1] += lm_start[l];
+  for (int c = 0; c < D.C; c++) cam_start[c + 1] += cam_start[c];
+  std::vector<int> s_cam_v, s_lm_v;
+  std::vector<double> s_uv_v;
+  const int32_t *s_cam = p->obs_cam, *s_lm = p->obs_lm;
+  const double* s_uv = p->obs_uv;
+  st.perm.clear();
+  if (!sorted_in) {
+    st.perm.resize(D.O);
+    {
+      std::vector<int> fill(lm_start.begin(), lm_start.end() - 1);
+      for (int i = 0; i < D.O; i++) st.perm[fill[p->obs_lm[i]]++] = i;
     }
-  });
+    s_cam_v.resize(D.O);
+    s_lm_v.resize(D.O);
+    s_uv_v.resize(2 * (size_t)D.O);
+    host_parallel(D.O, [&](int q0, int q1, int) {
+      for (int q = q0; q < q1; q++) {
+        const int i = st.perm[q];
+        s_cam_v[q] = p->obs_cam[i];
+        s_lm_v[q] = p->obs_lm[i];
+        s_uv_v[2 * (size_t)q] = p->obs_uv[2 * (size_t)i];
+        s_uv_v[2 * (size_t)q + 1] = p->obs_uv[2 * (size_t)i + 1];
+      }
+    });
+    s_cam = s_cam_v.data();
+    s_lm = s_lm_v.data();
+    s_uv = s_uv_v.data();
+  }
+  int kmax_free = 0;
   size_t n_pairs = 0;  // (observation, observation) pairs of the block lists of the gather-form Schur complement
   {
     size_t np_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1569,10 +1599,8 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
       kmax_free = std::max(kmax_free, km_t[t]);
     }
   }
-  // camera CSR over the sorted observation positions
-  std::vector<int> cam_start(D.C + 1, 0), cam_obs(D.O);
-  for (int q = 0; q < D.O; q++) cam_start[s_cam[q] + 1]++;
-  for (int c = 0; c < D.C; c++) cam_start[c + 1] += cam_start[c];
+  // camera CSR over the sorted observation positions (counts gathered with the landmark counts above)
+  std::vector<int> cam_obs(D.O);
   {
     std::vector<int> fill(cam_start.begin(), cam_start.end() - 1);
     for (int q = 0; q < D.O; q++) cam_obs[fill[s_cam[q]]++] = q;
@@ -1687,9 +1715,9 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   BA_HIP(up(st.cam_intr, p->cam_intr, 4 * C));
   BA_HIP(up(st.cam_free, cam_free.data(), 4 * C));
   BA_HIP(up(st.free_cams, free_cams.data(), 4 * free_cams.size()));
-  BA_HIP(up(st.obs_cam, s_cam.data(), 4 * O));
-  BA_HIP(up(st.obs_lm, s_lm.data(), 4 * O));
-  BA_HIP(up(st.obs_uv, s_uv.data(), 16 * O));
+  BA_HIP(up(st.obs_cam, s_cam, 4 * O));
+  BA_HIP(up(st.obs_lm, s_lm, 4 * O));
+  BA_HIP(up(st.obs_uv, s_uv, 16 * O));
   BA_HIP(up(st.lm_start, lm_start.data(), 4 * (L + 1)));
   BA_HIP(up(st.cam_start, cam_start.data(), 4 * (C + 1)));
   BA_HIP(up(st.cam_obs, cam_obs.data(), 4 * O));
@@ -1983,7 +2011,7 @@ extern "C" int vsl_ba_residuals_jacobians(vsl_ctx* ctx, const vsl_ba_problem* pr
   VSL_HIP(ctx, hipMemcpyAsync(hE.data(), st.E.p, 8 * hE.size(), hipMemcpyDeviceToHost, ctx->stream));
   VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int q = 0; q < D.O; q++) {  // back to the caller's observation order
-    const size_t i = (size_t)st.perm[q];
+    const size_t i = st.perm.empty() ? (size_t)q : (size_t)st.perm[q];
     memcpy(r + 2 * i, &hr[2 * (size_t)q], 16);
     memcpy(J_pose + 12 * i, &hF[12 * (size_t)q], 96);
     memcpy(J_point + 6 * i, &hE[6 * (size_t)q], 48);
