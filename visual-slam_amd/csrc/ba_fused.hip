@@ -1445,7 +1445,10 @@ int vsl_ba_fused_solve(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_op
     };
     const int max_bodies = std::max(opt->max_num_iterations, 0);
     int enq = 0, rc2;
-    for (; enq < std::min(2, max_bodies); enq++)
+    // (with the stage events on, a body is enqueued only once the previous decision is known: the speculative body that
+    // finds `done` would count as a launch of every stage and pull the per-launch averages down)
+    const int lead = ctx->profiling ? 1 : 2;
+    for (; enq < std::min(lead, max_bodies); enq++)
       if ((rc2 = enqueue_body())) return rc2;
     double last[BF_REC];
     memset(last, 0, sizeof(last));
