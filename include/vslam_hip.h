@@ -434,6 +434,10 @@ int vsl_bundle_adjust_intrinsics(vsl_ctx* ctx, const vsl_ba_problem* prob, const
  * (single-launch kernel for half_bandwidth <= 512 unless the "chol_no_fused" diagnostic is set).  x (host, n doubles)
  * receives the solution.  VSL_ERR_NUMERIC if S is not positive definite. */
 int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int n, int half_bandwidth, double* x);
+/* The same for a CYCLIC band (non-zeros where min(|i - j|, n - |i - j|) <= half_bandwidth: the reduced camera system of a
+ * closed loop ordered along the trajectory): block cyclic reduction over a ring of blocks.  VSL_ERR_INVALID when the system
+ * has no such block layout (fewer than 8 blocks of >= half_bandwidth + 1 unknowns). */
+int vsl_spd_solve_cyclic(vsl_ctx* ctx, const double* S, const double* b, int n, int half_bandwidth, double* x);
 
 /* ------------------------------------------------------------ pose graph optimisation */
 /*

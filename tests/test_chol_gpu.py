@@ -153,3 +153,53 @@ def test_not_positive_definite_is_reported(ctx, vsl, bw):
     with pytest.raises(vsl.VslError) as e:
         ctx.spd_solve(S, np.ones(n), bw)
     assert e.value.code == -7  # VSL_ERR_NUMERIC
+
+
+def _cyclic_band_spd(n, bw, seed):
+    """Random symmetric CYCLIC band matrix (non-zeros within cyclic distance bw of the diagonal), diagonally dominant."""
+    rng = np.random.default_rng(seed)
+    S = np.zeros((n, n))
+    idx = np.arange(n)
+    for d in range(1, bw + 1):
+        v = rng.standard_normal(n)
+        r, c = idx, (idx - d) % n      # (i, i - d), the wrap-around corner included
+        S[r, c] += v
+        S[c, r] += v
+    S[idx, idx] = np.abs(S).sum(1) + rng.uniform(0.5, 1.5, n)
+    return S
+
+
+@pytest.mark.parametrize("n,bw", [(1024, 100), (1000, 113), (2000, 221), (5988, 113), (1100, 31), (1030, 127), (4097, 60),
+                                  (1040, 128)])
+def test_cyclic_block_cyclic_reduction(ctx, n, bw):
+    # the ring form of the block cyclic reduction (a closed camera loop ordered along its trajectory): even and odd rings
+    # at every level, rings of three and two at the end, block sizes that are / are not multiples of the kernels' 32,
+    # a half bandwidth of exactly a block (the layout moves to the next block size)
+    S = _cyclic_band_spd(n, bw, n + bw)
+    rng = np.random.default_rng(7 * n + bw)
+    b = rng.standard_normal(n)
+    x = ctx.spd_solve_cyclic(S, b, bw)
+    assert _residual(S, x, b) < 1e-10
+    if n <= 2000:
+        assert np.allclose(x, np.linalg.solve(S, b), rtol=1e-8, atol=1e-10)
+
+
+def test_cyclic_form_equals_the_linear_band_form_without_a_corner(ctx):
+    # a plain band matrix IS a cyclic band matrix with an empty corner: both solvers, the same solution
+    n, bw = 3000, 90
+    S = _band_spd(n, bw, 99)
+    b = np.random.default_rng(5).standard_normal(n)
+    x_lin = ctx.spd_solve(S, b, bw)
+    x_cyc = ctx.spd_solve_cyclic(S, b, bw)
+    assert _residual(S, x_cyc, b) < 1e-10
+    assert np.allclose(x_cyc, x_lin, rtol=1e-9, atol=1e-12)
+
+
+def test_cyclic_solver_reports_what_it_cannot_take(ctx, vsl):
+    S = _cyclic_band_spd(600, 100, 3)
+    with pytest.raises(vsl.VslError):
+        ctx.spd_solve_cyclic(S, np.ones(600), 100)     # fewer than 8 blocks of >= 101 unknowns
+    S = _cyclic_band_spd(1200, 40, 4)
+    S[700, 700] = -1.0
+    with pytest.raises(vsl.VslError):
+        ctx.spd_solve_cyclic(S, np.ones(1200), 40)     # not positive definite

@@ -184,6 +184,17 @@ class Context:
                                       x.ctypes.data_as(f64p)))
         return x
 
+    def spd_solve_cyclic(self, S, b, half_bandwidth):
+        """Solves S x = b for a CYCLIC band matrix (non-zeros within cyclic distance half_bandwidth of the diagonal)."""
+        S = np.ascontiguousarray(S, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        n = len(b)
+        assert S.shape == (n, n)
+        x = np.zeros(n, np.float64)
+        self._ck(self.L.vsl_spd_solve_cyclic(self.h, S.ctypes.data_as(f64p), b.ctypes.data_as(f64p), n, int(half_bandwidth),
+                                             x.ctypes.data_as(f64p)))
+        return x
+
     # ---- keypoints.h drop-ins (host buffers)
     def detect_describe(self, img, num_features=1500, rotate=True):
         img, p, w, h, pitch = _img(img)

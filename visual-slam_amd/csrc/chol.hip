@@ -676,7 +676,7 @@ __global__ __launch_bounds__(CBF_THREADS) void cbf2_backward_kernel(CbfView top,
 }
 
 #define BCR_MAXB 256  // block size limit of the cyclic reduction: static LDS Us[256][33] + Lp[32][257] = 133 KB (dynamic LDS above 64 KiB is refused by the runtime)
-int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev);
+int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic);
 
 // Solves S x = b in place (S destroyed, b <- x).  *ok_dev = 1 on success, 0 if S is not SPD.
 // Dense: ld = n, bw = n.  Band: S = storage + bws, ld = bws = bw + CH_NB (see the file header); bw = the largest
@@ -686,7 +686,7 @@ int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, i
   const int n_panels = (n + CH_NB - 1) / CH_NB;
   if (ld != n && !ctx->chol_no_fused && !ctx->chol_no_bcr && (bw + 1 + 31) / 32 * 32 <= BCR_MAXB &&
       n >= 8 * ((bw + 1 + 31) / 32 * 32))  // long narrow band: block cyclic reduction over the whole chip
-    return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev);
+    return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev, 0);
   if (ld != n && bw <= CBF_MAXBW && !ctx->chol_no_fused) {  // narrow band: one launch for the whole solve, or two-ended
     VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     const bool two_ended = !ctx->chol_one_ended && bw + CH_NB - 1 <= CBF_MAXBW && n >= 8 * (bw + CH_NB);
@@ -818,6 +818,48 @@ extern "C" int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int
   return VSL_OK;
 }
 
+// Test / diagnostic entry point for the CYCLIC band form: S (dense, row-major, symmetric) has non-zeros only where the
+// cyclic distance min(|i - j|, n - |i - j|) <= half_bandwidth.
+bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out);
+extern "C" int vsl_spd_solve_cyclic(vsl_ctx* ctx, const double* S, const double* b, int n, int half_bandwidth, double* x) {
+  if (!ctx || !S || !b || !x || n <= 0 || half_bandwidth < 0) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_spd_solve_cyclic: bad argument");
+  const int bw = half_bandwidth, bws = bw + CH_NB;
+  int Bq, nq;
+  if (!vsl_chol_bcr_cyclic_layout(n, bw, &Bq, &nq))
+    return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_spd_solve_cyclic: %d unknowns with half bandwidth %d have no cyclic block layout (>= 8 blocks of >= bw + 1 and <= %d unknowns)", n, bw, BCR_MAXB);
+  const size_t elems = (size_t)n * (bws + 1) + 64;
+  double *dS = nullptr, *db = nullptr;
+  int* dok = nullptr;
+  VSL_HIP(ctx, hipMalloc((void**)&dS, sizeof(double) * elems));
+  int rc = VSL_OK, ok = 0;
+  hipError_t e = hipMalloc((void**)&db, sizeof(double) * n);
+  if (e == hipSuccess) e = hipMalloc((void**)&dok, sizeof(int));
+  if (e == hipSuccess) {
+    // row i keeps columns [i - bws, i]; a column below zero is column c + n of the wrap-around corner
+    std::vector<double> st(elems, 0.0);
+    for (int i = 0; i < n; i++)
+      for (int c = i - bw; c <= i; c++) st[(size_t)i * (bws + 1) + (c - i + bws)] = S[(size_t)i * n + (c < 0 ? c + n : c)];
+    e = hipMemcpyAsync(dS, st.data(), sizeof(double) * elems, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db, b, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      rc = vsl_chol_solve_bcr_dev(ctx, dS + bws, db, n, bws, bw, dok, 1);
+      if (rc == VSL_OK) {
+        e = hipMemcpyAsync(&ok, dok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(x, db, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      }
+    }
+  }
+  (void)hipFree(dS);
+  (void)hipFree(db);
+  (void)hipFree(dok);
+  if (e != hipSuccess) return vsl_fail(ctx, VSL_ERR_HIP, "vsl_spd_solve_cyclic: %s", hipGetErrorString(e));
+  if (rc != VSL_OK) return rc;
+  if (!ok) return vsl_fail(ctx, VSL_ERR_NUMERIC, "vsl_spd_solve_cyclic: matrix is not positive definite");
+  return VSL_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // BLOCK CYCLIC REDUCTION of a long narrow band (n >= 8 blocks of B >= bw + 1 unknowns).  The band Cholesky above is a
 // chain of n / 32 dependent panel steps on one compute unit (two with the two-ended form); cutting the band into
@@ -837,33 +879,59 @@ struct BcrJob {
   int u;            // slot of U1 / U2
 };
 
-// band storage -> dense blocks: D[i] (lower triangle, identity-padded past n), C[i] = block (i + 1, i), b[i]
+// band storage -> dense blocks: D[i] (lower triangle, identity-padded past the block's unknowns), C[i] = block (i + 1, i),
+// b[i].  Block i holds the unknowns [off[i], off[i + 1]) (<= B of them).  CYCLIC band (round 4): the storage of row i
+// keeps columns [i - bws, i]; for i < bws the leading slots -- columns "below zero" -- hold the entries (i, j - n) of the
+// wrap-around corner (a camera loop ordered along its trajectory: first and last keyframes see each other), and
+// C[nblk - 1] = block (0, nblk - 1) closes the ring of blocks.
 __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, int bws, const double* __restrict__ b, int B,
-                                   int nblk, double* __restrict__ D, double* __restrict__ C, double* __restrict__ bb,
-                                   double* __restrict__ pend) {
+                                   int nblk, const int* __restrict__ off, int cyclic, double* __restrict__ D,
+                                   double* __restrict__ C, double* __restrict__ bb, double* __restrict__ pend) {
   const int blk = blockIdx.y;
   const size_t BB = (size_t)B * B;
+  const int o0 = off[blk], sz = off[blk + 1] - o0;
+  const int nxt = blk + 1 < nblk ? blk + 1 : 0;  // rows of the coupling block: the next block (the first one for the last)
+  const int o1 = off[nxt], sz1 = off[nxt + 1] - o1;
+  const bool has_c = blk + 1 < nblk || cyclic;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * B; idx += gridDim.x * blockDim.x) {
     const int r = idx / B, c = idx - r * B;
-    const int gi = blk * B + r, gc = blk * B + c;
     double d = 0.0;
-    if (gi < n && gc < n) {
-      if (c <= r) d = A[(size_t)gi * ld + gc];  // r - c <= B - 1 <= bws: inside the row's slots (zeros beyond the band)
+    if (r < sz && c < sz) {
+      if (c <= r) d = A[(size_t)(o0 + r) * ld + o0 + c];  // r - c <= B - 1 <= bws: inside the row's slots (zeros beyond the band)
     } else if (r == c) {
       d = 1.0;
     }
     D[blk * BB + idx] = d;
-    if (blk + 1 < nblk) {
-      const int gr = (blk + 1) * B + r;
-      C[blk * BB + idx] = (gr < n && gr - gc <= bws) ? A[(size_t)gr * ld + gc] : 0.0;
+    if (has_c) {
+      double v = 0.0;
+      if (r < sz1 && c < sz) {
+        const int gr = o1 + r;
+        const int gc = blk + 1 < nblk ? o0 + c : o0 + c - n;  // the wrap coupling reads the slots of the columns "below zero"
+        if (gr - gc <= bws) v = A[(size_t)gr * ld + gc];
+      }
+      C[blk * BB + idx] = v;
     }
   }
   if (blockIdx.x == 0)
     for (int r = threadIdx.x; r < B; r += blockDim.x) {
-      bb[(size_t)blk * B + r] = blk * B + r < n ? b[blk * B + r] : 0.0;
+      bb[(size_t)blk * B + r] = r < sz ? b[o0 + r] : 0.0;
       pend[((size_t)2 * blk) * B + r] = 0.0;
       pend[((size_t)2 * blk + 1) * B + r] = 0.0;
     }
+}
+
+// c0 += c1^T (ring of two blocks: both couplings join the same pair); out = in (the wrap coupling of an odd ring moves on)
+__global__ void bcr_add_transposed_kernel(int B, double* __restrict__ c0, const double* __restrict__ c1, const int* __restrict__ ok) {
+  if (!*ok) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * B) return;
+  const int r = idx / B, c = idx - r * B;
+  c0[idx] += c1[(size_t)c * B + r];
+}
+__global__ void bcr_copy_block_kernel(int B, const double* __restrict__ in, double* __restrict__ out, const int* __restrict__ ok) {
+  if (!*ok) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < B * B) out[idx] = in[idx];
 }
 
 // Dense B x B block (B <= 256) with its trailing matrix in REGISTERS: the 16 x 16 tiles of the lower triangle are
@@ -1544,18 +1612,44 @@ __global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __r
   for (int r = tid; r < B; r += CBF_THREADS) bb[(size_t)jb.e * B + r] = ts[r];
 }
 
-__global__ void bcr_gather_kernel(const double* __restrict__ bb, int n, double* __restrict__ b, const int* __restrict__ ok) {
+__global__ void bcr_gather_kernel(const double* __restrict__ bb, int B, const int* __restrict__ off, double* __restrict__ b,
+                                  const int* __restrict__ ok) {
   if (!*ok) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) b[i] = bb[i];
+  const int blk = blockIdx.y, o0 = off[blk], sz = off[blk + 1] - o0;
+  for (int r = threadIdx.x; r < sz; r += blockDim.x) b[o0 + r] = bb[(size_t)blk * B + r];
 }
 
-// S (band storage, n unknowns, half bandwidth bw) x = b by block cyclic reduction; b <- x
-int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
-  const int B = (bw + 1 + 31) / 32 * 32, nblk = (n + B - 1) / B;
+// Block layout of the cyclic form: nblk blocks of floor / ceil (n / nblk) unknowns, every one >= bw + 1 (a block couples
+// with its two ring neighbours only) and <= B (the kernels' block size, a multiple of 32 <= BCR_MAXB).  false: no such layout.
+bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out) {
+  const int most = n / (bw + 1);  // blocks of >= bw + 1 unknowns each
+  for (int B = (bw + 1 + 31) / 32 * 32; B <= BCR_MAXB; B += 32) {
+    const int nblk = std::max(8, (n + B - 1) / B);  // the fewest blocks of <= B unknowns (fewer blocks: fewer levels)
+    if (nblk <= most) {
+      *B_out = B;
+      *nblk_out = nblk;
+      return true;
+    }
+  }
+  return false;
+}
+
+// S (band storage, n unknowns, half bandwidth bw) x = b by block cyclic reduction; b <- x.  cyclic: the band closes on
+// itself (entries (i, j) with j - i >= n - bw live in the leading slots of row i, see bcr_extract_kernel): the blocks form
+// a RING -- the neighbour below the last block is the first one -- and every level halves the ring: an even ring's last
+// elimination creates the next ring's wrap coupling, an odd ring's wrap coupling moves on unchanged, a ring of two blocks
+// is one coupling (the sum of both) and ends as a chain.
+int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic) {
+  int B = (bw + 1 + 31) / 32 * 32, nblk = (n + B - 1) / B;
+  if (cyclic && !vsl_chol_bcr_cyclic_layout(n, bw, &B, &nblk))
+    return vsl_fail(ctx, VSL_ERR_INVALID, "cyclic band of %d unknowns, half bandwidth %d: no block layout (the caller checks vsl_chol_bcr_cyclic_layout)", n, bw);
   const size_t BB = (size_t)B * B;
+  std::vector<int> off(nblk + 1);
+  for (int i = 0; i <= nblk; i++) off[i] = cyclic ? (int)((long long)i * n / nblk) : std::min(n, i * B);
   // levels on the host: active block lists, jobs
+  struct LevelOp { int combine = 0, carry = 0; };  // combine: c[0] += c[1]^T before the solves; carry: c[m - 1] -> next c[m' - 1]
   std::vector<std::vector<BcrJob>> levels;
+  std::vector<LevelOp> ops;
   std::vector<int> active(nblk), ncoup;
   for (int i = 0; i < nblk; i++) active[i] = i;
   int n_u = 0;
@@ -1563,23 +1657,28 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     const int m = (int)active.size();
     std::vector<BcrJob> jobs;
     std::vector<int> next;
+    LevelOp op;
+    const bool ring = cyclic && m >= 3;  // a ring of two is handled as a chain with one (combined) coupling
+    if (cyclic && m == 2) op.combine = 1;
+    if (ring && (m & 1)) op.carry = 1;
     for (int j = 0; j < m; j++) {
       if (j & 1) {
         BcrJob jb;
         jb.e = active[j];
         jb.p = active[j - 1];
-        jb.q = j + 1 < m ? active[j + 1] : -1;
+        jb.q = j + 1 < m ? active[j + 1] : (ring ? active[0] : -1);
         jb.kp = j - 1;
         jb.kq = j;
-        jb.knew = j + 1 < m ? (j - 1) / 2 : -1;
+        jb.knew = jb.q >= 0 ? (j - 1) / 2 : -1;
         jb.u = n_u++;
         jobs.push_back(jb);
       } else {
         next.push_back(active[j]);
       }
     }
-    ncoup.push_back(m - 1);
+    ncoup.push_back(cyclic ? m : m - 1);
     levels.push_back(jobs);
+    ops.push_back(op);
     active = next;
   }
   const int last = active[0];
@@ -1615,7 +1714,8 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
   size_t n_targets = 0;
   for (auto& tl : targets) n_targets += tl.size();
   const size_t job_only_bytes = ((n_jobs + 1) * sizeof(BcrJob) + 63) / 64 * 64;
-  const size_t job_bytes = job_only_bytes + (n_targets + 1) * sizeof(BcrTarget);
+  const size_t tgt_bytes = ((n_targets + 1) * sizeof(BcrTarget) + 63) / 64 * 64;
+  const size_t job_bytes = job_only_bytes + tgt_bytes + sizeof(int) * ((size_t)nblk + 1);
   void* ws = nullptr;
   int rc = vsl_ctx_dscratch(ctx, sizeof(double) * doubles + 256, &ws);
   if (rc) return rc;
@@ -1651,6 +1751,7 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     }
   }
   BcrTarget* targets_dev = (BcrTarget*)((char*)ctx->bcr_jobs + job_only_bytes);
+  int* off_dev = (int*)((char*)ctx->bcr_jobs + job_only_bytes + tgt_bytes);
   std::vector<BcrTarget> tflat;
   std::vector<size_t> tgt_off;
   for (auto& tl : targets) {
@@ -1659,22 +1760,29 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
   }
   static const int one = 1;
   VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->bcr_key_n != n || ctx->bcr_key_bw != bw) {
+  const int key_bw = cyclic ? -2 - bw : bw;  // (one cache slot: the cyclic form of the same (n, bw) is another plan)
+  if (ctx->bcr_key_n != n || ctx->bcr_key_bw != key_bw) {
     VSL_HIP(ctx, hipMemcpyAsync(jobs_dev, flat.data(), flat.size() * sizeof(BcrJob), hipMemcpyHostToDevice, ctx->stream));
     if (!tflat.empty())
       VSL_HIP(ctx, hipMemcpyAsync(targets_dev, tflat.data(), tflat.size() * sizeof(BcrTarget), hipMemcpyHostToDevice, ctx->stream));
-    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` / `tflat` are on this stack frame
+    VSL_HIP(ctx, hipMemcpyAsync(off_dev, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` / `tflat` / `off` are on this stack frame
     ctx->bcr_key_n = n;
-    ctx->bcr_key_bw = bw;
+    ctx->bcr_key_bw = key_bw;
   }
   hipStream_t q = ctx->stream;
-  hipLaunchKernelGGL(bcr_extract_kernel, dim3(64, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, D, K0, bb, pend);
+  hipLaunchKernelGGL(bcr_extract_kernel, dim3(64, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, off_dev, cyclic, D, K0, bb, pend);
   const int tiles = B / 32;
   for (size_t l = 0; l < levels.size(); l++) {
     const int nj = (int)levels[l].size();
     const BcrJob* jl = jobs_dev + job_off[l];
     double* Kl = K0 + k_off[l] * BB;
     double* Kn = l + 1 < levels.size() ? K0 + k_off[l + 1] * BB : nullptr;
+    if (ops[l].combine)
+      hipLaunchKernelGGL(bcr_add_transposed_kernel, dim3((B * B + 255) / 256), dim3(256), 0, q, B, Kl, Kl + BB, ok_dev);
+    if (ops[l].carry && Kn)
+      hipLaunchKernelGGL(bcr_copy_block_kernel, dim3((B * B + 255) / 256), dim3(256), 0, q, B, Kl + (size_t)(ncoup[l] - 1) * BB,
+                         Kn + (size_t)(ncoup[l + 1] - 1) * BB, ok_dev);
     if (B <= 224)
       hipLaunchKernelGGL(bcr_chol_kernel<14>, dim3(nj), dim3(BCR_REG_THREADS), 0, q, jl, B, D, bb, yy, dinv, pend, ok_dev);
     else
@@ -1702,7 +1810,7 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     hipLaunchKernelGGL(bcr_back_gemv_kernel, dim3(nj, BCR_GV_CHUNKS), dim3(256), 0, q, jobs_dev + job_off[l], B, U, bb, yy, ok_dev);
     hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, Linv, bb, ok_dev);
   }
-  hipLaunchKernelGGL(bcr_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, q, bb, n, b, ok_dev);
+  hipLaunchKernelGGL(bcr_gather_kernel, dim3(1, nblk), dim3(256), 0, q, bb, B, off_dev, b, ok_dev);
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
