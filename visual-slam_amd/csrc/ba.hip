@@ -632,7 +632,7 @@ __device__ __forceinline__ int ba_pair_slot(int c1, int c2, int hbp1) {
 // FILL = false: cnt[slot] += 1 per pair; FILL = true: pairs[start[slot] + cursor[slot]++] = (i, j)
 template <bool FILL>
 __global__ void ba_pair_list_kernel(int l_first, int l_count, const int* __restrict__ lm_start, const int* __restrict__ obs_cam,
-                                    const int* __restrict__ cam_free, const int* __restrict__ cam_pos, int hbp1,
+                                    const int* __restrict__ cam_free, const int* __restrict__ cam_pos, int hbp1, int nfree_cyclic,
                                     int* __restrict__ cnt, const int* __restrict__ start, int* __restrict__ pairs) {
   const int l = l_first + blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= l_first + l_count) return;
@@ -643,12 +643,21 @@ __global__ void ba_pair_list_kernel(int l_first, int l_count, const int* __restr
     for (int j = a; j < b; j++) {
       const int cj = cam_free[obs_cam[j]];
       if (cj < 0 || cj > ci) continue;  // (two observations of one landmark by the SAME camera: both orders land in the diagonal block)
-      const int slot = ba_pair_slot(ci, cj, hbp1);
+      int slot, pi = i, pj = j;
+      if (nfree_cyclic > 0 && ci - cj >= hbp1) {
+        // cyclic band: the two cameras are neighbours AROUND the loop -- the block is (cj, ci - nfree), stored in row cj
+        // (the smaller index) at distance cj + nfree - ci, and the roles of the two observations swap with it
+        slot = cj * hbp1 + (cj + nfree_cyclic - ci);
+        pi = j;
+        pj = i;
+      } else {
+        slot = ba_pair_slot(ci, cj, hbp1);
+      }
       const int k = atomicAdd(&cnt[slot], 1);
       if (FILL) {
         const size_t pos = (size_t)start[slot] + k;
-        pairs[2 * pos] = cam_pos[i];  // where W / Y of the observation live (camera-major order)
-        pairs[2 * pos + 1] = cam_pos[j];
+        pairs[2 * pos] = cam_pos[pi];  // where the block of the observation lives (camera-major order)
+        pairs[2 * pos + 1] = cam_pos[pj];
       }
     }
   }
@@ -1310,6 +1319,7 @@ struct BaState {
   // storage -- row i keeps columns [i - bws, i], bws = bw + VSL_CHOL_NB, entry (i, j) at S[i * ldS + j + offS] with
   // ldS = offS = bws (chol.hip "BAND FORM").  The free-camera numbering IS the band order.
   bool banded = false;
+  bool cyclic = false;  // band form whose band closes on itself (camera loop in trajectory order): wrap blocks in the leading slots of the first rows
   int ldS = 0, offS = 0, bw = 0;
   size_t s_elems = 0;  // doubles to allocate / clear / exchange for S
   double* S_eff() { return (double*)S.p + offS; }
@@ -1387,7 +1397,8 @@ void host_parallel(int n, Fn fn, int min_parallel = 1 << 19) {
 // order).  order[position] = free index in ascending-camera numbering; returns the block half-bandwidth (max
 // |position difference| over the edges).  A 500-keyframe loop comes out as a band of a few dozen cameras with no
 // corner blocks (the breadth-first levels run both ways round the loop).
-int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free0, int nfree, std::vector<int>& order) {
+int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free0, int nfree, std::vector<int>& order,
+                      int* half_cyclic_natural = nullptr) {
   const size_t words = ((size_t)nfree + 63) / 64;
   std::vector<uint64_t> adj((size_t)nfree * words, 0);
   {
@@ -1472,6 +1483,17 @@ int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free
   int half = 0;
   for (int c = 0; c < nfree; c++)
     for (int v : nb[c]) half = std::max(half, std::abs(pos[c] - pos[v]));
+  if (half_cyclic_natural) {
+    // the cameras as they come (ascending index = the reference's keyframe order, i.e. along the trajectory), distances
+    // taken AROUND the ring: a closed loop has half the bandwidth of its best linear order this way
+    int hc = 0;
+    for (int c = 0; c < nfree; c++)
+      for (int v : nb[c]) {
+        const int d = std::abs(c - v);
+        hc = std::max(hc, std::min(d, nfree - d));
+      }
+    *half_cyclic_natural = hc;
+  }
   return half;
 }
 
@@ -1519,9 +1541,23 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   st.s_elems = (size_t)D.n * D.n;
   if (allow_band && D.n > 128 && !ctx->ba_force_dense) {
     std::vector<int> order;
-    const int half = camera_band_order(graph_prob ? graph_prob : p, cam_free, D.nfree, order);
+    int half_cyc = 0;
+    const int half = camera_band_order(graph_prob ? graph_prob : p, cam_free, D.nfree, order, &half_cyc);
     const int bw = 6 * half + 5, bws = bw + VSL_CHOL_NB;
-    if ((size_t)(bws + 1) * 2 < (size_t)D.n) {  // worth it: the band holds less than half of the matrix
+    // CYCLIC band (round 4): in the cameras' own order with distances around the ring.  Taken when the ring solver has a
+    // block layout for it and its blocks are at most 3/4 of the linear form's (the solve costs ~ block size squared per
+    // level): the 500-keyframe loop of configs[4] has half bandwidth 18 cameras around the ring, 36 in its best line
+    const int bwc = 6 * half_cyc + 5, B_lin = (bw + 1 + 31) / 32 * 32;
+    int B_cyc = 0, nblk_cyc = 0;
+    static const bool env_no_cyclic = getenv("VSL_BA_NO_CYCLIC") != nullptr;
+    if (!ctx->ba_no_cyclic && !env_no_cyclic && !ctx->ba_schur_atomics && !ctx->chol_no_bcr && !ctx->chol_no_fused &&
+        vsl_chol_bcr_cyclic_layout(D.n, bwc, &B_cyc, &nblk_cyc) && 4 * B_cyc <= 3 * B_lin) {
+      st.banded = true;
+      st.cyclic = true;
+      st.bw = bwc;
+      st.ldS = st.offS = bwc + VSL_CHOL_NB;
+      st.s_elems = (size_t)D.n * (bwc + VSL_CHOL_NB + 1) + 64;
+    } else if ((size_t)(bws + 1) * 2 < (size_t)D.n) {  // worth it: the band holds less than half of the matrix
       std::vector<int> renum(D.nfree);
       for (int k = 0; k < D.nfree; k++) renum[k] = free_cams[order[k]];
       free_cams = renum;
@@ -1534,7 +1570,7 @@ int ba_setup(vsl_ctx* ctx, const vsl_ba_problem* p, const vsl_ba_options* o, BaS
   }
   // (diagnostic read-out for benchmarks: vsl_ctx_last_ba_layout)
   ctx->last_ba_s_elems = (int64_t)st.s_elems;
-  ctx->last_ba_banded = st.banded ? 1 : 0;
+  ctx->last_ba_banded = st.cyclic ? 2 : (st.banded ? 1 : 0);
   ctx->last_ba_bw = st.bw;
   tr.lap("free cameras + band order");
   // sort observations by landmark (stable: keeps the caller's order inside a landmark).  The reference's own order
@@ -1775,13 +1811,13 @@ int ba_pair_lists(vsl_ctx* ctx, BaState& st, int l0, int lc) {
   VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
   hipLaunchKernelGGL(ba_pair_list_kernel<false>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
                      st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
-                     st.pair_cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
+                     st.cyclic ? st.D.nfree : 0, st.pair_cnt.as<int>(), (const int*)nullptr, (int*)nullptr);
   hipLaunchKernelGGL(ba_pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, st.n_slots, st.pair_cnt.as<int>(),
                      st.pair_start.as<int>());
   VSL_HIP(ctx, hipMemsetAsync(st.pair_cnt.p, 0, sizeof(int) * ((size_t)st.n_slots + 1), ctx->stream));
   hipLaunchKernelGGL(ba_pair_list_kernel<true>, dim3((lc + 255) / 256), dim3(256), 0, ctx->stream, l0, lc,
                      st.lm_start.as<int>(), st.obs_cam.as<int>(), st.cam_free.as<int>(), st.cam_pos.as<int>(), st.hbp1,
-                     st.pair_cnt.as<int>(), st.pair_start.as<int>(), st.pairs.as<int>());
+                     st.cyclic ? st.D.nfree : 0, st.pair_cnt.as<int>(), st.pair_start.as<int>(), st.pairs.as<int>());
   hipLaunchKernelGGL(ba_pair_sort_kernel, dim3(st.n_slots), dim3(64), 0, ctx->stream, st.pair_start.as<int>(),
                      st.pairs.as<int>());
   VSL_CHECK_LAUNCH(ctx);
@@ -1863,7 +1899,7 @@ int ba_solve_enqueue(vsl_ctx* ctx, BaState& st) {
     hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, ctx->stream, n, st.S.as<double>(), st.rhs.as<double>(),
                        st.dc.as<double>(), st.flag.as<int>() + 1, st.flag.as<int>());
   } else {
-    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>() + 1);
+    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>() + 1, st.cyclic ? 1 : 0);
     if (rc) return rc;
     hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
   }
@@ -1886,7 +1922,7 @@ int ba_solve(vsl_ctx* ctx, BaState& st, bool& ok) {
     VSL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
     // blocked right-looking Cholesky + substitutions (chol.hip); rhs <- S^-1 rhs
-    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>());
+    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>(), st.cyclic ? 1 : 0);
     if (rc) return rc;
     hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
     VSL_CHECK_LAUNCH(ctx);
@@ -2754,7 +2790,7 @@ extern "C" int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduc
   sum.total_ms = now_ms() - t_start;
   if (verbosity >= 1)
     fprintf(stderr, "vsl global BA (%d rank%s, %s system, bandwidth %d of %d): iterations %d, initial cost %.6e, final cost %.6e, termination %d, %.3f ms\n",
-            world, world > 1 ? "s" : "", st.banded ? "band" : "dense", st.bw, n, sum.iterations, sum.initial_cost, sum.final_cost,
+            world, world > 1 ? "s" : "", st.cyclic ? "cyclic band" : (st.banded ? "band" : "dense"), st.bw, n, sum.iterations, sum.initial_cost, sum.final_cost,
             sum.termination, sum.total_ms);
   if (summary) *summary = sum;
   return VSL_OK;

@@ -681,8 +681,9 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
 // Solves S x = b in place (S destroyed, b <- x).  *ok_dev = 1 on success, 0 if S is not SPD.
 // Dense: ld = n, bw = n.  Band: S = storage + bws, ld = bws = bw + CH_NB (see the file header); bw = the largest
 // i - c of a non-zero entry.
-int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
+int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic) {
   const int one = 1;
+  if (cyclic) return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev, 1);  // (the caller has checked the layout)
   const int n_panels = (n + CH_NB - 1) / CH_NB;
   if (ld != n && !ctx->chol_no_fused && !ctx->chol_no_bcr && (bw + 1 + 31) / 32 * 32 <= BCR_MAXB &&
       n >= 8 * ((bw + 1 + 31) / 32 * 32))  // long narrow band: block cyclic reduction over the whole chip

@@ -28,6 +28,7 @@ extern "C" int vsl_ctx_set_diagnostic(vsl_ctx* ctx, const char* name, int value)
   else if (k == "bow_no_wg_score") ctx->bow_no_wg_score = value != 0;
   else if (k == "ba_no_fused") ctx->ba_no_fused = value != 0;
   else if (k == "ba_host_lm") ctx->ba_host_lm = value != 0;
+  else if (k == "ba_no_cyclic") ctx->ba_no_cyclic = value != 0;
   else if (k == "ba_schur_atomics") ctx->ba_schur_atomics = value != 0;
   else if (k == "ba_force_dense") ctx->ba_force_dense = value != 0;
   else if (k == "chol_no_fused") ctx->chol_no_fused = value != 0;

@@ -84,6 +84,7 @@ struct vsl_ctx {
   bool ba_no_fused = false;             // diagnostic: local windows by the operator-by-operator kernels of ba.hip instead of the fused iteration (ba_fused.hip)
   bool ba_schur_entries = false;        // diagnostic: single-entry ownership in the small-system Schur kernel instead of 3 x 3 sub-blocks
   int describe_tile_min_images = 96;   // describe launches of at least this many images use the shared-tile kernel (measured break-even ~64 images; diagnostic: 1 forces it, 0 disables it)
+  bool ba_no_cyclic = false;            // diagnostic: large reduced camera systems in the linear band form (reverse Cuthill-McKee order) even when the cyclic form is narrower
   bool ba_host_lm = false;              // diagnostic: the fused local iteration with the Levenberg-Marquardt decision on the HOST (one synchronisation per iteration) instead of on the device (ba_fused.hip baf_decide_kernel)
   bool bow_no_wg_score = false;         // diagnostic: wave-per-candidate scoring kernel also for few candidates
   bool bow_keys64 = false;              // diagnostic: 64-bit sort keys in the BowVector assembly even where (id, feature) fits 32 bits
@@ -193,7 +194,8 @@ int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_
 int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev);
 // the same on LAPACK-style lower band storage (chol.hip, "BAND FORM"): S = storage + bws, ld = bws = bw + VSL_CHOL_NB
 #define VSL_CHOL_NB 32
-int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev);
+int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic = 0);
+bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out);  // chol.hip: is there a ring of blocks for this cyclic band?
 
 // scratch store of the host-buffer API
 int vsl_ctx_scratch_frames(vsl_ctx* ctx, int w, int h, int feat, vsl_frames** out);
