@@ -245,7 +245,7 @@ def global_ba_multi_rank(args, vsl, ctx, synth, vdist, rank, world, backend):
     sg, a = last
     return {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d, %s"
                         % (len(dg["poses"]), int(dg["cam_fixed"].sum()), len(dg["points"]), len(dg["obs_cam"]), n_red, n_red,
-                           ("band form, half bandwidth %d" % bw) if banded else "dense"),
+                           ("%sband form, half bandwidth %d" % ("cyclic " if banded == 2 else "", bw)) if banded else "dense"),
             "world": world, "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (host memory: a rehearsal, not xGMI)"),
             "partition": "landmarks in contiguous ranges balanced by observation count, poses replicated; every rank factorises "
                          "the all-reduced system redundantly",
@@ -862,10 +862,13 @@ def main():
             g_iters = max(sgp.iterations, 1)
             g_dev = {k: round(stg_g[k][0] / g_iters, 4) for k in ("ba_linearize", "ba_schur", "ba_solve", "ba_step")
                      if stg_g.get(k, (0, 0))[1] > 0}
-            out["global_ba"] = {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d; "
+            lay0 = ctx.last_ba_layout()
+            out["global_ba"] = {"workload": "%d cameras (%d fixed), %d landmarks, %d observations; reduced system %d x %d, %s; "
                                             "session API, 1 rank" % (len(dg["poses"]), int(dg["cam_fixed"].sum()), len(dg["points"]),
                                                                      len(dg["obs_cam"]), 6 * int((dg["cam_fixed"] == 0).sum()),
-                                                                     6 * int((dg["cam_fixed"] == 0).sum())),
+                                                                     6 * int((dg["cam_fixed"] == 0).sum()),
+                                                                     ("%sband form, half bandwidth %d" % ("cyclic " if lay0[1] == 2 else "", lay0[2]))
+                                                                     if lay0[1] else "dense"),
                                "ms_per_lm_iteration_marginal": round(1e3 * (t12 - t3) / max(i12 - i3, 1), 2),
                                "marginal_is": "(solver clock of the 12-iteration solve - of the 3-iteration solve) / 9, best of three each",
                                "ms_per_lm_iteration_marginal_wall": round(1e3 * (t12w - t3w) / max(i12 - i3, 1), 2),

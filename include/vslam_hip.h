@@ -399,8 +399,9 @@ int vsl_ba_session_accept(vsl_ba_session* s);
 int vsl_ba_session_download(vsl_ba_session* s, double* poses, double* points_own);
 /* Layout of the reduced camera system inside packB: *s_elems doubles -- n * n when dense; in band form (cameras
  * renumbered into a narrow band by reverse Cuthill-McKee on the covisibility graph of the FULL problem, identically
- * on every rank) n * (bandwidth + 33) + 64 -- followed by rhs / diag H / g_c (n each), cost, 0.  Wherever this header
- * says "n*n" for packB read *s_elems. */
+ * on every rank; *banded = 1) or in CYCLIC band form (cameras as they came, the band closes around the loop -- the wrap
+ * blocks sit in the leading slots of the first rows; *banded = 2) n * (bandwidth + 33) + 64 -- followed by rhs / diag H /
+ * g_c (n each), cost, 0.  Wherever this header says "n*n" for packB read *s_elems. */
 int vsl_ba_session_layout(const vsl_ba_session* s, int64_t* s_elems, int* banded, int* bandwidth);
 
 /* The whole Levenberg-Marquardt loop over a session, host code in C++.  Collectives go through ONE caller-supplied
@@ -416,7 +417,9 @@ int vsl_ba_session_solve(vsl_ba_session* s, vsl_allreduce_fn allreduce, void* us
 int vsl_global_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const vsl_ba_options* opt,
                              vsl_allreduce_fn allreduce, void* user, int rank, int world, vsl_ba_summary* summary);
 /* Diagnostic: storage of the reduced camera system in the last solve the general path (vsl_bundle_adjust beyond the
- * local window, sessions, vsl_global_bundle_adjust) set up on this context: doubles of S, band form or dense, bandwidth. */
+ * local window, sessions, vsl_global_bundle_adjust) set up on this context: doubles of S, *banded = 0 dense / 1 band (cameras
+ * in reverse Cuthill-McKee order) / 2 cyclic band (cameras as they came, the band closes around the loop), bandwidth.
+ * Diagnostic "ba_no_cyclic" / VSL_BA_NO_CYCLIC keep form 1 where form 2 would be taken. */
 int vsl_ctx_last_ba_layout(vsl_ctx* ctx, int64_t* s_elems, int* banded, int* bandwidth);
 /* Plain synchronous copy on the context's device (kind 0 host->device, 1 device->host, 2 device->device): for
  * callers that hold device pointers handed out by this library (all-reduce callbacks). */

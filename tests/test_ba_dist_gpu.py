@@ -200,6 +200,23 @@ def test_global_ba_full_size_properties(vsl, orc, synth):
     assert s_band.initial_cost == pytest.approx(s_dense.initial_cost, rel=1e-12)
     assert s_band.final_cost == pytest.approx(s_dense.final_cost, rel=1e-9)
     assert s_band.final_cost < 0.3 * s_band.initial_cost
+    # the default form of this closed loop is the CYCLIC band (cameras in trajectory order, distances around the ring:
+    # less than half the bandwidth of the best linear order); the linear band form ("ba_no_cyclic": reverse
+    # Cuthill-McKee) is the same optimisation
+    a_cyc = _arr(orc, d)
+    ba_dist.bundle_adjust_distributed(vsl, c, a_cyc, max_iters=1)
+    _, banded_cyc, bw_cyc = c.last_ba_layout()
+    c.set_diagnostic("ba_no_cyclic", 1)
+    try:
+        a_lin = _arr(orc, d)
+        s_lin = ba_dist.bundle_adjust_distributed(vsl, c, a_lin, max_iters=6)
+        _, banded_lin, bw_lin = c.last_ba_layout()
+    finally:
+        c.set_diagnostic("ba_no_cyclic", 0)
+    assert banded_cyc == 2 and banded_lin == 1 and 2 * bw_cyc < bw_lin
+    assert (s_lin.iterations, s_lin.termination, s_lin.successful_steps) == (s_band.iterations, s_band.termination, s_band.successful_steps)
+    assert s_lin.final_cost == pytest.approx(s_band.final_cost, rel=1e-9)
+    assert np.allclose(a_lin.poses, a_band.poses, rtol=0, atol=1e-7)
     fixed = d["cam_fixed"].astype(bool)
     assert np.array_equal(a_band.poses[fixed], d["poses"][fixed])
     assert np.allclose(a_band.poses, a_dense.poses, rtol=0, atol=1e-6)

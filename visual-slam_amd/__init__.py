@@ -145,10 +145,12 @@ class Context:
         self._ck(self.L.vsl_ctx_set_profiling(self.h, int(on)))
 
     def last_ba_layout(self):
-        """(doubles of S, banded, bandwidth) of the last general-path bundle adjustment set up on this context."""
+        """(doubles of S, band form, bandwidth) of the last general-path bundle adjustment set up on this context; band form
+        0 = dense, 1 = band (cameras in reverse Cuthill-McKee order), 2 = cyclic band (cameras as they came, the band
+        closes around the loop)."""
         e, b, w = C.c_int64(), C.c_int(), C.c_int()
         self._ck(self.L.vsl_ctx_last_ba_layout(self.h, C.byref(e), C.byref(b), C.byref(w)))
-        return e.value, bool(b.value), w.value
+        return e.value, b.value, w.value
 
     def reset_profiling(self):
         self._ck(self.L.vsl_ctx_reset_profiling(self.h))

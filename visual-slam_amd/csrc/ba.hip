@@ -2477,7 +2477,7 @@ extern "C" int vsl_ba_session_dims(const vsl_ba_session* s, int* n, int* n_lms_o
 extern "C" int vsl_ba_session_layout(const vsl_ba_session* s, int64_t* s_elems, int* banded, int* bandwidth) {
   if (!s) return VSL_ERR_INVALID;
   if (s_elems) *s_elems = (int64_t)s->st.s_elems;
-  if (banded) *banded = s->st.banded ? 1 : 0;
+  if (banded) *banded = s->st.cyclic ? 2 : (s->st.banded ? 1 : 0);
   if (bandwidth) *bandwidth = s->st.bw;
   return VSL_OK;
 }
