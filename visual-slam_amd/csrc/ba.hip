@@ -1890,18 +1890,20 @@ int ba_schur(vsl_ctx* ctx, BaState& st, bool damp, double radius, int l0, int lc
 }
 
 // dc = -(S^-1 rhs), enqueued only: flag[0] = 1 (the finite check clears it), flag[1] = Cholesky succeeded.
-int ba_solve_enqueue(vsl_ctx* ctx, BaState& st) {
+// flags_set: the caller's previous kernel has set both flags (saves the launch)
+int ba_solve_enqueue(vsl_ctx* ctx, BaState& st, bool flags_set = false) {
   const int n = st.D.n;
   VslStage s(ctx, VSL_STAGE_BA_SOLVE);
-  if (n == 0 || n > 128) hipLaunchKernelGGL(ba_set_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, st.flag.as<int>());
+  if ((n == 0 || n > 128) && !flags_set) hipLaunchKernelGGL(ba_set_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, st.flag.as<int>());
   if (n == 0) return VSL_OK;
   if (n <= 128) {
     hipLaunchKernelGGL(ba_chol_small_kernel, dim3(1), dim3(256), 0, ctx->stream, n, st.S.as<double>(), st.rhs.as<double>(),
                        st.dc.as<double>(), st.flag.as<int>() + 1, st.flag.as<int>());
   } else {
-    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>() + 1, st.cyclic ? 1 : 0);
+    // dc = -(S^-1 rhs): the solver writes the negated solution as well
+    int rc = vsl_chol_solve_band_dev(ctx, st.S_eff(), st.rhs.as<double>(), n, st.ldS, st.bw, st.flag.as<int>() + 1, st.cyclic ? 1 : 0,
+                                     st.dc.as<double>());
     if (rc) return rc;
-    hipLaunchKernelGGL(ba_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.rhs.as<double>(), st.dc.as<double>());
   }
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
@@ -1965,12 +1967,11 @@ int bal_init_pass(vsl_ctx* ctx, BaState& st) {
   hipLaunchKernelGGL(bal_prep_kernel<true>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, (const int*)nullptr, 0.0,
                      (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, st.n2l.as<double>(),
                      st.lpart.as<double>());
-  hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
-                     st.scalars.as<double>(), (double*)nullptr);
   hipLaunchKernelGGL(bal_cam_kernel<true>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
                      st.cam_start.as<int>(), st.cam_lm.as<int>(), st.cam_uv.as<double>(), (const double*)nullptr, st.cam_part.as<double>());
   hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 0,
-                     st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
+                     st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>(), st.n_wg,
+                     st.lpart.as<double>(), st.scalars.as<double>(), (double*)nullptr);
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
@@ -1987,24 +1988,21 @@ int bal_reduce(vsl_ctx* ctx, BaState& st, double radius, double* gl_out) {
   hipLaunchKernelGGL(bal_prep_kernel<false>, dim3(st.n_wg), dim3(BL_THREADS), 0, ctx->stream, a, st.cam_pos.as<int>(),
                      1.0 / radius, st.Yg.as<double>(), st.Pinv.as<double>(), st.bl.as<double>(), st.pbs.as<double>(),
                      (double*)nullptr, st.lpart.as<double>());
-  hipLaunchKernelGGL(bal_prep_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
-                     st.scalars.as<double>(), gl_out);
   hipLaunchKernelGGL(bal_cam_kernel<false>, dim3(D.nfree, st.bl_seg), dim3(256), 0, ctx->stream, a, st.free_cams.as<int>(),
                      st.cam_start.as<int>(), st.cam_lm.as<int>(), st.cam_uv.as<double>(), st.pbs.as<double>(), st.cam_part.as<double>());
   hipLaunchKernelGGL(bal_cam_finish_kernel, dim3((D.nfree * 33 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.bl_seg, 1,
-                     st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>());
+                     st.cam_part.as<double>(), st.H.as<double>(), st.g_c.as<double>(), st.rhs.as<double>(), st.n_wg,
+                     st.lpart.as<double>(), st.scalars.as<double>(), gl_out);
   hipLaunchKernelGGL(ba_schur_gather_kernel, dim3(gather_grid(st)), dim3(64), 0, ctx->stream, st.n_slots, st.hbp1,
                      st.pair_start.as<int>(), st.pairs.as<int>(), st.Yg.as<double>(), st.Yg.as<double>(), st.S_eff(), st.ldS,
                      st.banded ? 2 : (D.n > 128 ? 1 : 0));  // n <= 128 is solved by ba_chol_small_kernel (full matrix)
-  hipLaunchKernelGGL(ba_add_cam_blocks_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree,
-                     st.H.as<double>(), st.g_c.as<double>(), (const double*)nullptr, 0.0, st.S_eff(), st.rhs.as<double>(),
-                     st.ldS, st.banded ? 1 : 0);
+  // (the camera blocks are added by the caller together with the packing: sess_add_pack_kernel)
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
 
 // recompute form: candidate (cand_poses, cand_points) from dc, scalars[2..7] as the operator-by-operator chain leaves them
-int bal_step(vsl_ctx* ctx, BaState& st) {
+int bal_step(vsl_ctx* ctx, BaState& st, double* packC_dev) {
   const BaDims& D = st.D;
   VslStage s(ctx, VSL_STAGE_BA_STEP);
   const BlArgs a = bal_args(st);
@@ -2015,7 +2013,7 @@ int bal_step(vsl_ctx* ctx, BaState& st) {
                      st.bl.as<double>(), st.dc.as<double>(), st.cand_poses.as<double>(), st.cand_points.as<double>(),
                      st.lpart.as<double>(), st.flag.as<int>());
   hipLaunchKernelGGL(bal_step_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, st.n_wg, st.lpart.as<double>(),
-                     st.scalars.as<double>());
+                     st.scalars.as<double>(), st.flag.as<int>(), packC_dev);
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }
@@ -2331,12 +2329,38 @@ __global__ void sess_pack_b_kernel(int nfree, const double* __restrict__ rhs, co
   }
 }
 
+// ba_add_cam_blocks_kernel (no camera damping) and sess_pack_b_kernel in one launch: S += blockdiag(H), rhs += g_c, and
+// the tail of packB from the sums
+__global__ void sess_add_pack_kernel(int nfree, const double* __restrict__ H, const double* __restrict__ g_c,
+                                     const double* __restrict__ scalars, double* __restrict__ S, double* __restrict__ rhs, int ldS,
+                                     int lower_elems, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = 6 * nfree;
+  if (t < nfree * 36) {
+    const int fc = t / 36, x = (t % 36) / 6, y = t % 6;
+    if (!(lower_elems && y > x)) S[(size_t)(6 * fc + x) * ldS + 6 * fc + y] += H[t];
+  }
+  if (t < n) {
+    const double r = rhs[t] + g_c[t];
+    rhs[t] = r;
+    out[t] = r;
+    out[n + t] = H[36 * (size_t)(t / 6) + 7 * (t % 6)];
+    out[2 * n + t] = g_c[t];
+  }
+  if (t == 0) {
+    out[3 * n] = scalars[0];
+    out[3 * n + 1] = 0.0;
+  }
+}
+
 // S = S_full + diag(diag_c / radius); diag_c = clamp(diag H_full) when refresh, else kept.  S_full (the first
 // `elems` doubles of packB, dense or band layout) has been copied into S already; this adds the damping to the
 // diagonal (entry (i, i) at S_eff[i * ldS + i]) and unpacks rhs.
 __global__ void sess_damp_kernel(int n, size_t elems, const double* __restrict__ packB, double inv_radius, int refresh,
-                                 double* __restrict__ diag_keep, double* __restrict__ S_eff, int ldS, double* __restrict__ rhs) {
+                                 double* __restrict__ diag_keep, double* __restrict__ S_eff, int ldS, double* __restrict__ rhs,
+                                 int* __restrict__ flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (flags && i < 2) flags[i] = 1;  // (step finite / factorisation succeeded: what ba_set_flags_kernel would set)
   if (i < n) {
     double d = diag_keep[i];
     if (refresh) {
@@ -2548,7 +2572,13 @@ extern "C" int vsl_ba_session_reduce_dev(vsl_ba_session* s, double radius, doubl
     VSL_HIP(ctx, hipMemsetAsync(st.diag_c.p, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), ctx->stream));
     if ((rc = ba_schur(ctx, st, true, radius, 0, D.L, true, true))) return rc;
   }
-  if (n > 0) {
+  if (n > 0 && st.large_fused) {
+    hipLaunchKernelGGL(sess_add_pack_kernel, dim3((D.nfree * 36 + 255) / 256), dim3(256), 0, ctx->stream, D.nfree, st.H.as<double>(),
+                       st.g_c.as<double>(), st.scalars.as<double>(), st.S_eff(), st.rhs.as<double>(), st.ldS, st.banded ? 1 : 0,
+                       packB_dev + st.s_elems);
+    VSL_CHECK_LAUNCH(ctx);
+    if (!s->solo) VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (n > 0) {
     if (!s->solo) VSL_HIP(ctx, hipMemcpyAsync(packB_dev, st.S.p, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(sess_pack_b_kernel, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, D.nfree, st.rhs.as<double>(),
                        st.H.as<double>(), st.g_c.as<double>(), st.scalars.as<double>(), packB_dev + st.s_elems);
@@ -2570,17 +2600,16 @@ extern "C" int vsl_ba_session_step_dev(vsl_ba_session* s, const double* packB_fu
   if (n > 0) {
     if (!s->solo) VSL_HIP(ctx, hipMemcpyAsync(st.S.p, packB_full_dev, sizeof(double) * st.s_elems, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(sess_damp_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, st.s_elems, packB_full_dev, 1.0 / radius,
-                       refresh_diag, s->diagc_keep.as<double>(), st.S_eff(), st.ldS, st.rhs.as<double>());
+                       refresh_diag, s->diagc_keep.as<double>(), st.S_eff(), st.ldS, st.rhs.as<double>(),
+                       st.large_fused ? st.flag.as<int>() : (int*)nullptr);
     VSL_CHECK_LAUNCH(ctx);
   }
   int rc;
   if (st.large_fused) {
     // everything is enqueued, nothing is read back here: a failed factorisation leaves flag[1] = 0 and numbers nobody
     // uses (the caller's one read of packC per iteration sees the step as unusable)
-    if ((rc = ba_solve_enqueue(ctx, st))) return rc;
-    if ((rc = bal_step(ctx, st))) return rc;
-    hipLaunchKernelGGL(sess_pack_c_kernel, dim3(1), dim3(64), 0, ctx->stream, st.scalars.as<double>(), st.flag.as<int>(), 1, packC_dev);
-    VSL_CHECK_LAUNCH(ctx);
+    if ((rc = ba_solve_enqueue(ctx, st, n > 0))) return rc;
+    if ((rc = bal_step(ctx, st, packC_dev))) return rc;  // (packC written by the step's last kernel)
     return VSL_OK;
   }
   bool ok = true;

@@ -259,31 +259,6 @@ __global__ __launch_bounds__(BL_THREADS) void bal_prep_kernel(BlArgs a, const in
   }
 }
 
-// (cost, max |landmark gradient|) of the workgroups -> scalars[0], gl_out[0] (when given).  One workgroup.
-__global__ __launch_bounds__(256) void bal_prep_finish_kernel(int G, const double* __restrict__ part,
-                                                              double* __restrict__ scalars, double* __restrict__ gl_out) {
-  __shared__ double sh[2][256];
-  double c = 0.0, g = 0.0;
-  for (int i = threadIdx.x; i < G; i += 256) {
-    c += part[i];
-    g = fmax(g, part[G + i]);
-  }
-  sh[0][threadIdx.x] = c;
-  sh[1][threadIdx.x] = g;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-      sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + o]);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    scalars[0] = sh[0][0];
-    if (gl_out) gl_out[0] = sh[1][0];
-  }
-}
-
 // camera-major copies of (landmark, pixel) for bal_cam_kernel: once per session
 __global__ void bal_cam_major_kernel(int O, const int* __restrict__ cam_obs, const int* __restrict__ obs_lm,
                                      const double* __restrict__ obs_uv, int* __restrict__ cam_lm, double* __restrict__ cam_uv) {
@@ -347,28 +322,55 @@ __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __res
     part[((size_t)fc * nseg + seg) * 33 + threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
 }
 
-// segments summed in order: H (6 x 6, both triangles), g_c, and rhs = -(sum Y b) (ba_add_cam_blocks_kernel adds g_c)
-__global__ void bal_cam_finish_kernel(int nfree, int nseg, int with_rhs, const double* __restrict__ part,
-                                      double* __restrict__ H, double* __restrict__ g, double* __restrict__ rhs) {
+// segments summed in order: H (6 x 6, both triangles), g_c, and rhs = -(sum Y b) (the camera blocks are added to S
+// afterwards).  The LAST workgroup also folds bal_prep_kernel's per-workgroup (cost, max |landmark gradient|) into
+// scalars[0] / gl_out[0] (lpart given: what bal_prep_finish_kernel does as a launch of its own).
+__global__ __launch_bounds__(256) void bal_cam_finish_kernel(int nfree, int nseg, int with_rhs, const double* __restrict__ part,
+                                                             double* __restrict__ H, double* __restrict__ g,
+                                                             double* __restrict__ rhs, int G, const double* __restrict__ lpart,
+                                                             double* __restrict__ scalars, double* __restrict__ gl_out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nfree * 33) return;
-  const int fc = t / 33, k = t - fc * 33;
-  if (k >= 27 && !with_rhs) return;
-  double v = 0;
-  for (int sgm = 0; sgm < nseg; sgm++) v += part[((size_t)fc * nseg + sgm) * 33 + k];
-  if (k >= 27) {
-    rhs[6 * (size_t)fc + (k - 27)] = -v;
-  } else if (k >= 21) {
-    g[6 * (size_t)fc + (k - 21)] = v;
-  } else {
-    int x = 0, rem = k;  // k-th entry of the upper triangle, row-major
-    while (rem >= 6 - x) {
-      rem -= 6 - x;
-      x++;
+  if (t < nfree * 33) {
+    const int fc = t / 33, k = t - fc * 33;
+    if (k < 27 || with_rhs) {
+      double v = 0;
+      for (int sgm = 0; sgm < nseg; sgm++) v += part[((size_t)fc * nseg + sgm) * 33 + k];
+      if (k >= 27) {
+        rhs[6 * (size_t)fc + (k - 27)] = -v;
+      } else if (k >= 21) {
+        g[6 * (size_t)fc + (k - 21)] = v;
+      } else {
+        int x = 0, rem = k;  // k-th entry of the upper triangle, row-major
+        while (rem >= 6 - x) {
+          rem -= 6 - x;
+          x++;
+        }
+        const int y = x + rem;
+        H[36 * (size_t)fc + 6 * x + y] = v;
+        H[36 * (size_t)fc + 6 * y + x] = v;
+      }
     }
-    const int y = x + rem;
-    H[36 * (size_t)fc + 6 * x + y] = v;
-    H[36 * (size_t)fc + 6 * y + x] = v;
+  }
+  if (!lpart || blockIdx.x != gridDim.x - 1) return;
+  __shared__ double sh[2][256];
+  double c = 0.0, gm = 0.0;
+  for (int i = threadIdx.x; i < G; i += 256) {
+    c += lpart[i];
+    gm = fmax(gm, lpart[G + i]);
+  }
+  sh[0][threadIdx.x] = c;
+  sh[1][threadIdx.x] = gm;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    scalars[0] = sh[0][0];
+    if (gl_out) gl_out[0] = sh[1][0];
   }
 }
 
@@ -525,9 +527,10 @@ __global__ __launch_bounds__(BL_THREADS) void bal_step_kernel(BlArgs a, const do
 }
 
 // scalars[2] = model change, [3] / [4] = squared step / x norms (landmarks + cameras), [5] = candidate cost.  One
-// workgroup; scalars[6] / [7] were written by bal_pose_kernel.
+// workgroup; scalars[6] / [7] were written by bal_pose_kernel.  packC (nullable): the session's step record as well.
 __global__ __launch_bounds__(256) void bal_step_finish_kernel(int G, const double* __restrict__ part,
-                                                              double* __restrict__ scalars) {
+                                                              double* __restrict__ scalars, const int* __restrict__ flag,
+                                                              double* __restrict__ packC) {
   __shared__ double sh[4][256];
   double v[4] = {0, 0, 0, 0};
   for (int i = threadIdx.x; i < G; i += 256)
@@ -543,10 +546,21 @@ __global__ __launch_bounds__(256) void bal_step_finish_kernel(int G, const doubl
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    const double s6 = scalars[6], s7 = scalars[7];
     scalars[2] = sh[0][0];
-    scalars[3] = sh[1][0] + scalars[6];
-    scalars[4] = sh[2][0] + scalars[7];
+    scalars[3] = sh[1][0] + s6;
+    scalars[4] = sh[2][0] + s7;
     scalars[5] = sh[3][0];
+    if (packC) {  // the session's packC (sess_pack_c_kernel's layout; flag[0] = step finite, flag[1] = factorisation succeeded)
+      packC[0] = (flag[0] && flag[1]) ? 0.0 : 1.0;
+      packC[1] = sh[0][0];
+      packC[2] = sh[1][0] + s6;
+      packC[3] = sh[2][0] + s7;
+      packC[4] = sh[3][0];
+      packC[5] = s6;
+      packC[6] = s7;
+      packC[7] = 0.0;
+    }
   }
 }
 

@@ -676,18 +676,33 @@ __global__ __launch_bounds__(CBF_THREADS) void cbf2_backward_kernel(CbfView top,
 }
 
 #define BCR_MAXB 256  // block size limit of the cyclic reduction: static LDS Us[256][33] + Lp[32][257] = 133 KB (dynamic LDS above 64 KiB is refused by the runtime)
-int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic);
+int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic, double* neg_out = nullptr);
 
 // Solves S x = b in place (S destroyed, b <- x).  *ok_dev = 1 on success, 0 if S is not SPD.
 // Dense: ld = n, bw = n.  Band: S = storage + bws, ld = bws = bw + CH_NB (see the file header); bw = the largest
 // i - c of a non-zero entry.
-int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic) {
-  const int one = 1;
-  if (cyclic) return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev, 1);  // (the caller has checked the layout)
-  const int n_panels = (n + CH_NB - 1) / CH_NB;
+__global__ void chol_negate_kernel(int n, const double* __restrict__ x, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = -x[i];
+}
+int vsl_chol_solve_band_impl(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev);
+// neg_out (nullable): -x as well (the bundle adjustment's step is the negated solution: saves its launch on the BCR path)
+int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic, double* neg_out) {
+  if (cyclic) return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev, 1, neg_out);  // (the caller has checked the layout)
   if (ld != n && !ctx->chol_no_fused && !ctx->chol_no_bcr && (bw + 1 + 31) / 32 * 32 <= BCR_MAXB &&
       n >= 8 * ((bw + 1 + 31) / 32 * 32))  // long narrow band: block cyclic reduction over the whole chip
-    return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev, 0);
+    return vsl_chol_solve_bcr_dev(ctx, S, b, n, ld, bw, ok_dev, 0, neg_out);
+  const int rc = vsl_chol_solve_band_impl(ctx, S, b, n, ld, bw, ok_dev);
+  if (rc == VSL_OK && neg_out) {
+    hipLaunchKernelGGL(chol_negate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, b, neg_out);
+    VSL_CHECK_LAUNCH(ctx);
+  }
+  return rc;
+}
+
+int vsl_chol_solve_band_impl(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev) {
+  const int one = 1;
+  const int n_panels = (n + CH_NB - 1) / CH_NB;
   if (ld != n && bw <= CBF_MAXBW && !ctx->chol_no_fused) {  // narrow band: one launch for the whole solve, or two-ended
     VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     const bool two_ended = !ctx->chol_one_ended && bw + CH_NB - 1 <= CBF_MAXBW && n >= 8 * (bw + CH_NB);
@@ -887,7 +902,8 @@ struct BcrJob {
 // C[nblk - 1] = block (0, nblk - 1) closes the ring of blocks.
 __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, int bws, const double* __restrict__ b, int B,
                                    int nblk, const int* __restrict__ off, int cyclic, double* __restrict__ D,
-                                   double* __restrict__ C, double* __restrict__ bb, double* __restrict__ pend) {
+                                   double* __restrict__ C, double* __restrict__ bb, double* __restrict__ pend,
+                                   int* __restrict__ ok_out) {
   const int blk = blockIdx.y;
   const size_t BB = (size_t)B * B;
   const int o0 = off[blk], sz = off[blk + 1] - o0;
@@ -919,6 +935,7 @@ __global__ void bcr_extract_kernel(const double* __restrict__ A, int ld, int n, 
       pend[((size_t)2 * blk) * B + r] = 0.0;
       pend[((size_t)2 * blk + 1) * B + r] = 0.0;
     }
+  if (blk == 0 && blockIdx.x == 0 && threadIdx.x == 0) *ok_out = 1;  // (the factorisations clear it; this kernel does not read it)
 }
 
 // c0 += c1^T (ring of two blocks: both couplings join the same pair); out = in (the wrap coupling of an odd ring moves on)
@@ -1614,11 +1631,16 @@ __global__ __launch_bounds__(CBF_THREADS) void bcr_back_kernel(const BcrJob* __r
 }
 
 __global__ void bcr_gather_kernel(const double* __restrict__ bb, int B, const int* __restrict__ off, double* __restrict__ b,
-                                  const int* __restrict__ ok) {
+                                  double* __restrict__ neg_out, const int* __restrict__ ok) {
   if (!*ok) return;
   const int blk = blockIdx.y, o0 = off[blk], sz = off[blk + 1] - o0;
-  for (int r = threadIdx.x; r < sz; r += blockDim.x) b[o0 + r] = bb[(size_t)blk * B + r];
+  for (int r = threadIdx.x; r < sz; r += blockDim.x) {
+    const double v = bb[(size_t)blk * B + r];
+    b[o0 + r] = v;
+    if (neg_out) neg_out[o0 + r] = -v;
+  }
 }
+
 
 // Block layout of the cyclic form: nblk blocks of floor / ceil (n / nblk) unknowns, every one >= bw + 1 (a block couples
 // with its two ring neighbours only) and <= B (the kernels' block size, a multiple of 32 <= BCR_MAXB).  false: no such layout.
@@ -1640,7 +1662,7 @@ bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out) {
 // a RING -- the neighbour below the last block is the first one -- and every level halves the ring: an even ring's last
 // elimination creates the next ring's wrap coupling, an odd ring's wrap coupling moves on unchanged, a ring of two blocks
 // is one coupling (the sum of both) and ends as a chain.
-int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic) {
+int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic, double* neg_out) {
   int B = (bw + 1 + 31) / 32 * 32, nblk = (n + B - 1) / B;
   if (cyclic && !vsl_chol_bcr_cyclic_layout(n, bw, &B, &nblk))
     return vsl_fail(ctx, VSL_ERR_INVALID, "cyclic band of %d unknowns, half bandwidth %d: no block layout (the caller checks vsl_chol_bcr_cyclic_layout)", n, bw);
@@ -1759,8 +1781,6 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     tgt_off.push_back(tflat.size());
     tflat.insert(tflat.end(), tl.begin(), tl.end());
   }
-  static const int one = 1;
-  VSL_HIP(ctx, hipMemcpyAsync(ok_dev, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   const int key_bw = cyclic ? -2 - bw : bw;  // (one cache slot: the cyclic form of the same (n, bw) is another plan)
   if (ctx->bcr_key_n != n || ctx->bcr_key_bw != key_bw) {
     VSL_HIP(ctx, hipMemcpyAsync(jobs_dev, flat.data(), flat.size() * sizeof(BcrJob), hipMemcpyHostToDevice, ctx->stream));
@@ -1772,7 +1792,7 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     ctx->bcr_key_bw = key_bw;
   }
   hipStream_t q = ctx->stream;
-  hipLaunchKernelGGL(bcr_extract_kernel, dim3(64, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, off_dev, cyclic, D, K0, bb, pend);
+  hipLaunchKernelGGL(bcr_extract_kernel, dim3(64, nblk), dim3(256), 0, q, S, ld, n, ld, b, B, nblk, off_dev, cyclic, D, K0, bb, pend, ok_dev);
   const int tiles = B / 32;
   for (size_t l = 0; l < levels.size(); l++) {
     const int nj = (int)levels[l].size();
@@ -1811,7 +1831,7 @@ int vsl_chol_solve_bcr_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, in
     hipLaunchKernelGGL(bcr_back_gemv_kernel, dim3(nj, BCR_GV_CHUNKS), dim3(256), 0, q, jobs_dev + job_off[l], B, U, bb, yy, ok_dev);
     hipLaunchKernelGGL(bcr_back_kernel, dim3(nj), dim3(CBF_THREADS), 0, q, jobs_dev + job_off[l], B, D, Linv, bb, ok_dev);
   }
-  hipLaunchKernelGGL(bcr_gather_kernel, dim3(1, nblk), dim3(256), 0, q, bb, B, off_dev, b, ok_dev);
+  hipLaunchKernelGGL(bcr_gather_kernel, dim3(1, nblk), dim3(256), 0, q, bb, B, off_dev, b, neg_out, ok_dev);
   VSL_CHECK_LAUNCH(ctx);
   return VSL_OK;
 }

@@ -194,7 +194,7 @@ int vsl_set_pairs(vsl_ctx* ctx, vsl_frames* f, const int32_t* slot_pairs, int n_
 int vsl_chol_solve_dev(vsl_ctx* ctx, double* S, double* b, int n, int* ok_dev);
 // the same on LAPACK-style lower band storage (chol.hip, "BAND FORM"): S = storage + bws, ld = bws = bw + VSL_CHOL_NB
 #define VSL_CHOL_NB 32
-int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic = 0);
+int vsl_chol_solve_band_dev(vsl_ctx* ctx, double* S, double* b, int n, int ld, int bw, int* ok_dev, int cyclic = 0, double* neg_out = nullptr);
 bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out);  // chol.hip: is there a ring of blocks for this cyclic band?
 
 // scratch store of the host-buffer API
