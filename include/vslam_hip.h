@@ -441,6 +441,10 @@ int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int n, int hal
  * closed loop ordered along the trajectory): block cyclic reduction over a ring of blocks.  VSL_ERR_INVALID when the system
  * has no such block layout (fewer than 8 blocks of >= half_bandwidth + 1 unknowns). */
 int vsl_spd_solve_cyclic(vsl_ctx* ctx, const double* S, const double* b, int n, int half_bandwidth, double* x);
+/* Host-only (no device needed): 1 and the ring layout -- *block unknowns per solver block (a multiple of 32, <= 256),
+ * *n_blocks >= 8 blocks of floor / ceil (n / *n_blocks) >= half_bandwidth + 1 unknowns each -- when the cyclic solver takes
+ * such a system, 0 when it does not (the bundle adjustment then keeps the linear band form). */
+int vsl_bcr_cyclic_layout(int n, int half_bandwidth, int* block, int* n_blocks);
 
 /* ------------------------------------------------------------ pose graph optimisation */
 /*

@@ -44,6 +44,30 @@ def test_no_device_means_loud_failure(vsl):
         vsl.Context(0)
 
 
+def test_cyclic_ring_layout_of_the_band_solver(vsl):
+    # host logic of the ring solver (chol.hip, no device needed): whenever a layout is offered every block holds at least
+    # half_bandwidth + 1 unknowns (it couples with its two ring neighbours only), at most the kernels' block size, and the
+    # ring has at least 8 blocks; systems that are too short for that are refused (the caller keeps the linear band form)
+    lib = vsl.load()
+    B, nb = ctypes.c_int(), ctypes.c_int()
+    rng = np.random.default_rng(12)
+    offered = 0
+    for n, bw in [(5988, 83), (5988, 113), (5988, 221), (1040, 128), (1030, 128), (600, 100), (2048, 255), (2047, 255), (7, 1)] + \
+            [(int(a), int(b)) for a, b in zip(rng.integers(50, 20000, 300), rng.integers(1, 300, 300))]:
+        ok = lib.vsl_bcr_cyclic_layout(n, bw, ctypes.byref(B), ctypes.byref(nb))
+        most = n // (bw + 1)
+        if not ok:
+            # refused only when no ring of >= 8 blocks of <= 256 unknowns exists
+            assert most < 8 or -(-n // most) > 256 or bw + 1 > 256, (n, bw)
+            continue
+        offered += 1
+        assert B.value % 32 == 0 and bw + 1 <= B.value <= 256 and nb.value >= 8, (n, bw, B.value, nb.value)
+        sizes = np.diff([(i * n) // nb.value for i in range(nb.value + 1)])
+        assert sizes.sum() == n and sizes.min() >= bw + 1 and sizes.max() <= B.value, (n, bw, B.value, nb.value)
+    assert offered > 100
+    assert lib.vsl_bcr_cyclic_layout(5988, 83, ctypes.byref(B), ctypes.byref(nb)) == 1 and (B.value, nb.value) == (96, 63)
+
+
 def test_oracle_exports(orc):
     names = _declared("oracle/vslam_oracle.h")
     lib = orc.lib()

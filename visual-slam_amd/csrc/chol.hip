@@ -834,6 +834,18 @@ extern "C" int vsl_spd_solve(vsl_ctx* ctx, const double* S, const double* b, int
   return VSL_OK;
 }
 
+// Host-only query (no device needed): the ring layout the cyclic solver would use for n unknowns of half bandwidth
+// half_bandwidth -- *block = the kernels' block size, *n_blocks the ring length; returns 0 when there is none
+// (vsl_spd_solve_cyclic / the bundle adjustment then keep the linear band form).
+bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out);
+extern "C" int vsl_bcr_cyclic_layout(int n, int half_bandwidth, int* block, int* n_blocks) {
+  int B = 0, nb = 0;
+  if (n <= 0 || half_bandwidth < 0 || !vsl_chol_bcr_cyclic_layout(n, half_bandwidth, &B, &nb)) return 0;
+  if (block) *block = B;
+  if (n_blocks) *n_blocks = nb;
+  return 1;
+}
+
 // Test / diagnostic entry point for the CYCLIC band form: S (dense, row-major, symmetric) has non-zeros only where the
 // cyclic distance min(|i - j|, n - |i - j|) <= half_bandwidth.
 bool vsl_chol_bcr_cyclic_layout(int n, int bw, int* B_out, int* nblk_out);
