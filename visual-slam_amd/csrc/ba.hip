@@ -2669,7 +2669,7 @@ extern "C" int vsl_ba_session_download(vsl_ba_session* s, double* poses, double*
 // (include/visnav_amd/bundle_adjustment.h), a host hop for the gloo tests (visual-slam_amd/ba_dist.py) -- so the loop
 // itself does not depend on a communication library.  Policy = the [upstream] Ceres policy of vsl_bundle_adjust.
 // Per iteration: SUM of packB (the packed partial reduced camera system, band form when the cameras order into a band:
-// ~20 MB instead of 287 MB at 1000 cameras), MAX of one scalar after an accepted step, SUM of the 8 doubles of packC.
+// ~6 MB in the cyclic band form, ~12 MB in the linear one, instead of 287 MB at 1000 cameras), MAX of one scalar after an accepted step, SUM of the 8 doubles of packC.
 namespace {
 __global__ __launch_bounds__(1024) void sess_gmax_c_kernel(int n, const double* __restrict__ g_c, const double* __restrict__ scale_c,
                                                            const double* __restrict__ cost_in, const double* __restrict__ gl,
