@@ -34,7 +34,13 @@ def test_session_world1_matches_single_call_and_oracle(vsl, orc, synth):
     ctx = vsl.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     a_sess, a_one, a_cpu = _arr(orc, d), _arr(orc, d), _arr(orc, d)
     s = ba_dist.bundle_adjust_distributed(vsl, ctx, a_sess, max_iters=8)
-    s1 = ctx.bundle_adjust(a_one, max_iters=8)
+    # (the single call takes large maps through the session solver itself since round 4; "ba_no_fused" keeps it on the
+    # operator-by-operator chain over stored blocks: the independent path this test compares with)
+    ctx.set_diagnostic("ba_no_fused", 1)
+    try:
+        s1 = ctx.bundle_adjust(a_one, max_iters=8)
+    finally:
+        ctx.set_diagnostic("ba_no_fused", 0)
     s2 = orc.bundle_adjust(a_cpu, max_iters=8)
     assert (s.iterations, s.termination, s.successful_steps) == (s1.iterations, s1.termination, s1.successful_steps)
     assert (s.iterations, s.termination) == (s2.iterations, s2.termination)
@@ -91,7 +97,11 @@ def test_session_world2_gloo_shared_gpu(tmp_path, vsl, orc, synth, ctx):
     assert r0["meta"].tolist() == r1["meta"].tolist() and r0["meta"][3] == 2
     d = _problem(synth)
     one = _arr(orc, d)
-    s1 = ctx.bundle_adjust(one, max_iters=8)
+    ctx.set_diagnostic("ba_no_fused", 1)   # the stored-blocks single call: an independent path (see above)
+    try:
+        s1 = ctx.bundle_adjust(one, max_iters=8)
+    finally:
+        ctx.set_diagnostic("ba_no_fused", 0)
     assert r0["meta"][:3].tolist() == [s1.iterations, s1.termination, s1.successful_steps]
     assert r0["cost"][0] == pytest.approx(s1.initial_cost, rel=1e-12)
     assert r0["cost"][1] == pytest.approx(s1.final_cost, rel=1e-8)
@@ -220,9 +230,16 @@ def test_global_ba_full_size_properties(vsl, orc, synth):
     fixed = d["cam_fixed"].astype(bool)
     assert np.array_equal(a_band.poses[fixed], d["poses"][fixed])
     assert np.allclose(a_band.poses, a_dense.poses, rtol=0, atol=1e-6)
-    # single call == session path (both band)
+    # single call (the stored-blocks chain under "ba_no_fused"; by default it IS the session path) == session path
     a_one = _arr(orc, d)
-    s_one = c.bundle_adjust(a_one, max_iters=6)
+    c.set_diagnostic("ba_no_fused", 1)
+    try:
+        s_one = c.bundle_adjust(a_one, max_iters=6)
+    finally:
+        c.set_diagnostic("ba_no_fused", 0)
+    a_def = _arr(orc, d)
+    s_def = c.bundle_adjust(a_def, max_iters=6)
+    assert (s_def.iterations, s_def.termination, s_def.final_cost) == (s_band.iterations, s_band.termination, s_band.final_cost)
     assert (s_one.iterations, s_one.termination) == (s_band.iterations, s_band.termination)
     assert s_one.final_cost == pytest.approx(s_band.final_cost, rel=1e-9)
     c.close()

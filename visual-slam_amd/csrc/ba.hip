@@ -2121,6 +2121,15 @@ extern "C" int vsl_bundle_adjust(vsl_ctx* ctx, const vsl_ba_problem* prob, const
     int handled = 0;
     rc = vsl_ba_fused_solve(ctx, prob, opt, summary, &handled);
     if (rc || handled) return rc;
+    // Large maps (more free cameras than the fused window takes: the reduced system goes through the pair-list gather
+    // and the band solver): the session solver at world size 1 -- the recompute-form iteration of ba_large.h, the cyclic
+    // band form, one host round trip per iteration -- the same LM policy on the same numbers
+    // (tests/test_ba_dist_gpu.py::test_session_world1_matches_single_call_and_oracle).  What follows below remains for
+    // mid-size windows the fused kernels decline (more than 64 cameras, a landmark seen more than 64 times), for
+    // "ba_no_fused" and as the cross-check of both.
+    int nfree = 0;
+    for (int c = 0; c < prob->n_cams; c++) nfree += prob->cam_fixed[c] ? 0 : 1;
+    if (6 * nfree > 128) return vsl_global_bundle_adjust(ctx, prob, opt, nullptr, nullptr, 0, 1, summary);
   }
   const double t_start = now_ms();
   BaState st;
