@@ -37,6 +37,30 @@ def test_pose_graph_optimize_matches_the_oracle(ctx, orc, synth, seed, n_nodes, 
     assert np.array_equal(a.poses[-1], d["poses"][-1])   # the fixed node did not move
 
 
+@pytest.mark.parametrize("seed,n_nodes,window,noise", [(31, 400, 6, 0.002), (32, 500, 1, 0.003), (33, 120, 3, 0.002), (34, 300, 12, 0.001)])
+def test_banded_pose_graphs_take_the_band_solvers_and_match_the_oracle(ctx, orc, synth, seed, n_nodes, window, noise):
+    # graphs with odometry + covisibility edges inside a time window and the loop edge (no random long-range edges): the
+    # normal equations are kept in cyclic band storage and solved by the ring form of the block cyclic reduction (400 /
+    # 500 / 300 nodes), or in linear band storage when the ring has too few blocks (120 nodes) -- same LM trajectory as
+    # the oracle's dense solve, and as the dense device path
+    d = synth.pose_graph(seed, n_nodes, 0, meas_noise=noise, drift=0.02, window=window)
+    a, b, c = _arr(orc, d), _arr(orc, d), _arr(orc, d)
+    s = ctx.pose_graph_optimize(a, True, 1.0, 20)
+    os_ = orc.pose_graph_optimize(b, True, 1.0, 20)
+    assert s.iterations == os_.iterations and s.termination == os_.termination and s.successful_steps == os_.successful_steps
+    assert abs(s.initial_cost - os_.initial_cost) <= 1e-9 * max(1.0, os_.initial_cost)
+    assert abs(s.final_cost - os_.final_cost) <= 1e-6 * max(os_.final_cost, 1e-12) + 1e-15
+    assert np.abs(a.poses - b.poses).max() < 1e-7
+    assert s.final_cost < s.initial_cost
+    ctx.set_diagnostic("ba_force_dense", 1)
+    try:
+        sd = ctx.pose_graph_optimize(c, True, 1.0, 20)
+    finally:
+        ctx.set_diagnostic("ba_force_dense", 0)
+    assert (sd.iterations, sd.termination, sd.successful_steps) == (s.iterations, s.termination, s.successful_steps)
+    assert np.abs(a.poses - c.poses).max() < 1e-8
+
+
 def test_consistent_graph_converges_to_zero_cost(ctx, orc, synth):
     d = synth.pose_graph(31, 80, 30, meas_noise=0.0, drift=0.03)
     a = _arr(orc, d)

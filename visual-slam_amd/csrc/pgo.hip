@@ -247,27 +247,33 @@ __global__ void pgo_scale_kernel(int n, const double* __restrict__ colsq, double
 // One thread per (free node, row c of its 6 x 6 block row): row 6 nx + c of the scaled normal equations and entry
 // 6 nx + c of the gradient, accumulated over the node's incident edges in list order.  The thread is the only writer
 // of its row (H and g are zeroed before the launch).
+// Band forms (round 4): ld > 0 -- row i of H keeps its columns [i - (ld), i] at H[i * (ld + 1) + (j - i + ld)] (the
+// LAPACK-style lower band storage of chol.hip, ld = bandwidth + 32); the thread writes the entries at or left of the
+// diagonal (the mirror entries belong to the other endpoint's thread), and in the CYCLIC form (`cyclic`) the entries of
+// the wrap-around corner (j - i >= n - bw: nodes that are neighbours around the loop) as (i, j - n) in the leading slots
+// of its row.  ld = 0: dense, every entry.
 __global__ void pgo_build_kernel(int n_nodes, int n, const int* __restrict__ inc_off, const int* __restrict__ inc,
                                  const int* __restrict__ edge_a, const int* __restrict__ edge_b,
                                  const int* __restrict__ free_idx, const double* __restrict__ r, const double* __restrict__ Ja,
                                  const double* __restrict__ Jb, const double* __restrict__ scale, double* __restrict__ H,
-                                 double* __restrict__ g) {
+                                 double* __restrict__ g, int ld, int bw, int cyclic) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_nodes * 6) return;
   const int node = t / 6, c = t - node * 6;
   const int nx = free_idx[node];
   if (nx < 0) return;
   const double sx = scale[6 * nx + c];
-  double* __restrict__ Hrow = H + (size_t)(6 * nx + c) * n;
+  const int i = 6 * nx + c;
+  double* __restrict__ Hrow = ld > 0 ? H + (size_t)i * (ld + 1) + (ld - i) : H + (size_t)i * n;  // Hrow[j] = entry (i, j)
   double gacc = 0;
   for (int k = inc_off[node]; k < inc_off[node + 1]; k++) {
     const int e = inc[k] >> 1, x = inc[k] & 1;
     const double* Jx = (x ? Jb : Ja) + 36 * (size_t)e;
     const double* re = r + 6 * (size_t)e;
     double col[6], gv = 0;
-    for (int i = 0; i < 6; i++) {
-      col[i] = Jx[6 * i + c];
-      gv += col[i] * re[i];
+    for (int q = 0; q < 6; q++) {
+      col[q] = Jx[6 * q + c];
+      gv += col[q] * re[q];
     }
     gacc += sx * gv;
     for (int y = 0; y < 2; y++) {
@@ -275,13 +281,68 @@ __global__ void pgo_build_kernel(int n_nodes, int n, const int* __restrict__ inc
       if (ny < 0) continue;
       const double* Jy = (y ? Jb : Ja) + 36 * (size_t)e;
       for (int c2 = 0; c2 < 6; c2++) {
+        int j = 6 * ny + c2;
+        if (ld > 0) {
+          if (j > i) {
+            if (!(cyclic && j - i >= n - bw)) continue;  // the mirror entry is the other thread's
+            j -= n;                                        // wrap-around corner: column "below zero"
+          } else if (i - j > bw) {
+            continue;  // (cyclic: the far side of a wrap pair -- stored by the row of the smaller index)
+          }
+        }
         double hv = 0;
-        for (int i = 0; i < 6; i++) hv += col[i] * Jy[6 * i + c2];
-        Hrow[6 * ny + c2] += sx * scale[6 * ny + c2] * hv;
+        for (int q = 0; q < 6; q++) hv += col[q] * Jy[6 * q + c2];
+        Hrow[j] += sx * scale[6 * ny + c2] * hv;
       }
     }
   }
   g[6 * nx + c] = gacc;
+}
+
+// band forms: A = H (all s_elems slots) with the LM damping on the diagonal, b = -g, gabs
+__global__ void pgo_damp_band_kernel(int n, size_t elems, int ld, const double* __restrict__ H, const double* __restrict__ g,
+                                     const double* __restrict__ scale, double inv_radius, double* __restrict__ A,
+                                     double* __restrict__ b, double* __restrict__ gabs) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= elems) return;
+  double v = H[t];
+  const size_t row = t / (size_t)(ld + 1);
+  if (row < (size_t)n && t - row * (ld + 1) == (size_t)ld) {  // the diagonal slot of row `row`
+    v += fmin(fmax(v, 1e-6), 1e32) * inv_radius;
+    b[row] = -g[row];
+    gabs[row] = fabs(g[row] / scale[row]);
+  }
+  A[t] = v;
+}
+
+// band forms: the model cost change without H: d^T H d = sum over the edges of |Ja S_a d_a + Jb S_b d_b|^2.
+// part[e] = |J_e S d|^2 / 2 per edge; the gradient part -d_i g_i per unknown goes to part2 (flag cleared on a non-finite d_i)
+__global__ void pgo_model_edges_kernel(int n_edges, const int* __restrict__ edge_a, const int* __restrict__ edge_b,
+                                       const int* __restrict__ free_idx, const double* __restrict__ Ja,
+                                       const double* __restrict__ Jb, const double* __restrict__ scale,
+                                       const double* __restrict__ d, double* __restrict__ part) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int fa = free_idx[edge_a[e]], fb = free_idx[edge_b[e]];
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  // (H is the SCALED system S J^T J S and d its solution: the kernels' Ja / Jb are unscaled, build applies S -- so here)
+  for (int side = 0; side < 2; side++) {
+    const int f = side ? fb : fa;
+    if (f < 0) continue;
+    const double* J = (side ? Jb : Ja) + 36 * (size_t)e;
+    for (int q = 0; q < 6; q++)
+      for (int c = 0; c < 6; c++) v[q] += J[6 * q + c] * (scale[6 * f + c] * d[6 * f + c]);
+  }
+  double s = 0;
+  for (int q = 0; q < 6; q++) s += v[q] * v[q];
+  part[e] = 0.5 * s;
+}
+__global__ void pgo_model_grad_kernel(int n, const double* __restrict__ g, const double* __restrict__ d, double* __restrict__ part,
+                                      int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  part[i] = -d[i] * g[i];
+  if (!isfinite(d[i])) *flag = 0;
 }
 
 // A = H + diag(clamp(H_ii)) / radius, b = -g; gabs[i] = |g_i / scale_i|
@@ -407,6 +468,12 @@ static int pgo_validate(vsl_ctx* ctx, const vsl_pgo_problem* p) {
 namespace {
 struct PgoState {
   int N = 0, E = 0, n = 0;
+  // storage of the normal equations: dense (ld = 0) or, when the graph is narrow in the nodes' own order (keyframes in
+  // time order: odometry + covisibility edges, and the loop edge that closes the ring), lower band storage -- linear or
+  // CYCLIC (the band closes on itself; chol.hip's ring solver) -- with ld = bw + 32 slots left of the diagonal
+  int ld = 0, bw = 0, cyclic = 0;
+  size_t h_elems = 0;
+  bool force_dense = false;
   Buf poses, cand, free_idx, edge_a, edge_b, inc_off, inc, meas, r, Ja, Jb, cost, colsq, scale, H, g, A, b, gabs, part, part2, scalars, flag;
 };
 
@@ -418,6 +485,36 @@ int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
   for (int i = 0; i < st.N; i++)
     if (!p->node_fixed[i]) free_idx[i] = nf++;
   st.n = 6 * nf;
+  {
+    int lin = 0, cyc = 0;
+    for (int e = 0; e < st.E; e++) {
+      const int fa = free_idx[p->edge_a[e]], fb = free_idx[p->edge_b[e]];
+      if (fa < 0 || fb < 0) continue;
+      const int d = std::abs(fa - fb);
+      lin = std::max(lin, d);
+      cyc = std::max(cyc, std::min(d, nf - d));
+    }
+    const int bw_lin = 6 * lin + 5, bw_cyc = 6 * cyc + 5;
+    int Bc = 0, nc = 0;
+    static const bool env_dense = getenv("VSL_PGO_DENSE") != nullptr;
+    st.ld = 0;
+    st.h_elems = (size_t)st.n * st.n;
+    if (!st.force_dense && !env_dense && !ctx->ba_force_dense && st.n > 128) {
+      if (!ctx->chol_no_bcr && !ctx->chol_no_fused && 2 * bw_cyc < bw_lin && vsl_chol_bcr_cyclic_layout(st.n, bw_cyc, &Bc, &nc)) {
+        st.cyclic = 1;
+        st.bw = bw_cyc;
+      } else if ((size_t)(bw_lin + 33) * 2 < (size_t)st.n) {
+        st.cyclic = 0;
+        st.bw = bw_lin;
+      } else {
+        st.bw = 0;
+      }
+      if (st.bw > 0) {
+        st.ld = st.bw + 32;
+        st.h_elems = (size_t)st.n * (st.ld + 1) + 64;
+      }
+    }
+  }
   const size_t N = st.N, E = st.E, n = st.n;
   PGO_ALLOC(st.poses, 56 * N);
   PGO_ALLOC(st.cand, 56 * N);
@@ -433,13 +530,13 @@ int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
   PGO_ALLOC(st.cost, 8 * E);
   PGO_ALLOC(st.colsq, 8 * n);
   PGO_ALLOC(st.scale, 8 * n);
-  PGO_ALLOC(st.H, 8 * n * n);
+  PGO_ALLOC(st.H, 8 * st.h_elems);
   PGO_ALLOC(st.g, 8 * n);
-  PGO_ALLOC(st.A, 8 * n * n);
+  PGO_ALLOC(st.A, 8 * st.h_elems);
   PGO_ALLOC(st.b, 8 * n);
   PGO_ALLOC(st.gabs, 8 * n);
-  PGO_ALLOC(st.part, 8 * std::max(n, N));
-  PGO_ALLOC(st.part2, 8 * std::max(n, N));
+  PGO_ALLOC(st.part, 8 * std::max(std::max(n, N), E));
+  PGO_ALLOC(st.part2, 8 * std::max(std::max(n, N), E));
   PGO_ALLOC(st.scalars, 64);
   PGO_ALLOC(st.flag, 8);
   hipStream_t s = ctx->stream;
@@ -486,12 +583,12 @@ int pgo_linearize(vsl_ctx* ctx, PgoState& st, const vsl_ba_options* opt, bool fi
     hipLaunchKernelGGL(pgo_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, st.colsq.as<double>(), st.scale.as<double>());
   }
   if (n > 0) {
-    VSL_HIP(ctx, hipMemsetAsync(st.H.p, 0, 8 * (size_t)n * n, s));
+    VSL_HIP(ctx, hipMemsetAsync(st.H.p, 0, 8 * st.h_elems, s));
     VSL_HIP(ctx, hipMemsetAsync(st.g.p, 0, 8 * (size_t)n, s));
     if (st.N > 0)
       hipLaunchKernelGGL(pgo_build_kernel, dim3((st.N * 6 + 255) / 256), dim3(256), 0, s, st.N, n, st.inc_off.as<int>(), st.inc.as<int>(),
                          st.edge_a.as<int>(), st.edge_b.as<int>(), st.free_idx.as<int>(), st.r.as<double>(), st.Ja.as<double>(),
-                         st.Jb.as<double>(), st.scale.as<double>(), st.H.as<double>(), st.g.as<double>());
+                         st.Jb.as<double>(), st.scale.as<double>(), st.H.as<double>(), st.g.as<double>(), st.ld, st.bw, st.cyclic);
   }
   hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.cost.as<double>(), E, st.scalars.as<double>(), 0);
   VSL_CHECK_LAUNCH(ctx);
@@ -510,6 +607,7 @@ extern "C" int vsl_pgo_linearize(vsl_ctx* ctx, const vsl_pgo_problem* prob, cons
   if (!opt) return vsl_fail(ctx, VSL_ERR_INVALID, "vsl_pgo_linearize: options are null");
   VSL_HIP(ctx, hipSetDevice(ctx->device));
   PgoState st;
+  st.force_dense = true;  // (the hook returns H as a dense matrix)
   if ((rc = pgo_setup(ctx, prob, st))) return rc;
   // unit scaling: fill scale with ones by pretending every column norm is zero
   if (st.n > 0) {
@@ -549,8 +647,13 @@ extern "C" int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob
     if (radius <= 1e-32) { sum.termination = 4; break; }
     if (n == 0) { sum.termination = 2; break; }
     // damped system + gradient norm
-    hipLaunchKernelGGL(pgo_damp_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, n, st.H.as<double>(), st.g.as<double>(),
-                       st.scale.as<double>(), 1.0 / radius, st.A.as<double>(), st.b.as<double>(), st.gabs.as<double>());
+    if (st.ld > 0)
+      hipLaunchKernelGGL(pgo_damp_band_kernel, dim3((unsigned)((st.h_elems + 255) / 256)), dim3(256), 0, s, n, st.h_elems, st.ld,
+                         st.H.as<double>(), st.g.as<double>(), st.scale.as<double>(), 1.0 / radius, st.A.as<double>(), st.b.as<double>(),
+                         st.gabs.as<double>());
+    else
+      hipLaunchKernelGGL(pgo_damp_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, n, st.H.as<double>(), st.g.as<double>(),
+                         st.scale.as<double>(), 1.0 / radius, st.A.as<double>(), st.b.as<double>(), st.gabs.as<double>());
     if (need_gmax) {
       hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.gabs.as<double>(), n, st.scalars.as<double>() + 1, 1);
       VSL_CHECK_LAUNCH(ctx);
@@ -560,18 +663,32 @@ extern "C" int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob
       if (gmax <= 1e-10) { sum.termination = 2; break; }
     }
     it++;
-    if ((rc = vsl_chol_solve_dev(ctx, st.A.as<double>(), st.b.as<double>(), n, st.flag.as<int>()))) return rc;
+    if (st.ld > 0)
+      rc = vsl_chol_solve_band_dev(ctx, st.A.as<double>() + st.ld, st.b.as<double>(), n, st.ld, st.bw, st.flag.as<int>(), st.cyclic);
+    else
+      rc = vsl_chol_solve_dev(ctx, st.A.as<double>(), st.b.as<double>(), n, st.flag.as<int>());
+    if (rc) return rc;
     int spd = 1;
     VSL_HIP(ctx, hipMemcpyAsync(&spd, st.flag.p, 4, hipMemcpyDeviceToHost, s));
     VSL_HIP(ctx, hipStreamSynchronize(s));
     bool ok = spd != 0;
-    double sc[4] = {0, 0, 0, 0};
+    double sc[5] = {0, 0, 0, 0, 0};  // model (gradient part in band form) | step^2 | x^2 | candidate cost | band form: sum |J S d|^2 / 2
     int finite = 1;
     if (ok) {
       const int one = 1;
       VSL_HIP(ctx, hipMemcpyAsync(st.flag.p, &one, 4, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(pgo_model_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, st.H.as<double>(), st.g.as<double>(),
-                         st.b.as<double>(), st.part.as<double>(), st.flag.as<int>());
+      if (st.ld > 0) {
+        // model change = sum_i -d_i g_i - sum_e |J_e S d|^2 / 2 (no product with H: the band keeps one triangle only)
+        hipLaunchKernelGGL(pgo_model_edges_kernel, dim3((E + 255) / 256 > 0 ? (E + 255) / 256 : 1), dim3(256), 0, s, E, st.edge_a.as<int>(),
+                           st.edge_b.as<int>(), st.free_idx.as<int>(), st.Ja.as<double>(), st.Jb.as<double>(), st.scale.as<double>(),
+                           st.b.as<double>(), st.part2.as<double>());
+        hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.part2.as<double>(), E, st.scalars.as<double>() + 6, 0);
+        hipLaunchKernelGGL(pgo_model_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, st.g.as<double>(), st.b.as<double>(),
+                           st.part.as<double>(), st.flag.as<int>());
+      } else {
+        hipLaunchKernelGGL(pgo_model_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, st.H.as<double>(), st.g.as<double>(),
+                           st.b.as<double>(), st.part.as<double>(), st.flag.as<int>());
+      }
       hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.part.as<double>(), n, st.scalars.as<double>() + 2, 0);
       hipLaunchKernelGGL(pgo_update_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, st.free_idx.as<int>(), st.poses.as<double>(),
                          st.b.as<double>(), st.scale.as<double>(), st.cand.as<double>(), st.part.as<double>(), st.part2.as<double>());
@@ -583,9 +700,10 @@ extern "C" int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob
                            (double*)nullptr, (double*)nullptr, st.cost.as<double>());
       hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.cost.as<double>(), E, st.scalars.as<double>() + 5, 0);
       VSL_CHECK_LAUNCH(ctx);
-      VSL_HIP(ctx, hipMemcpyAsync(sc, st.scalars.as<double>() + 2, 32, hipMemcpyDeviceToHost, s));
+      VSL_HIP(ctx, hipMemcpyAsync(sc, st.scalars.as<double>() + 2, 40, hipMemcpyDeviceToHost, s));
       VSL_HIP(ctx, hipMemcpyAsync(&finite, st.flag.p, 4, hipMemcpyDeviceToHost, s));
       VSL_HIP(ctx, hipStreamSynchronize(s));
+      if (st.ld > 0) sc[0] -= sc[4];
       ok = finite != 0 && sc[0] > 0.0;
     }
     if (!ok) {

@@ -304,7 +304,7 @@ def write_vocabulary_text(path, k, L, parent, is_leaf, desc, weight, chunk=65536
             f.write("\n")
 
 
-def pose_graph(seed, n_nodes=60, n_loop_edges=25, meas_noise=0.0, drift=0.02, outlier_edges=0):
+def pose_graph(seed, n_nodes=60, n_loop_edges=25, meas_noise=0.0, drift=0.02, outlier_edges=0, window=0):
     """Keyframe poses on a noisy loop + relative-pose edges (loop_closure_utils.h:446-587: spanning-tree edges
     between consecutive keyframes, covisibility edges, one loop constraint).  Returns a dict with
     poses_gt / poses (drifted initial guess) [N, 7] (qx qy qz qw tx ty tz), node_fixed [N], edge_a, edge_b [E]
@@ -355,6 +355,17 @@ def pose_graph(seed, n_nodes=60, n_loop_edges=25, meas_noise=0.0, drift=0.02, ou
         b = int(rng.integers(0, a - 1))
         ea.append(a)
         eb.append(b)
+    # covisibility edges the way the reference's pose graph has them (keyframes within `window` of each other in time
+    # order, and around the closed loop): a graph whose normal equations are a narrow CYCLIC band
+    for j in range(2, window + 1):
+        for k in range(n_nodes):
+            a, b = k, k - j
+            if b < 0:
+                a, b = k - j + n_nodes, k      # across the seam of the loop (newer keyframe first)
+                if a <= b + 1:
+                    continue
+            ea.append(a)
+            eb.append(b)
     ea.append(n_nodes - 1)  # the loop constraint
     eb.append(0)
     meas = np.array([log(mul(inv(gt[a]), gt[b])) for a, b in zip(ea, eb)])
