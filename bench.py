@@ -900,6 +900,47 @@ def main():
                     "note": "latency- and fp64-compute-bound, not bandwidth-bound: the solve is log2(n / B) dependent levels of "
                             "dense 224-block factorisations (DESIGN 8.4)"}
 
+        # ---- pose graph optimisation at BASELINE configs[4] scale ("loop-closure pose-graph, ~500 keyframes"): odometry +
+        # covisibility edges inside a window of six keyframes + the loop edge -- the shape pose_graph_optimization builds
+        # (loop_closure_utils.h:446-587); the normal equations are a narrow CYCLIC band, solved by the ring solver
+        if args.gba and world == 1:
+            import types
+            dpg = synth.pose_graph(5, 500, 0, meas_noise=0.002, drift=0.02, window=6)
+
+            def mk_pg():
+                return types.SimpleNamespace(poses=np.ascontiguousarray(dpg["poses"], np.float64).copy(),
+                                             node_fixed=np.ascontiguousarray(dpg["node_fixed"], np.uint8),
+                                             edge_a=np.ascontiguousarray(dpg["edge_a"], np.int32),
+                                             edge_b=np.ascontiguousarray(dpg["edge_b"], np.int32),
+                                             edge_meas=np.ascontiguousarray(dpg["edge_meas"], np.float64))
+
+            pg = {}
+            for form, dense in (("band", 0), ("dense", 1)):
+                ctx.set_diagnostic("ba_force_dense", dense)
+                try:
+                    ctx.pose_graph_optimize(mk_pg(), True, 1.0, 3)
+                    best = None
+                    for _ in range(3 if not dense else 1):
+                        apg = mk_pg()
+                        ctx.synchronize()
+                        t0 = time.perf_counter()
+                        spg = ctx.pose_graph_optimize(apg, True, 1.0, 20)
+                        dt = 1e3 * (time.perf_counter() - t0)
+                        best = dt if best is None else min(best, dt)
+                    pg[form] = (best, spg)
+                finally:
+                    ctx.set_diagnostic("ba_force_dense", 0)
+            (tb, sb), (td, sd) = pg["band"], pg["dense"]
+            out["pose_graph"] = {"workload": "500 keyframes on a loop (1 fixed), %d relative-pose edges (odometry, covisibility window 6, loop edge), "
+                                             "Huber 1.0, <= 20 LM iterations; normal equations 2994 x 2994 in cyclic band storage" % len(dpg["edge_a"]),
+                                 "iterations": sb.iterations, "ms_per_lm_iteration": round(tb / max(sb.iterations, 1), 3),
+                                 "ms_total_incl_setup": round(tb, 2),
+                                 "dense_solver_ms_per_lm_iteration": round(td / max(sd.iterations, 1), 3),
+                                 "same_trajectory_as_dense": (sb.iterations, sb.termination) == (sd.iterations, sd.termination),
+                                 "final_cost_rel_diff_vs_dense": abs(sb.final_cost - sd.final_cost) / max(sd.final_cost, 1e-300),
+                                 "note": "the host takes the LM decision with four synchronisations per iteration (a small problem: "
+                                         "~0.1 ms of kernels); the reference hands this to Ceres (SPARSE_NORMAL_CHOLESKY)"}
+
         # ---- BoW (K8 / K9) at the reference's vocabulary shape; the vocabulary file also serves the end-to-end legs
         voc_path = None
         if (args.bow or args.e2e) and world == 1:

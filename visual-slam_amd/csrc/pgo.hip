@@ -437,8 +437,9 @@ __global__ __launch_bounds__(256) void pgo_reduce_kernel(const double* __restric
 
 struct Buf {
   void* p = nullptr;
+  bool owned = true;  // (PgoState carves its buffers out of ONE allocation: 23 hipMalloc / hipFree pairs were ~1 ms of a 3 ms solve)
   ~Buf() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
   }
   template <class T>
   T* as() {
@@ -448,11 +449,8 @@ struct Buf {
 
 }  // namespace
 
-#define PGO_ALLOC(buf, bytes)                                                                              \
-  do {                                                                                                     \
-    if (hipMalloc(&(buf).p, (bytes) > 0 ? (bytes) : 8) != hipSuccess)                                      \
-      return vsl_fail(ctx, VSL_ERR_NOMEM, "vsl_pose_graph_optimize: device allocation of %zu bytes failed", (size_t)(bytes)); \
-  } while (0)
+// (buffers of a solve: sizes collected first, ONE device allocation, carved in 256-byte steps)
+#define PGO_ALLOC(buf, bytes) want.push_back({&(buf), (size_t)(bytes)})
 
 static int pgo_validate(vsl_ctx* ctx, const vsl_pgo_problem* p) {
   if (!ctx) return VSL_ERR_INVALID;
@@ -474,6 +472,7 @@ struct PgoState {
   int ld = 0, bw = 0, cyclic = 0;
   size_t h_elems = 0;
   bool force_dense = false;
+  Buf arena;
   Buf poses, cand, free_idx, edge_a, edge_b, inc_off, inc, meas, r, Ja, Jb, cost, colsq, scale, H, g, A, b, gabs, part, part2, scalars, flag;
 };
 
@@ -516,6 +515,8 @@ int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
     }
   }
   const size_t N = st.N, E = st.E, n = st.n;
+  struct Want { Buf* b; size_t bytes; };
+  std::vector<Want> want;
   PGO_ALLOC(st.poses, 56 * N);
   PGO_ALLOC(st.cand, 56 * N);
   PGO_ALLOC(st.free_idx, 4 * N);
@@ -539,6 +540,18 @@ int pgo_setup(vsl_ctx* ctx, const vsl_pgo_problem* p, PgoState& st) {
   PGO_ALLOC(st.part2, 8 * std::max(std::max(n, N), E));
   PGO_ALLOC(st.scalars, 64);
   PGO_ALLOC(st.flag, 8);
+  {
+    size_t total = 0;
+    for (auto& w : want) total += (std::max<size_t>(w.bytes, 8) + 255) & ~(size_t)255;
+    if (hipMalloc(&st.arena.p, total) != hipSuccess)
+      return vsl_fail(ctx, VSL_ERR_NOMEM, "vsl_pose_graph_optimize: device allocation of %zu bytes failed", total);
+    size_t off = 0;
+    for (auto& w : want) {
+      w.b->p = (char*)st.arena.p + off;
+      w.b->owned = false;
+      off += (std::max<size_t>(w.bytes, 8) + 255) & ~(size_t)255;
+    }
+  }
   hipStream_t s = ctx->stream;
   if (N) VSL_HIP(ctx, hipMemcpyAsync(st.poses.p, p->poses, 56 * N, hipMemcpyHostToDevice, s));
   if (N) VSL_HIP(ctx, hipMemcpyAsync(st.free_idx.p, free_idx.data(), 4 * N, hipMemcpyHostToDevice, s));
@@ -654,13 +667,12 @@ extern "C" int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob
     else
       hipLaunchKernelGGL(pgo_damp_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, n, st.H.as<double>(), st.g.as<double>(),
                          st.scale.as<double>(), 1.0 / radius, st.A.as<double>(), st.b.as<double>(), st.gabs.as<double>());
+    const bool gmax_pending = need_gmax;
     if (need_gmax) {
+      // max |gradient| of this linearisation: reduced here, READ with the step's scalars below (round 4: one host round
+      // trip per iteration instead of three -- a gradient below tolerance is found one step late and that step is dropped)
       hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.gabs.as<double>(), n, st.scalars.as<double>() + 1, 1);
-      VSL_CHECK_LAUNCH(ctx);
-      VSL_HIP(ctx, hipMemcpyAsync(&gmax, st.scalars.as<double>() + 1, 8, hipMemcpyDeviceToHost, s));
-      VSL_HIP(ctx, hipStreamSynchronize(s));
       need_gmax = false;
-      if (gmax <= 1e-10) { sum.termination = 2; break; }
     }
     it++;
     if (st.ld > 0)
@@ -668,15 +680,11 @@ extern "C" int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob
     else
       rc = vsl_chol_solve_dev(ctx, st.A.as<double>(), st.b.as<double>(), n, st.flag.as<int>());
     if (rc) return rc;
-    int spd = 1;
-    VSL_HIP(ctx, hipMemcpyAsync(&spd, st.flag.p, 4, hipMemcpyDeviceToHost, s));
-    VSL_HIP(ctx, hipStreamSynchronize(s));
-    bool ok = spd != 0;
-    double sc[5] = {0, 0, 0, 0, 0};  // model (gradient part in band form) | step^2 | x^2 | candidate cost | band form: sum |J S d|^2 / 2
+    // (the factorisation leaves flag = 1 on success, 0 on a bad pivot; the kernels below only ever CLEAR it -- on a
+    // non-finite step --, so one read at the end tells both; after a failed factorisation they run on numbers nobody uses)
+    double sc[6] = {0, 0, 0, 0, 0, 0};  // |g| max | model (gradient part in band form) | step^2 | x^2 | candidate cost | band form: sum |J S d|^2 / 2
     int finite = 1;
-    if (ok) {
-      const int one = 1;
-      VSL_HIP(ctx, hipMemcpyAsync(st.flag.p, &one, 4, hipMemcpyHostToDevice, s));
+    {
       if (st.ld > 0) {
         // model change = sum_i -d_i g_i - sum_e |J_e S d|^2 / 2 (no product with H: the band keeps one triangle only)
         hipLaunchKernelGGL(pgo_model_edges_kernel, dim3((E + 255) / 256 > 0 ? (E + 255) / 256 : 1), dim3(256), 0, s, E, st.edge_a.as<int>(),
@@ -700,19 +708,27 @@ extern "C" int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob
                            (double*)nullptr, (double*)nullptr, st.cost.as<double>());
       hipLaunchKernelGGL(pgo_reduce_kernel, dim3(1), dim3(256), 0, s, st.cost.as<double>(), E, st.scalars.as<double>() + 5, 0);
       VSL_CHECK_LAUNCH(ctx);
-      VSL_HIP(ctx, hipMemcpyAsync(sc, st.scalars.as<double>() + 2, 40, hipMemcpyDeviceToHost, s));
+      VSL_HIP(ctx, hipMemcpyAsync(sc, st.scalars.as<double>() + 1, 48, hipMemcpyDeviceToHost, s));
       VSL_HIP(ctx, hipMemcpyAsync(&finite, st.flag.p, 4, hipMemcpyDeviceToHost, s));
       VSL_HIP(ctx, hipStreamSynchronize(s));
-      if (st.ld > 0) sc[0] -= sc[4];
-      ok = finite != 0 && sc[0] > 0.0;
     }
+    if (gmax_pending) {
+      gmax = sc[0];
+      if (gmax <= 1e-10) {
+        it--;
+        sum.termination = 2;
+        break;
+      }
+    }
+    if (st.ld > 0) sc[1] -= sc[5];
+    const bool ok = finite != 0 && sc[1] > 0.0;
     if (!ok) {
       if (++invalid >= 5) { sum.termination = 4; break; }
       radius *= 0.5;
       continue;
     }
     invalid = 0;
-    const double model = sc[0], step_norm = sqrt(sc[1]), x_norm = sqrt(sc[2]), cand_cost = sc[3];
+    const double model = sc[1], step_norm = sqrt(sc[2]), x_norm = sqrt(sc[3]), cand_cost = sc[4];
     if (step_norm <= 1e-8 * (x_norm + 1e-8)) { sum.termination = 3; break; }
     const double change = cost - cand_cost;
     if (fabs(change) <= 1e-6 * cost) { sum.termination = 1; break; }
