@@ -465,6 +465,9 @@ typedef struct vsl_pgo_problem {
   const int32_t* edge_b;     /* [n_edges] the functor's T_w_n */
   const double* edge_meas;   /* [n_edges][6] upsilon, omega */
 } vsl_pgo_problem;
+/* The normal equations are kept dense, or -- when the graph is narrow in the nodes' own order (keyframes in time order:
+ * odometry + covisibility edges, and the loop edge that closes the ring) -- in linear / cyclic band storage and solved by
+ * the band / ring solvers of the reduced camera system (diagnostic "ba_force_dense" / VSL_PGO_DENSE: always dense). */
 int vsl_pose_graph_optimize(vsl_ctx* ctx, const vsl_pgo_problem* prob, const vsl_ba_options* opt, vsl_ba_summary* summary);
 /* Test hook: H = J^T J (n x n row-major, n = 6 x free nodes in node order), g = J^T r and the cost of the
  * robustified problem at the given poses. */
