@@ -810,6 +810,8 @@ __global__ __launch_bounds__(256) void ba_schur_prep_kernel(BaDims D, const int*
 // 64th pair of the list -- both 144-byte blocks with 16-byte loads, all 36 products -- so 64 pairs' loads are in flight
 // at once (one pair per iteration with the 36 entries over the lanes was bound by the latency of the dependent loads
 // pair -> W / Y: 0.85 ms per iteration at 4.4 M pairs); the 36 x 64 partial sums are folded through LDS in lane order.
+// (Sessions in the recompute form pass ONE array for both operands: the block Z = F^T E chol(P^-1) of ba_large.h, with
+// Y_i W_j^T = Z_i Z_j^T.)
 // The blocks of a round's 64 pairs are FETCHED COOPERATIVELY (round 4): the 128 blocks are 1152 pieces of 16 bytes,
 // piece m = 64 t + lane belongs to block m / 9, so nine consecutive lanes read one contiguous 144-byte block and an
 // instruction touches ~10 cache lines; they land in LDS at double2[m] (linear, conflict-free) and every lane reads its

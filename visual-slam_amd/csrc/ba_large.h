@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void bal_cam_kernel(BlArgs a, const int* __res
 
 // segments summed in order: H (6 x 6, both triangles), g_c, and rhs = -(sum Y b) (the camera blocks are added to S
 // afterwards).  The LAST workgroup also folds bal_prep_kernel's per-workgroup (cost, max |landmark gradient|) into
-// scalars[0] / gl_out[0] (lpart given: what bal_prep_finish_kernel does as a launch of its own).
+// scalars[0] / gl_out[0] (lpart given; it was a one-workgroup launch of its own).
 __global__ __launch_bounds__(256) void bal_cam_finish_kernel(int nfree, int nseg, int with_rhs, const double* __restrict__ part,
                                                              double* __restrict__ H, double* __restrict__ g,
                                                              double* __restrict__ rhs, int G, const double* __restrict__ lpart,
