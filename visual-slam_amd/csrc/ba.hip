@@ -1412,14 +1412,17 @@ int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free
       if (i > 0 && gp->obs_lm[i] < gp->obs_lm[i - 1]) sorted_in = false;
     }
     for (int l = 0; l < gp->n_lms; l++) start[l + 1] += start[l];
-    // free-camera index of every observation in landmark order (the reference's own order is landmark order already)
-    std::vector<int> cams(gp->n_obs);
-    if (sorted_in) {
-      for (int i = 0; i < gp->n_obs; i++) cams[i] = cam_free0[gp->obs_cam[i]];
-    } else {
+    // free-camera index of every observation in landmark order; the reference's own order is landmark order already:
+    // then the threads below look the cameras up themselves (no gathered copy)
+    std::vector<int> cams_v;
+    if (!sorted_in) {
+      cams_v.resize(gp->n_obs);
       std::vector<int> fill(start.begin(), start.end() - 1);
-      for (int i = 0; i < gp->n_obs; i++) cams[fill[gp->obs_lm[i]]++] = cam_free0[gp->obs_cam[i]];
+      for (int i = 0; i < gp->n_obs; i++) cams_v[fill[gp->obs_lm[i]]++] = cam_free0[gp->obs_cam[i]];
     }
+    const int* cams_p = sorted_in ? nullptr : cams_v.data();
+    const int32_t* ocam = gp->obs_cam;
+    auto cam_at = [&](int a) { return cams_p ? cams_p[a] : cam_free0[ocam[a]]; };
     // a private bit matrix per thread, OR-ed together afterwards (shared atomics made the threads fight over its lines)
     std::vector<std::vector<uint64_t>> priv(8);
     host_parallel(gp->n_lms, [&](int l0, int l1, int t) {
@@ -1427,10 +1430,10 @@ int camera_band_order(const vsl_ba_problem* gp, const std::vector<int>& cam_free
       my.assign((size_t)nfree * words, 0);
       for (int l = l0; l < l1; l++)
         for (int a = start[l]; a < start[l + 1]; a++) {
-          const int ca = cams[a];
+          const int ca = cam_at(a);
           if (ca < 0) continue;
           for (int b = a + 1; b < start[l + 1]; b++) {
-            const int cb = cams[b];
+            const int cb = cam_at(b);
             if (cb < 0 || cb == ca) continue;
             my[(size_t)ca * words + (cb >> 6)] |= 1ull << (cb & 63);
             my[(size_t)cb * words + (ca >> 6)] |= 1ull << (ca & 63);
