@@ -230,6 +230,17 @@ def test_global_ba_full_size_properties(vsl, orc, synth):
     fixed = d["cam_fixed"].astype(bool)
     assert np.array_equal(a_band.poses[fixed], d["poses"][fixed])
     assert np.allclose(a_band.poses, a_dense.poses, rtol=0, atol=1e-6)
+    # observations in ARBITRARY order (the set-up then sorts them by landmark and builds its indices on several host
+    # threads): the same optimisation
+    perm = np.random.default_rng(3).permutation(len(d["obs_cam"]))
+    d_sh = dict(d)
+    for k in ("obs_cam", "obs_lm", "obs_uv"):
+        d_sh[k] = np.ascontiguousarray(d[k][perm])
+    a_sh = _arr(orc, d_sh)
+    s_sh = ba_dist.bundle_adjust_distributed(vsl, c, a_sh, max_iters=6)
+    assert (s_sh.iterations, s_sh.termination, s_sh.successful_steps) == (s_band.iterations, s_band.termination, s_band.successful_steps)
+    assert s_sh.final_cost == pytest.approx(s_band.final_cost, rel=1e-9)
+    assert np.allclose(a_sh.poses, a_band.poses, rtol=0, atol=1e-7)
     # single call (the stored-blocks chain under "ba_no_fused"; by default it IS the session path) == session path
     a_one = _arr(orc, d)
     c.set_diagnostic("ba_no_fused", 1)
